@@ -1,0 +1,200 @@
+"""The oracle against the golden vectors captured from the reference's own
+modules (tests/golden/capture_goldens.py).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import penet_oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from scene_image import pattern_image  # noqa: E402
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _calib_from_text(tmp_path, text_u8, name="c.txt"):
+    p = tmp_path / name
+    p.write_bytes(bytes(text_u8))
+    return O.Calibration(str(p))
+
+
+# ---------------------------------------------------------------- G1
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g1_calibration(golden_dir, tmp_path, tag):
+    g = _load(golden_dir, "g1_calib.npz")
+    c = _calib_from_text(tmp_path, g[tag + "_text"])
+    assert np.array_equal(c.P2, g[tag + "_P2"])
+    assert np.array_equal(c.R0, g[tag + "_R0"])
+    assert np.array_equal(c.V2C, g[tag + "_V2C"])
+    scal = np.array([c.cu, c.cv, c.fu, c.fv, c.tx, c.ty], np.float32)
+    assert np.array_equal(scal, g[tag + "_scal"])
+    # fp32 chain: bit-exact against the reference's numpy/BLAS result
+    rect = c.lidar_to_rect(g[tag + "_pts32"])
+    assert rect.dtype == np.float32
+    assert np.array_equal(rect, g[tag + "_rect32"])
+    img, dep = c.rect_to_img(rect)
+    assert np.array_equal(img, g[tag + "_img32"])
+    assert np.array_equal(dep, g[tag + "_dep32"])
+    img_b, dep_b = c.lidar_to_img(g[tag + "_pts32"])
+    assert np.array_equal(img_b, g[tag + "_img_b"])
+    assert np.array_equal(dep_b, g[tag + "_dep_b"])
+    fov = O.get_fov_flag(rect, (900, 1600), c)
+    assert np.array_equal(fov, g[tag + "_fov"])
+    # fp64 paths
+    r64 = c.lidar_to_rect(g[tag + "_pts64"])
+    assert r64.dtype == np.float64
+    np.testing.assert_allclose(r64, g[tag + "_rect64"], rtol=1e-13, atol=1e-12)
+    prect = c.img_to_rect(g[tag + "_u"], g[tag + "_v"], g[tag + "_d"])
+    assert prect.dtype == np.float64
+    assert np.array_equal(prect, g[tag + "_prect"])     # elementwise IEEE ops
+    plid = c.rect_to_lidar(prect)
+    np.testing.assert_allclose(plid, g[tag + "_plid"], rtol=1e-13, atol=1e-12)
+
+
+def test_fp32_chain_matches_numpy_sgemm():
+    """The explicit FMA chain is what np.dot does for (n,4)@(4,3) float32."""
+    rng = np.random.default_rng(5)
+    V2C = rng.normal(0, 1, (3, 4)).astype(np.float32)
+    R0 = (np.eye(3) + rng.normal(0, 0.01, (3, 3))).astype(np.float32)
+    P2 = rng.normal(0, 500, (3, 4)).astype(np.float32)
+    c = O.Calibration({"P2": P2, "R0": R0, "Tr_velo2cam": V2C})
+    assert np.array_equal(c.M43, np.dot(V2C.T, R0.T))
+    pts = rng.normal(0, 30, (50000, 3)).astype(np.float32)
+    hom = np.hstack([pts, np.ones((pts.shape[0], 1), np.float32)])
+    rect = c.lidar_to_rect(pts)
+    assert np.array_equal(rect, np.dot(hom, np.dot(V2C.T, R0.T)))
+    hom2 = np.hstack([rect, np.ones((pts.shape[0], 1), np.float32)])
+    h = np.dot(hom2, P2.T)
+    img, dep = c.rect_to_img(rect)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(img, (h[:, 0:2].T / hom2[:, 2]).T, equal_nan=True)
+    assert np.array_equal(dep, h[:, 2] - P2.T[3, 2])
+
+
+# ---------------------------------------------------------------- G2
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_g2_above_plane(golden_dir, k):
+    g = _load(golden_dir, "g2_plane.npz")
+    pts, plane = g["pts%d" % k], g["plane%d" % k]
+    d = O.distance_to_plane(pts[:, :3], plane, directional=True)
+    np.testing.assert_allclose(d, g["dist%d" % k], rtol=1e-12, atol=1e-13)
+    assert np.array_equal(O.above_plane(pts[:, :3], plane), g["mask%d" % k])
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_g2_seeded_ransac_statistically_matches_sklearn(golden_dir, k):
+    """H1: our seeded RANSAC vs the reference's sklearn fit (np.random.seed(0))."""
+    g = _load(golden_dir, "g2_plane.npz")
+    pts, ref_plane = g["pts%d" % k], g["plane%d" % k]
+    ours = O.plane_ransac(pts[:, :3], O.Params(), key=k)
+    assert abs(np.linalg.norm(ours[:3]) - 1) < 1e-12 and ours[2] > 0
+    ang = np.degrees(np.arccos(np.clip(ours[:3] @ ref_plane[:3], -1, 1)))
+    assert ang < 0.1
+    assert abs(ours[3] - ref_plane[3]) < 0.03
+    m_ref = g["mask%d" % k]
+    m = O.above_plane(pts[:, :3], ours)
+    assert (m != m_ref).mean() < 0.03
+
+
+# ---------------------------------------------------------------- G4
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_g4_ballquery(golden_dir, k):
+    g = _load(golden_dir, "g4_ballquery.npz")
+    m = O.ball_query(g["p1_%d" % k], g["p2_%d" % k], 0.1)
+    assert np.array_equal(m, g["mask%d" % k])
+
+
+# ---------------------------------------------------------------- G5 / G6
+def _g5_names(g):
+    return [k[3:] for k in g.files if k.startswith("xy_")]
+
+
+def test_g5_clusters_and_rectangles(golden_dir):
+    g = _load(golden_dir, "g5_lshape.npz")
+    for name in _g5_names(g):
+        xy = g["xy_" + name]
+        clusters = O.range_segmentation(xy[:, 0], xy[:, 1])
+        assert len(clusters) == int(g["nclu_" + name]), name
+        lab = np.full((xy.shape[0],), -1, np.int64)
+        for k, ids in enumerate(clusters):
+            lab[ids] = k
+        assert np.array_equal(lab, g["lab_" + name]), name
+        abc = g["abc_" + name]
+        for k, ids in enumerate(clusters):
+            _, a, b, c = O.rectangle_search(xy[ids, 0], xy[ids, 1])
+            np.testing.assert_allclose(np.array([a, b, c]), abc[k], rtol=1e-9,
+                                       atol=1e-9, err_msg=name)
+
+
+def test_g6_generate_anns_rows(golden_dir, tmp_path):
+    g = _load(golden_dir, "g5_lshape.npz")
+    calib = _calib_from_text(tmp_path, g["calib_text"])
+    want = {}
+    for line in open(os.path.join(golden_dir, "g6_rows.txt")):
+        case, seem, cls_idx, row = line.rstrip("\n").split("|")
+        want.setdefault((case, seem, int(cls_idx)), []).append(row.split(" "))
+    names = O.NUSC_CLASSES
+    n_checked = 0
+    for ci, name in enumerate(_g5_names(g)):
+        xy = g["xy_" + name]
+        pts = np.concatenate([xy, g["z_" + name][:, None]], 1)
+        box = np.array([570.0 + ci, 177.5, 666.25, 247.0], np.float32)
+        for seem, cls_idx in (("Car", 0), (names[(ci % 9) + 1], (ci % 9) + 1)):
+            rows = O.generate_anns(seem, pts, cls_idx, box, calib)
+            ref = want.get((name, seem, cls_idx), [])
+            assert len(rows) == len(ref), (name, seem)
+            for r, w in zip(rows, ref):
+                assert r.name == w[0]
+                got = O.format_row(r).split(" ")
+                assert got[1:3] == w[1:3]
+                np.testing.assert_allclose(np.array(got[3:], float), np.array(w[3:], float),
+                                           rtol=1e-9, atol=1e-9, err_msg=name)
+                n_checked += 1
+    assert n_checked > 20
+
+
+# ---------------------------------------------------------------- G7
+@pytest.mark.parametrize("tag", ["dense", "dense2"])
+def test_g7_whole_function(golden_dir, tmp_path, tag):
+    g = _load(golden_dir, "g7_%s.npz" % tag)
+    calib = _calib_from_text(tmp_path, g["calib_text"])
+    lidar_all = g["lidar_all"]
+    lidar, flag = O.fov_filter(lidar_all, calib, (900, 1600))
+    assert np.array_equal(flag, g["fov"])
+    masks = g["masks"].astype(np.float32)
+    depth = g["depth"].copy().reshape(900, 1600, 1)
+    res = O.depth2pointsrgbpm(depth, pattern_image(), calib, lidar, O.NUSC_CLASSES,
+                              masks, g["classes"], g["boxes"], O.Params(),
+                              plane=g["plane"], debug=True)
+    # (1) per-instance inputs of the filters == what the reference handed to
+    #     Open3D (vehicles: lidar then pseudo; small classes: pseudo only)
+    v3d = [g["v3d_%d" % i] for i in range(int(g["n_v3d"]))]
+    k = 0
+    for i, cls in enumerate(g["classes"]):
+        name = O.NUSC_CLASSES[int(cls)]
+        lidar_i = lidar[O.above_plane(lidar[:, :3], g["plane"])][:res.dbg["K"]][res.dbg["inst_lidar"][i]][:, :3]
+        if name in O.VEHICLE_CLASSES:
+            assert np.array_equal(v3d[k], lidar_i.astype(np.float64))
+            k += 1
+        np.testing.assert_allclose(res.dbg["inst_pseudo"][i], v3d[k], rtol=1e-12, atol=1e-11)
+        assert res.dbg["inst_pseudo"][i].shape == v3d[k].shape
+        k += 1
+    assert k == len(v3d)
+    # (2) points handed to GenerateAnns
+    for i in range(int(g["n_ann"])):
+        np.testing.assert_allclose(res.dbg["inst_points"][i], g["ann_%d" % i], rtol=1e-12, atol=1e-11)
+    # (3) label rows
+    ref_rows = [r.split(" ") for r in bytes(g["rows"]).decode().strip().split("\n")]
+    assert len(res.rows) == len(ref_rows)
+    for r, w in zip(res.rows, ref_rows):
+        assert r.name == w[0]
+        got = O.format_row(r).split(" ")
+        np.testing.assert_allclose(np.array(got[3:], float), np.array(w[3:], float),
+                                   rtol=1e-9, atol=1e-9)
+    # (4) virtual-point output (my_loader.py:611-617)
+    assert res.all_points.shape == g["all_points"].shape
+    np.testing.assert_allclose(res.all_points, g["all_points"], rtol=1e-12, atol=1e-11)
