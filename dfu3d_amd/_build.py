@@ -1,0 +1,48 @@
+"""Build libdfu3d_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`python -m dfu3d_amd._build` or __graft_entry__.build().  hipcc cross-compiles
+without a GPU; the built .so is git-ignored but travels with the repo snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(CSRC, "libdfu3d_hip.so")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # numerics contract: no implicit FMA contraction; IEEE fp32 div/sqrt
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(INCLUDE, "dfu3d.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

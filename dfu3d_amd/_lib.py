@@ -1,0 +1,108 @@
+"""ctypes binding of libdfu3d_hip.so (C ABI in include/dfu3d.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, every
+entry point raises.  Signatures are declared from the header so a mismatch is
+caught at load time (tests/test_abi.py checks every symbol of include/dfu3d.h).
+"""
+import ctypes
+import os
+import re
+
+from . import _build
+
+c_void_p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_f64 = ctypes.c_double
+
+HEADER = os.path.join(_build.INCLUDE, "dfu3d.h")
+
+
+class BinGeom(ctypes.Structure):
+    """dfu3d_bin_geom (include/dfu3d.h)."""
+    _fields_ = [
+        ("vsize_r", c_f64), ("vsize_t", c_f64), ("vsize_p", c_f64),
+        ("rmin_r", c_f64), ("rmin_t", c_f64), ("rmin_p", c_f64),
+        ("grid_r", c_i32), ("grid_t", c_i32), ("grid_p", c_i32),
+        ("t_lo", c_i32), ("t_n", c_i32), ("p_lo", c_i32), ("p_n", c_i32),
+        ("max_points_per_voxel", c_i32), ("max_voxels", c_i32),
+        ("theta_min", c_f64), ("z_max", c_f64), ("depth_min", c_f64),
+    ]
+
+
+_P = c_void_p
+# argument lists mirror include/dfu3d.h exactly (pointers as void*)
+SIGNATURES = {
+    "dfu3d_version": (c_i32, []),
+    "dfu3d_strerror": (ctypes.c_char_p, [c_i32]),
+    "dfu3d_bin_table_geometry": (c_i64, [ctypes.POINTER(BinGeom)]),
+    "dfu3d_fov_filter": (c_i32, [_P, _P, _P, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P]),
+    "dfu3d_plane_ransac": (c_i32, [_P, _P, _P, _P, _P, c_i32, c_i32, c_f64, c_f64, c_i32,
+                                   c_u64, _P, _P, _P, _P]),
+    "dfu3d_project_label": (c_i32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i32,
+                                    c_i32, c_i32, c_f64, c_f64, _P, _P, _P, _P, _P, _P, _P,
+                                    _P, _P]),
+    "dfu3d_bin_table_init": (c_i32, [_P, c_i64, _P]),
+    "dfu3d_backproject_scratch_words": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, _P, c_i32, c_i32, c_i32, c_i32,
+                                      ctypes.POINTER(BinGeom), c_i32, _P, _P, _P, c_i32, _P,
+                                      _P, _P, _P, _P, _P, _P, _P]),
+    "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,
+                                     c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P]),
+    "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P]),
+    "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,
+                                  _P, _P, _P]),
+    "dfu3d_ballquery_fuse": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,
+                                     _P]),
+    "dfu3d_range_cluster": (c_i32, [_P, _P, _P, _P, c_i32, c_f64, c_f64, _P, _P]),
+    "dfu3d_lshape_fit": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, _P, _P, _P, _P, _P,
+                                 c_i32, c_f64, c_f64, _P, _P, _P, c_i32, _P, _P, _P, _P]),
+}
+
+_LIB = None
+
+
+class Dfu3dError(RuntimeError):
+    pass
+
+
+def header_symbols():
+    """Function names declared in include/dfu3d.h."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfu3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (building in-tree if needed) libdfu3d_hip.so; raises if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.OUT
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as e:  # no silent fallback
+            raise Dfu3dError("libdfu3d_hip.so is missing and could not be built: %r" % (e,))
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:
+        raise Dfu3dError("cannot load %s: %s" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise Dfu3dError("%s does not export %s" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dfu3d_strerror(int(code)).decode()
+        raise Dfu3dError("%s failed: %s (%d)" % (what, msg, code))

@@ -1,0 +1,173 @@
+// common.hpp -- shared device helpers for libdfu3d_hip (gfx950 / CDNA4, wave64).
+//
+// Arithmetic contract: this library is compiled with
+// -ffp-contract=off; every fused multiply-add below is written explicitly and
+// exists only where the reference's BLAS sgemm fuses (measured: sequential-k
+// FMA chain).  fp32 division / sqrt are correctly rounded (hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfu3d.h"
+
+#define DFU3D_WAVE 64
+
+struct ViewCalib {           // 48 floats, see dfu3d.h
+  float M43[12];
+  float P2[12];
+  float cu, cv, fu, fv, tx, ty;
+  float Minv[12];
+  float pad[6];
+};
+static_assert(sizeof(ViewCalib) == DFU3D_CALIB_FLOATS * 4, "calib record");
+
+// ---- wave / block ordered-compaction helpers -------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// exclusive rank of this lane among lanes with flag set; total in wave_total
+__device__ __forceinline__ int wave_rank(bool flag, int &wave_total) {
+  const unsigned long long m = __ballot(flag);
+  wave_total = __popcll(m);
+  return __popcll(m & ((1ull << lane_id()) - 1ull));
+}
+
+// Block-wide exclusive rank for a flag.  NW = waves per block.  s_w: NW ints
+// of LDS.  Contains two barriers; s_w is reusable on return.
+template <int NW>
+__device__ __forceinline__ int block_rank(bool flag, int *s_w, int &block_total) {
+  int wt;
+  const int r = wave_rank(flag, wt);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0) s_w[w] = wt;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    const int c = s_w[i];
+    off += (i < w) ? c : 0;
+    tot += c;
+  }
+  __syncthreads();
+  block_total = tot;
+  return off + r;
+}
+
+// wave inclusive scan of an int
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+// Block-wide exclusive scan of an int value.
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int *s_w, int &block_total) {
+  const int inc = wave_incl_scan(v);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 63) s_w[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    const int c = s_w[i];
+    off += (i < w) ? c : 0;
+    tot += c;
+  }
+  __syncthreads();
+  block_total = tot;
+  return off + inc - v;
+}
+
+// ---- fp64 wave reductions ---------------------------------------------------
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m, 64);
+  hi = __shfl_xor(hi, m, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, shfl_xor_d(v, m));
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_d(v, m));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ---- calibration arithmetic -------------------------------------------------
+// calibration_kitti.py:104-112, float32: sequential-k FMA chain (== sgemm).
+__device__ __forceinline__ void lidar_to_rect_f32(const float *M, float x, float y,
+                                                  float z, float r[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float acc = x * M[0 * 3 + j];
+    acc = __fmaf_rn(y, M[1 * 3 + j], acc);
+    acc = __fmaf_rn(z, M[2 * 3 + j], acc);
+    acc = acc + M[3 * 3 + j];
+    r[j] = acc;
+  }
+}
+// calibration_kitti.py:114-123, float32.
+__device__ __forceinline__ void rect_to_img_f32(const float *P2, const float r[3],
+                                                float &u, float &v, float &depth) {
+  float h[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float acc = r[0] * P2[j * 4 + 0];
+    acc = __fmaf_rn(r[1], P2[j * 4 + 1], acc);
+    acc = __fmaf_rn(r[2], P2[j * 4 + 2], acc);
+    acc = acc + P2[j * 4 + 3];
+    h[j] = acc;
+  }
+  u = h[0] / r[2];
+  v = h[1] / r[2];
+  depth = h[2] - P2[2 * 4 + 3];
+}
+// calibration_kitti.py:134-144 + 89-102, fp64: pixel (col u, row v, depth d)
+// -> LiDAR xyz.
+__device__ __forceinline__ void pixel_to_lidar(const ViewCalib &c, int u, int v,
+                                               float d, double &x, double &y,
+                                               double &z) {
+  const double dd = (double)d;
+  const double xr = (((double)u - (double)c.cu) * dd) / (double)c.fu + (double)c.tx;
+  const double yr = (((double)v - (double)c.cv) * dd) / (double)c.fv + (double)c.ty;
+  const double zr = dd;
+  const float *M = c.Minv;   // (4,3) row-major
+  x = ((xr * (double)M[0] + yr * (double)M[3]) + zr * (double)M[6]) + (double)M[9];
+  y = ((xr * (double)M[1] + yr * (double)M[4]) + zr * (double)M[7]) + (double)M[10];
+  z = ((xr * (double)M[2] + yr * (double)M[5]) + zr * (double)M[8]) + (double)M[11];
+}
+
+// monotone map double -> uint64 (total order; -0.0 canonicalised by caller)
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// splitmix64 finaliser; must match oracle/penet_oracle.py:_mix64
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+#define DFU3D_LAUNCH_CHECK()                                      \
+  do {                                                            \
+    if (hipGetLastError() != hipSuccess) return DFU3D_ELAUNCH;    \
+  } while (0)

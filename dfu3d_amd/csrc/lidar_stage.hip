@@ -1,0 +1,400 @@
+// lidar_stage.hip -- LiDAR-side kernels: FOV filter, seeded plane RANSAC,
+// above-plane + point->pixel label inheritance.
+//
+// One workgroup (1024 threads = 16 waves) per camera view walks the frame's
+// (N,4) float32 points in 1024-point tiles with float4 (16 B/lane) loads and
+// keeps the reference's ORDER by ballot + popcount ranks inside each wave and
+// an LDS hand-off of the 16 wave totals (ordered compaction, hazard H3).
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NW = NT / 64;
+
+// ---------------------------------------------------------------- a4 FOV
+// vis_utils.py:108-123 / 152-154
+__global__ __launch_bounds__(NT) void k_fov_filter(
+    const float4 *__restrict__ pts, const int *__restrict__ pt_off,
+    const int *__restrict__ view_frame, const ViewCalib *__restrict__ calib,
+    float fovH, float fovW, int capN, int *__restrict__ fov_idx,
+    int *__restrict__ n_fov) {
+  __shared__ int s_w[NW];
+  const int v = blockIdx.x;
+  const int f = view_frame[v];
+  const int p0 = pt_off[f];
+  const int n = pt_off[f + 1] - p0;
+  const ViewCalib c = calib[v];
+  int running = 0;
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+      const float4 p = pts[p0 + i];
+      float r[3], u, w, d;
+      lidar_to_rect_f32(c.M43, p.x, p.y, p.z, r);
+      rect_to_img_f32(c.P2, r, u, w, d);
+      ok = (u >= 0.0f) && (u < fovW) && (w >= 0.0f) && (w < fovH) && (d >= 0.0f);
+    }
+    int tot;
+    const int r = block_rank<NW>(ok, s_w, tot);
+    if (ok) {
+      const int pos = running + r;
+      if (pos < capN) fov_idx[(size_t)v * capN + pos] = i;
+    }
+    running += tot;
+  }
+  if (threadIdx.x == 0) n_fov[v] = running < capN ? running : capN;
+}
+
+// ---------------------------------------------------------------- a5 RANSAC
+// Seeded 3-point RANSAC with sklearn's inlier rule (|res| <= MAD(z)), see
+// oracle/penet_oracle.py:plane_ransac for the bit-level specification.
+
+__device__ __forceinline__ unsigned int f32_key(float v) {
+  const unsigned int b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Radix select of the value with 0-based rank k among n keys produced by
+// keyfn(i) (64-bit ordered keys).  All threads of the block call it; returns
+// the key to every thread.  hist: 256 ints of LDS, s_sel: 2 x u64 of LDS.
+template <typename KeyFn>
+__device__ unsigned long long block_select(int n, int k, KeyFn keyfn, int *hist,
+                                           unsigned long long *s_sel) {
+  unsigned long long prefix = 0ull, mask = 0ull;
+  int kk = k;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int b = threadIdx.x; b < 256; b += NT) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const unsigned long long key = keyfn(i);
+      if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xFFull)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 0;
+      for (; b < 256; b++) {
+        const int c = hist[b];
+        if (acc + c > kk) break;
+        acc += c;
+      }
+      if (b > 255) b = 255;      // cannot happen for k < n
+      s_sel[0] = prefix | ((unsigned long long)b << shift);
+      s_sel[1] = (unsigned long long)(kk - acc);
+    }
+    __syncthreads();
+    prefix = s_sel[0];
+    kk = (int)s_sel[1];
+    mask |= (0xFFull << shift);
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__device__ __forceinline__ double key_to_double(unsigned long long k) {
+  const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+// median of n fp64 values valfn(i) exactly as np.median: mean of the two
+// middle order statistics for even n.
+template <typename ValFn>
+__device__ double block_median(int n, ValFn valfn, int *hist, unsigned long long *s_sel) {
+  auto keyfn = [&](int i) { return ordered_key(valfn(i)); };
+  const int k2 = n / 2;
+  const double hi = key_to_double(block_select(n, k2, keyfn, hist, s_sel));
+  if (n & 1) return hi;
+  const double lo = key_to_double(block_select(n, k2 - 1, keyfn, hist, s_sel));
+  return (lo + hi) / 2.0;
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double *s_red) {
+  v = wave_sum_d(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) s_red[w] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) t += s_red[i];
+  return t;
+}
+__device__ __forceinline__ int block_sum_i(int v, int *s_red) {
+  v = wave_sum_i(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) s_red[w] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) t += s_red[i];
+  return t;
+}
+
+__global__ __launch_bounds__(NT) void k_plane_ransac(
+    const float4 *__restrict__ pts, const int *__restrict__ pt_off,
+    const int *__restrict__ view_frame, const int *__restrict__ fov_idx,
+    const int *__restrict__ n_fov, int capN, float max_hs, float xy_range,
+    int trials, unsigned long long seed, const long long *__restrict__ key,
+    int *__restrict__ cand_idx, double *__restrict__ plane) {
+  __shared__ int s_w[NW];
+  __shared__ int s_hist[256];
+  __shared__ unsigned long long s_sel[2];
+  __shared__ double s_red[NW];
+  __shared__ int s_redi[NW];
+  const int v = blockIdx.x;
+  const int p0 = pt_off[view_frame[v]];
+  const int nf = n_fov[v];
+  const int *fidx = fov_idx + (size_t)v * capN;
+  int *cidx = cand_idx + (size_t)v * capN;
+  // candidate set: my_loader.py:449-453 (float32 compares)
+  int n = 0;
+  for (int base = 0; base < nf; base += NT) {
+    const int t = base + threadIdx.x;
+    bool ok = false;
+    int pi = 0;
+    if (t < nf) {
+      pi = fidx[t];
+      const float4 p = pts[p0 + pi];
+      ok = (p.z < max_hs) && (p.x > -xy_range) && (p.x < xy_range) &&
+           (p.y > -xy_range) && (p.y < xy_range);
+    }
+    int tot;
+    const int r = block_rank<NW>(ok, s_w, tot);
+    if (ok) cidx[n + r] = pi;
+    n += tot;
+  }
+  __syncthreads();
+  double *out = plane + (size_t)v * 4;
+  if (n < 3) {
+    if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 1e30; }
+    return;
+  }
+  auto zval = [&](int i) { return (double)pts[p0 + cidx[i]].z; };
+  const double med = block_median(n, zval, s_hist, s_sel);
+  auto dev = [&](int i) { return fabs((double)pts[p0 + cidx[i]].z - med); };
+  const double thr = block_median(n, dev, s_hist, s_sel);
+
+  int best_cnt = -1;
+  double ba = 0.0, bb = 0.0, bc = 0.0;
+  const unsigned long long vkey = (unsigned long long)key[v];
+  for (int t = 0; t < trials; t++) {
+    // every thread derives the same three sample indices
+    int idx[3];
+    int got = 0;
+    for (int a = 0; a < 64 && got < 3; a++) {
+      const unsigned long long r = mix64(seed ^ mix64((vkey << 20) ^ ((unsigned long long)t << 8) ^ (unsigned long long)a));
+      const int i = (int)__umul64hi(r, (unsigned long long)n);
+      bool dup = false;
+      for (int q = 0; q < got; q++) dup |= (idx[q] == i);
+      if (!dup) idx[got++] = i;
+    }
+    if (got < 3) continue;
+    const float4 q0 = pts[p0 + cidx[idx[0]]], q1 = pts[p0 + cidx[idx[1]]], q2 = pts[p0 + cidx[idx[2]]];
+    const double x0 = q0.x, y0 = q0.y, z0 = q0.z;
+    const double dx1 = (double)q1.x - x0, dy1 = (double)q1.y - y0, dz1 = (double)q1.z - z0;
+    const double dx2 = (double)q2.x - x0, dy2 = (double)q2.y - y0, dz2 = (double)q2.z - z0;
+    const double det = dx1 * dy2 - dx2 * dy1;
+    if (!(fabs(det) > 1e-12)) continue;
+    const double ca = (dz1 * dy2 - dz2 * dy1) / det;
+    const double cb = (dx1 * dz2 - dx2 * dz1) / det;
+    const double cc = (z0 - ca * x0) - cb * y0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const float4 p = pts[p0 + cidx[i]];
+      const double res = fabs((double)p.z - ((ca * (double)p.x + cb * (double)p.y) + cc));
+      cnt += (res <= thr) ? 1 : 0;
+    }
+    cnt = block_sum_i(cnt, s_redi);
+    if (cnt > best_cnt) { best_cnt = cnt; ba = ca; bb = cb; bc = cc; }
+  }
+  if (best_cnt < 0) {
+    if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 1e30; }
+    return;
+  }
+  // least-squares refit on the inliers (centred normal equations)
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  int k = 0;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float4 p = pts[p0 + cidx[i]];
+    const double res = fabs((double)p.z - ((ba * (double)p.x + bb * (double)p.y) + bc));
+    if (res <= thr) { sx += p.x; sy += p.y; sz += p.z; k++; }
+  }
+  k = block_sum_i(k, s_redi);
+  sx = block_sum_d(sx, s_red);
+  sy = block_sum_d(sy, s_red);
+  sz = block_sum_d(sz, s_red);
+  const double mx = sx / k, my = sy / k, mz = sz / k;
+  double sxx = 0.0, sxy = 0.0, syy = 0.0, sxz = 0.0, syz = 0.0;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float4 p = pts[p0 + cidx[i]];
+    const double res = fabs((double)p.z - ((ba * (double)p.x + bb * (double)p.y) + bc));
+    if (res <= thr) {
+      const double ux = (double)p.x - mx, uy = (double)p.y - my, uz = (double)p.z - mz;
+      sxx += ux * ux; sxy += ux * uy; syy += uy * uy; sxz += ux * uz; syz += uy * uz;
+    }
+  }
+  sxx = block_sum_d(sxx, s_red);
+  sxy = block_sum_d(sxy, s_red);
+  syy = block_sum_d(syy, s_red);
+  sxz = block_sum_d(sxz, s_red);
+  syz = block_sum_d(syz, s_red);
+  if (threadIdx.x == 0) {
+    double ca = ba, cb = bb, cc = bc;
+    const double det2 = sxx * syy - sxy * sxy;
+    const double ref = fmax(sxx * syy, 1e-300);
+    if (det2 > 1e-12 * ref) {
+      ca = (sxz * syy - syz * sxy) / det2;
+      cb = (syz * sxx - sxz * sxy) / det2;
+      cc = (mz - ca * mx) - cb * my;
+    }
+    const double norm = sqrt((ca * ca + cb * cb) + 1.0);   // my_loader.py:457-466
+    out[0] = -(ca / norm);
+    out[1] = -(cb / norm);
+    out[2] = 1.0 / norm;
+    out[3] = -(cc / norm);
+  }
+}
+
+// ---------------------------------------------------------------- a5/a6
+// my_loader.py:471-477 (above_plane), 517-530 (round + in-bounds compaction)
+__global__ __launch_bounds__(NT) void k_project_rows(
+    const float4 *__restrict__ pts, const int *__restrict__ pt_off,
+    const int *__restrict__ view_frame, const ViewCalib *__restrict__ calib,
+    const double *__restrict__ plane, const int *__restrict__ fov_idx,
+    const int *__restrict__ n_fov, int capN, float boundH, float boundW, int W,
+    double plane_offset, float xy_range, int *__restrict__ ag_pt,
+    int *__restrict__ ib_pix, int *__restrict__ n_ag, int *__restrict__ Kout) {
+  __shared__ int s_w[NW];
+  const int v = blockIdx.x;
+  const int p0 = pt_off[view_frame[v]];
+  const int nf = n_fov[v];
+  const ViewCalib c = calib[v];
+  const double pl0 = plane[v * 4 + 0], pl1 = plane[v * 4 + 1], pl2 = plane[v * 4 + 2],
+               pl3 = plane[v * 4 + 3];
+  const double pn = sqrt((pl0 * pl0 + pl1 * pl1) + pl2 * pl2);
+  const int *fidx = fov_idx + (size_t)v * capN;
+  int nag = 0, nib = 0;
+  for (int base = 0; base < nf; base += NT) {
+    const int t = base + threadIdx.x;
+    bool ag = false, ib = false;
+    int pi = 0, pix = 0;
+    if (t < nf) {
+      pi = fidx[t];
+      const float4 p = pts[p0 + pi];
+      double d = (((double)p.x * pl0 + (double)p.y * pl1) + (double)p.z * pl2) + pl3;
+      d = d / pn;
+      const bool below = d < plane_offset;
+      const bool inr = (p.x < xy_range) && (p.x > -xy_range) && (p.y < xy_range) && (p.y > -xy_range);
+      ag = !(below && inr);
+      if (ag) {
+        float r[3], u, w, dep;
+        lidar_to_rect_f32(c.M43, p.x, p.y, p.z, r);
+        rect_to_img_f32(c.P2, r, u, w, dep);
+        const float ru = rintf(u), rv = rintf(w);        // np.round: half to even
+        ib = (0.0f <= ru) && (ru < boundW) && (0.0f <= rv) && (rv < boundH);
+        if (ib) pix = (int)rv * W + (int)ru;
+      }
+    }
+    int tot_ag, tot_ib;
+    const int r_ag = block_rank<NW>(ag, s_w, tot_ag);
+    const int r_ib = block_rank<NW>(ib, s_w, tot_ib);
+    if (ag) ag_pt[(size_t)v * capN + nag + r_ag] = pi;
+    if (ib) ib_pix[(size_t)v * capN + nib + r_ib] = pix;
+    nag += tot_ag;
+    nib += tot_ib;
+  }
+  if (threadIdx.x == 0) {
+    n_ag[v] = nag;
+    Kout[v] = nib < nag ? nib : nag;   // my_loader.py:527
+  }
+}
+
+// row t < K: point = ag_pt[t] (positional), pixel = ib_pix[t]; bits from masks
+__global__ __launch_bounds__(256) void k_label_rows(
+    const float4 *__restrict__ pts, const int *__restrict__ pt_off,
+    const int *__restrict__ view_frame, const int *__restrict__ ag_pt,
+    const int *__restrict__ ib_pix, const int *__restrict__ Kin,
+    const uint8_t *__restrict__ masks, const int *__restrict__ n_inst, int max_inst,
+    int HW, int capN, uint32_t *__restrict__ it_bits, double *__restrict__ it_x,
+    double *__restrict__ it_y, double *__restrict__ it_z) {
+  const int v = blockIdx.y;
+  const int K = Kin[v];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K) return;
+  const size_t o = (size_t)v * capN + t;
+  const int p0 = pt_off[view_frame[v]];
+  const float4 p = pts[p0 + ag_pt[o]];
+  const int pix = ib_pix[o];
+  uint32_t bits = 0u;
+  const int m = n_inst[v];
+  const uint8_t *mb = masks + (size_t)v * max_inst * HW;
+  for (int j = 0; j < m; j++)
+    bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
+  it_bits[o] = bits;
+  it_x[o] = (double)p.x;
+  it_y[o] = (double)p.y;
+  it_z[o] = (double)p.z;
+}
+
+}  // namespace
+
+extern "C" int dfu3d_fov_filter(const float *points, const int32_t *pt_off,
+                                const int32_t *view_frame, const float *calib,
+                                int32_t V, int32_t fov_h, int32_t fov_w,
+                                int32_t cap_n, int32_t *fov_idx, int32_t *n_fov,
+                                void *stream) {
+  if (!points || !pt_off || !view_frame || !calib || !fov_idx || !n_fov) return DFU3D_EINVAL;
+  if (V <= 0 || cap_n <= 0 || fov_h <= 0 || fov_w <= 0) return DFU3D_EINVAL;
+  hipLaunchKernelGGL(k_fov_filter, dim3(V), dim3(NT), 0, (hipStream_t)stream,
+                     (const float4 *)points, pt_off, view_frame,
+                     (const ViewCalib *)calib, (float)fov_h, (float)fov_w, cap_n,
+                     fov_idx, n_fov);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_plane_ransac(const float *points, const int32_t *pt_off,
+                                  const int32_t *view_frame, const int32_t *fov_idx,
+                                  const int32_t *n_fov, int32_t V, int32_t cap_n,
+                                  double max_hs, double xy_range, int32_t trials,
+                                  uint64_t seed, const int64_t *key,
+                                  int32_t *cand_idx, double *plane, void *stream) {
+  if (!points || !pt_off || !view_frame || !fov_idx || !n_fov || !key || !cand_idx || !plane)
+    return DFU3D_EINVAL;
+  if (V <= 0 || cap_n <= 0 || trials < 0) return DFU3D_EINVAL;
+  hipLaunchKernelGGL(k_plane_ransac, dim3(V), dim3(NT), 0, (hipStream_t)stream,
+                     (const float4 *)points, pt_off, view_frame, fov_idx, n_fov,
+                     cap_n, (float)max_hs, (float)xy_range, trials,
+                     (unsigned long long)seed, (const long long *)key, cand_idx, plane);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_project_label(
+    const float *points, const int32_t *pt_off, const int32_t *view_frame,
+    const float *calib, const double *plane, const int32_t *fov_idx,
+    const int32_t *n_fov, const uint8_t *masks, const int32_t *n_inst, int32_t V,
+    int32_t max_inst, int32_t H, int32_t W, int32_t cap_n, double plane_offset,
+    double xy_range, int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag, int32_t *K,
+    uint32_t *it_bits, double *it_x, double *it_y, double *it_z, void *stream) {
+  if (!points || !pt_off || !view_frame || !calib || !plane || !fov_idx || !n_fov ||
+      !masks || !n_inst || !ag_pt || !ib_pix || !n_ag || !K || !it_bits || !it_x ||
+      !it_y || !it_z)
+    return DFU3D_EINVAL;
+  if (V <= 0 || cap_n <= 0 || H <= 0 || W <= 0 || max_inst <= 0) return DFU3D_EINVAL;
+  if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  hipLaunchKernelGGL(k_project_rows, dim3(V), dim3(NT), 0, (hipStream_t)stream,
+                     (const float4 *)points, pt_off, view_frame,
+                     (const ViewCalib *)calib, plane, fov_idx, n_fov, cap_n,
+                     (float)H, (float)W, W, plane_offset, (float)xy_range, ag_pt,
+                     ib_pix, n_ag, K);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_label_rows, dim3((cap_n + 255) / 256, V), dim3(256), 0,
+                     (hipStream_t)stream, (const float4 *)points, pt_off, view_frame,
+                     ag_pt, ib_pix, K, masks, n_inst, max_inst, H * W, cap_n, it_bits,
+                     it_x, it_y, it_z);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}

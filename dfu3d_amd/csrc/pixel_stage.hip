@@ -1,0 +1,533 @@
+// pixel_stage.hip -- camera-side kernels: fp64 back-projection of the dense
+// depth map and spherical voxel sampling (la_sampling2 / la_sampling20).
+//
+// Reference semantics (my_loader.py:507-509, 532-557, 166-180, 247-275 + the
+// spconv point-to-voxel leaf): points are visited in row-major
+// pixel order; a voxel keeps the first `max_points` points that fall in it; the
+// representative is the first argmin of one coordinate among those; voxels come
+// out in first-seen order, at most `max_voxels` of them.
+//
+// GPU formulation (order-free, deterministic): because input order == pixel
+// index, "first seen" is the minimum pixel index of a bin and "the first 100"
+// are the 100 smallest pixel indices.  Per view a direct-addressed table over
+// the reachable (theta,phi) bins holds {min key, count, first pixel, rep pixel}:
+//   P1  per pixel: back-project, bin, store bin id; atomics: count++,
+//       first=min(pix), kmin=min(key)             (100-cap assumed not to bind)
+//   O*  bins whose count exceeded the cap are listed by the 101st arrival and
+//       repaired exactly: their pixel lists are gathered, the 100th smallest
+//       pixel index T is radix-selected and kmin recomputed over pix <= T
+//   P2  per pixel: if key == kmin (and pix <= T): rep=min(pix); count pixels
+//       that are the first of their bin per 1024-pixel block
+//   SC  per view: exclusive scan of the block counts
+//   P3  per pixel block: ordered ranks of first-pixels -> voxel list
+//   P4  per voxel: representative's xyz + instance bits; table entry reset
+// Each pass streams the (V,H,W) float32 depth with float4 loads.
+#include "common.hpp"
+
+namespace {
+
+constexpr int PB = 256;            // threads per pixel block
+constexpr int PPT = 4;             // pixels per thread (one float4)
+constexpr int PBLK = PB * PPT;     // 1024 pixels per block
+constexpr uint32_t NOBIN = 0xFFFFFFFFu;
+constexpr uint32_t OVF_FLAG = 0x80000000u;
+
+struct Table {
+  unsigned long long *kmin;
+  uint32_t *cnt, *first, *rep;
+};
+__host__ __device__ inline Table table_view(void *base, int64_t E) {
+  Table t;
+  t.kmin = (unsigned long long *)base;
+  t.cnt = (uint32_t *)(t.kmin + E);
+  t.first = t.cnt + E;
+  t.rep = t.first + E;
+  return t;
+}
+
+__global__ void k_table_init(unsigned long long *kmin, uint32_t *cnt, uint32_t *first,
+                             uint32_t *rep, int64_t E) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    kmin[i] = ~0ull;
+    cnt[i] = 0u;
+    first[i] = NOBIN;
+    rep[i] = NOBIN;
+  }
+}
+
+// back-project pixel and classify; returns table index or NOBIN; key = chosen
+// coordinate (canonical +0.0).
+__device__ __forceinline__ uint32_t pixel_bin(const ViewCalib &c, const dfu3d_bin_geom &g,
+                                              int W, int pix, float d, int key_axis,
+                                              double &key, bool &range_err) {
+  if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
+  const int row = pix / W, col = pix - row * W;
+  double x, y, z;
+  pixel_to_lidar(c, col, row, d, x, y, z);
+  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540
+  double s = x * x;                                              // my_loader.py:167
+  s = s + y * y;
+  s = s + z * z;
+  const double r = sqrt(s);
+  const double theta = acos(z / r);                              // :168
+  if (!(theta > g.theta_min)) return NOBIN;                      // :175
+  const double phi = atan(y / x);                                // :169
+  const double cr = floor((r - g.rmin_r) / g.vsize_r);
+  const double ct = floor((theta - g.rmin_t) / g.vsize_t);
+  const double cp = floor((phi - g.rmin_p) / g.vsize_p);
+  if (!(cr >= 0.0 && cr < (double)g.grid_r)) return NOBIN;
+  if (!(ct >= 0.0 && ct < (double)g.grid_t)) return NOBIN;
+  if (!(cp >= 0.0 && cp < (double)g.grid_p)) return NOBIN;
+  const int it = (int)ct - g.t_lo, ip = (int)cp - g.p_lo;
+  if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) { range_err = true; return NOBIN; }
+  key = (key_axis == 2) ? z : y;
+  if (key == 0.0) key = 0.0;
+  return (uint32_t)(it * g.p_n + ip);
+}
+
+// recompute only the key of a pixel already known to be kept
+__device__ __forceinline__ double pixel_key(const ViewCalib &c, int W, int pix, float d,
+                                            int key_axis) {
+  const int row = pix / W, col = pix - row * W;
+  double x, y, z;
+  pixel_to_lidar(c, col, row, d, x, y, z);
+  double key = (key_axis == 2) ? z : y;
+  if (key == 0.0) key = 0.0;
+  return key;
+}
+
+__device__ __forceinline__ void load4(const float *p, int base, int n, float d[PPT]) {
+  if (base + PPT <= n) {
+    const float4 q = *(const float4 *)(p + base);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < PPT; k++) d[k] = (base + k < n) ? p[base + k] : 0.0f;
+  }
+}
+
+// ---- P1 ---------------------------------------------------------------------
+__global__ __launch_bounds__(PB) void k_bp_bin(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
+    dfu3d_bin_geom g, int W, int HW, int key_axis, int64_t E_view, void *table,
+    int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
+    uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf,
+    uint32_t *__restrict__ status) {
+  const int v = blockIdx.y;
+  const ViewCalib c = calib[v];
+  const Table T = table_view(table, E_total);
+  const int64_t tb0 = (int64_t)v * E_view;
+  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
+  if (base >= HW) return;
+  const float *dv = depth + (size_t)v * HW;
+  float d[PPT];
+  load4(dv, base, HW, d);
+  uint32_t bins[PPT];
+  bool rerr = false;
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    bins[k] = NOBIN;
+    const int pix = base + k;
+    if (pix < HW) {
+      double key;
+      const uint32_t b = pixel_bin(c, g, W, pix, d[k], key_axis, key, rerr);
+      bins[k] = b;
+      if (b != NOBIN) {
+        const int64_t e = tb0 + b;
+        const uint32_t old = atomicAdd(&T.cnt[e], 1u);
+        atomicMin(&T.first[e], (uint32_t)pix);
+        atomicMin(&T.kmin[e], ordered_key(key));
+        if (old == (uint32_t)g.max_points_per_voxel) {   // the (cap+1)-th arrival
+          const int slot = atomicAdd(&n_ovf[v], 1);
+          if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
+        }
+      }
+    }
+  }
+  if (base + PPT <= HW) {
+    *(uint4 *)(pix_bin + (size_t)v * HW + base) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
+  } else {
+    for (int k = 0; k < PPT; k++)
+      if (base + k < HW) pix_bin[(size_t)v * HW + base + k] = bins[k];
+  }
+  if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
+}
+
+// ---- O2: allocate a pixel list per overflow bin ------------------------------
+// rep[e] <- list base, cnt[e] <- OVF_FLAG | 0 (fill cursor), ovf_cnt <- count
+__global__ void k_ovf_alloc(void *table, int64_t E_total, int64_t E_view, int cap_ovf,
+                            const uint32_t *__restrict__ ovf_bins,
+                            const int *__restrict__ n_ovf, int *__restrict__ ovf_cnt,
+                            int *__restrict__ ovf_cursor, int HW,
+                            uint32_t *__restrict__ status) {
+  const int v = blockIdx.y;
+  const int no = min(n_ovf[v], cap_ovf);
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= no) return;
+  const Table T = table_view(table, E_total);
+  const int64_t e = (int64_t)v * E_view + ovf_bins[(size_t)v * cap_ovf + s];
+  const int c = (int)T.cnt[e];
+  const int off = atomicAdd(&ovf_cursor[v], c);
+  if (off + c > HW) atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);   // cannot happen
+  ovf_cnt[(size_t)v * cap_ovf + s] = c;
+  T.rep[e] = (uint32_t)off;
+  T.cnt[e] = OVF_FLAG;
+}
+
+// ---- O3: gather the pixel indices of overflow bins ---------------------------
+__global__ __launch_bounds__(PB) void k_ovf_gather(
+    const uint32_t *__restrict__ pix_bin, void *table, int64_t E_total, int64_t E_view,
+    int HW, const int *__restrict__ n_ovf, uint32_t *__restrict__ ovf_list) {
+  const int v = blockIdx.y;
+  if (n_ovf[v] == 0) return;
+  const Table T = table_view(table, E_total);
+  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
+  for (int k = 0; k < PPT; k++) {
+    const int pix = base + k;
+    if (pix >= HW) break;
+    const uint32_t b = pix_bin[(size_t)v * HW + pix];
+    if (b == NOBIN) continue;
+    const int64_t e = (int64_t)v * E_view + b;
+    if (T.cnt[e] & OVF_FLAG) {
+      const uint32_t pos = atomicAdd(&T.cnt[e], 1u) & ~OVF_FLAG;
+      ovf_list[(size_t)v * HW + T.rep[e] + pos] = (uint32_t)pix;
+    }
+  }
+}
+
+// ---- O4: per overflow bin, T = max_points-th smallest pixel, kmin over pix<=T -
+__global__ __launch_bounds__(256) void k_ovf_select(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, int W, int HW,
+    int key_axis, int max_points, void *table, int64_t E_total, int64_t E_view,
+    int cap_ovf, const uint32_t *__restrict__ ovf_bins, const int *__restrict__ n_ovf,
+    const int *__restrict__ ovf_cnt, const uint32_t *__restrict__ ovf_list) {
+  __shared__ int hist[256];
+  __shared__ uint32_t s_sel[2];
+  __shared__ unsigned long long s_min[4];
+  const int v = blockIdx.y;
+  const int no = min(n_ovf[v], cap_ovf);
+  const Table T = table_view(table, E_total);
+  const ViewCalib c = calib[v];
+  for (int s = blockIdx.x; s < no; s += gridDim.x) {     // uniform per block
+  const int64_t e = (int64_t)v * E_view + ovf_bins[(size_t)v * cap_ovf + s];
+  const int n = ovf_cnt[(size_t)v * cap_ovf + s];
+  const uint32_t *lst = ovf_list + (size_t)v * HW + T.rep[e];
+  __syncthreads();
+  // radix select (24 bits, 3 x 8) of the value with 0-based rank max_points-1
+  uint32_t prefix = 0u, mask = 0u;
+  int kk = max_points - 1;
+  for (int shift = 16; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const uint32_t key = lst[i];
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFFu], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 0;
+      for (; b < 256; b++) {
+        const int c = hist[b];
+        if (acc + c > kk) break;
+        acc += c;
+      }
+      if (b > 255) b = 255;
+      s_sel[0] = prefix | ((uint32_t)b << shift);
+      s_sel[1] = (uint32_t)(kk - acc);
+    }
+    __syncthreads();
+    prefix = s_sel[0];
+    kk = (int)s_sel[1];
+    mask |= (0xFFu << shift);
+    __syncthreads();
+  }
+  const uint32_t thr = prefix;
+  unsigned long long m = ~0ull;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t pix = lst[i];
+    if (pix <= thr) {
+      const unsigned long long k = ordered_key(
+          pixel_key(c, W, (int)pix, depth[(size_t)v * HW + pix], key_axis));
+      m = k < m ? k : m;
+    }
+  }
+#pragma unroll
+  for (int x = 32; x >= 1; x >>= 1) {
+    const unsigned long long o = __shfl_xor(m, x, 64);
+    m = o < m ? o : m;
+  }
+  if (lane_id() == 0) s_min[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
+    T.kmin[e] = m;
+    T.cnt[e] = OVF_FLAG | thr;       // P2 reads the threshold from here
+    T.rep[e] = NOBIN;
+  }
+  }
+}
+
+// ---- P2 ---------------------------------------------------------------------
+__global__ __launch_bounds__(PB) void k_bp_rep(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, int W, int HW,
+    int key_axis, int64_t E_view, void *table, int64_t E_total,
+    const uint32_t *__restrict__ pix_bin, int nblk, int *__restrict__ blk_cnt) {
+  __shared__ int s_w[PB / 64];
+  const int v = blockIdx.y;
+  const ViewCalib c = calib[v];
+  const Table T = table_view(table, E_total);
+  const int64_t tb0 = (int64_t)v * E_view;
+  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
+  int nfirst = 0;
+  if (base < HW) {
+    uint32_t bins[PPT];
+    if (base + PPT <= HW) {
+      const uint4 q = *(const uint4 *)(pix_bin + (size_t)v * HW + base);
+      bins[0] = q.x; bins[1] = q.y; bins[2] = q.z; bins[3] = q.w;
+    } else {
+      for (int k = 0; k < PPT; k++)
+        bins[k] = (base + k < HW) ? pix_bin[(size_t)v * HW + base + k] : NOBIN;
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      if (bins[k] == NOBIN) continue;
+      const int pix = base + k;
+      const int64_t e = tb0 + bins[k];
+      const uint32_t cw = T.cnt[e];
+      const uint32_t thr = (cw & OVF_FLAG) ? (cw & ~OVF_FLAG) : 0x7FFFFFFFu;
+      if ((uint32_t)pix <= thr) {
+        const double key = pixel_key(c, W, pix, depth[(size_t)v * HW + pix], key_axis);
+        if (ordered_key(key) == T.kmin[e]) atomicMin(&T.rep[e], (uint32_t)pix);
+      }
+      nfirst += (T.first[e] == (uint32_t)pix) ? 1 : 0;
+    }
+  }
+  nfirst = wave_sum_i(nfirst);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = nfirst;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blk_cnt[(size_t)v * (nblk + 1) + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// ---- SC: per-view exclusive scan of the block counts -------------------------
+__global__ __launch_bounds__(1024) void k_bp_scan(int nblk, int *__restrict__ blk_cnt,
+                                                  int *__restrict__ n_vox, int cap_vox,
+                                                  uint32_t *__restrict__ status) {
+  __shared__ int s_w[16];
+  const int v = blockIdx.x;
+  int *bc = blk_cnt + (size_t)v * (nblk + 1);
+  int running = 0;
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int val = (i < nblk) ? bc[i] : 0;
+    int tot;
+    const int ex = block_excl_scan<16>(val, s_w, tot);
+    if (i < nblk) bc[i] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) {
+    bc[nblk] = running;
+    n_vox[v] = running;                  // all touched bins (clamped in P4)
+    if (running > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+  }
+}
+
+// ---- P3: ordered voxel list --------------------------------------------------
+__global__ __launch_bounds__(PB) void k_bp_emit(
+    int HW, int64_t E_view, void *table, int64_t E_total,
+    const uint32_t *__restrict__ pix_bin, int nblk, const int *__restrict__ blk_cnt,
+    int cap_vox, uint32_t *__restrict__ vox_bin) {
+  __shared__ int s_w[PB / 64];
+  const int v = blockIdx.y;
+  const Table T = table_view(table, E_total);
+  const int64_t tb0 = (int64_t)v * E_view;
+  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
+  uint32_t bins[PPT];
+  bool isf[PPT];
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    const int pix = base + k;
+    bins[k] = (pix < HW) ? pix_bin[(size_t)v * HW + pix] : NOBIN;
+    isf[k] = (bins[k] != NOBIN) && (T.first[tb0 + bins[k]] == (uint32_t)pix);
+    mine += isf[k] ? 1 : 0;
+  }
+  int tot;
+  int r = block_excl_scan<PB / 64>(mine, s_w, tot) +
+          blk_cnt[(size_t)v * (nblk + 1) + blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < PPT; k++)
+    if (isf[k]) {
+      if (r < cap_vox) vox_bin[(size_t)v * cap_vox + r] = bins[k];
+      r++;
+    }
+}
+
+// ---- P4: per voxel output + table reset --------------------------------------
+__global__ __launch_bounds__(256) void k_bp_vox(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
+    const uint8_t *__restrict__ masks, const int *__restrict__ n_inst, int max_inst, int W,
+    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox,
+    const uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
+    uint32_t *__restrict__ vox_pix, uint32_t *__restrict__ it_bits,
+    double *__restrict__ it_x, double *__restrict__ it_y, double *__restrict__ it_z) {
+  const int v = blockIdx.y;
+  const int ntouched = min(n_vox[v], cap_vox);
+  const int nout = min(ntouched, max_voxels);
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < ntouched) {
+    const Table T = table_view(table, E_total);
+    const size_t o = (size_t)v * cap_vox + k;
+    const int64_t e = (int64_t)v * E_view + vox_bin[o];
+    if (k < nout) {
+      const uint32_t pix = T.rep[e];
+      const ViewCalib c = calib[v];
+      const int row = (int)pix / W, col = (int)pix - row * W;
+      double x, y, z;
+      pixel_to_lidar(c, col, row, depth[(size_t)v * HW + pix], x, y, z);
+      uint32_t bits = 0u;
+      if (masks) {
+        const int m = n_inst[v];
+        const uint8_t *mb = masks + (size_t)v * max_inst * HW;
+        for (int j = 0; j < m; j++)
+          bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
+      }
+      vox_pix[o] = pix;
+      it_bits[o] = bits;
+      it_x[o] = x;
+      it_y[o] = y;
+      it_z[o] = z;
+    }
+    // leave the table clean for the next launch
+    T.kmin[e] = ~0ull;
+    T.cnt[e] = 0u;
+    T.first[e] = NOBIN;
+    T.rep[e] = NOBIN;
+  }
+}
+
+__global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restrict__ n_vox,
+                              int *__restrict__ n_ovf, int *__restrict__ ovf_cursor) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int n = n_vox[v];
+  n_vox[v] = min(min(n, cap_vox), max_voxels);
+  n_ovf[v] = 0;
+  ovf_cursor[v] = 0;
+}
+
+}  // namespace
+
+extern "C" int64_t dfu3d_bin_table_geometry(dfu3d_bin_geom *g) {
+  if (!g) return DFU3D_EINVAL;
+  const double pi = 3.14159265358979323846;
+  // bins reachable with theta in (theta_min, pi], phi in [-pi/2, pi/2]
+  auto binf = [](double v, double mn, double vs) { return (int64_t)__builtin_floor((v - mn) / vs); };
+  int64_t t0 = binf(g->theta_min, g->rmin_t, g->vsize_t) - 1;
+  int64_t t1 = binf(pi, g->rmin_t, g->vsize_t) + 2;
+  int64_t p0 = binf(-pi / 2, g->rmin_p, g->vsize_p) - 1;
+  int64_t p1 = binf(pi / 2, g->rmin_p, g->vsize_p) + 2;
+  if (t0 < 0) t0 = 0;
+  if (p0 < 0) p0 = 0;
+  if (t1 > g->grid_t) t1 = g->grid_t;
+  if (p1 > g->grid_p) p1 = g->grid_p;
+  if (t1 <= t0 || p1 <= p0) return DFU3D_EINVAL;
+  g->t_lo = (int32_t)t0;
+  g->t_n = (int32_t)(t1 - t0);
+  g->p_lo = (int32_t)p0;
+  g->p_n = (int32_t)(p1 - p0);
+  return (int64_t)g->t_n * g->p_n;
+}
+
+extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
+  if (!table || E <= 0) return DFU3D_EINVAL;
+  const Table T = table_view(table, E);
+  hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(256), 0, (hipStream_t)stream, T.kmin,
+                     T.cnt, T.first, T.rep, E);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+// Scratch carve-up of blk_cnt (int32):
+//   [0, V*(nblk+1))                       block counts / offsets
+//   then n_ovf[V], ovf_cursor[V], ovf_cnt[V*cap_ovf], ovf_bins[V*cap_ovf]
+// and of pix_bin (uint32): [0, V*HW) bin ids, [V*HW, 2*V*HW) overflow pixel
+// lists, [2*V*HW, 2*V*HW + V*cap_vox) voxel bin list.
+extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
+                                                   int32_t cap_vox, int32_t max_points,
+                                                   int64_t *pix_words, int64_t *blk_words) {
+  if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1) return DFU3D_EINVAL;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t nblk = (HW + PBLK - 1) / PBLK;
+  const int64_t cap_ovf = HW / (max_points + 1) + 1;
+  if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
+  if (blk_words) *blk_words = V * (nblk + 1) + 2 * (int64_t)V + 2 * V * cap_ovf;
+  return 0;
+}
+
+extern "C" int dfu3d_backproject_bin(
+    const float *depth, const float *calib, const uint8_t *masks, const int32_t *n_inst,
+    int32_t V, int32_t max_inst, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
+    int32_t key_axis, void *table, uint32_t *pix_bin, int32_t *blk_cnt, int32_t cap_vox,
+    int32_t *n_vox, uint32_t *vox_pix, uint32_t *it_bits, double *it_x, double *it_y,
+    double *it_z, uint32_t *status, void *stream) {
+  if (!depth || !calib || !geom || !table || !pix_bin || !blk_cnt || !n_vox || !vox_pix ||
+      !it_bits || !it_x || !it_y || !it_z || !status)
+    return DFU3D_EINVAL;
+  if (masks && !n_inst) return DFU3D_EINVAL;
+  if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0) return DFU3D_EINVAL;
+  if (key_axis != 1 && key_axis != 2) return DFU3D_EINVAL;
+  if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  const int64_t HW64 = (int64_t)H * W;
+  if (HW64 >= (1ll << 24)) return DFU3D_ERANGE;     // 24-bit pixel radix select
+  if (geom->max_points_per_voxel < 1) return DFU3D_EINVAL;
+  const int HW = (int)HW64;
+  const int nblk = (HW + PBLK - 1) / PBLK;
+  const int cap_ovf = HW / (geom->max_points_per_voxel + 1) + 1;
+  const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
+  const int64_t E_total = E_view * V;
+  hipStream_t st = (hipStream_t)stream;
+  int *n_ovf = blk_cnt + (size_t)V * (nblk + 1);
+  int *ovf_cursor = n_ovf + V;
+  int *ovf_cnt = ovf_cursor + V;
+  uint32_t *ovf_bins = (uint32_t *)(ovf_cnt + (size_t)V * cap_ovf);
+  uint32_t *ovf_list = pix_bin + (size_t)V * HW;
+  uint32_t *vox_bin = pix_bin + 2 * (size_t)V * HW;
+  const ViewCalib *cal = (const ViewCalib *)calib;
+
+  if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 2 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_bp_bin, dim3(nblk, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
+                     key_axis, E_view, table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf,
+                     status);
+  DFU3D_LAUNCH_CHECK();
+  // exact repair of bins that saw more than max_points points (no-ops otherwise)
+  hipLaunchKernelGGL(k_ovf_alloc, dim3((cap_ovf + 255) / 256, V), dim3(256), 0, st, table,
+                     E_total, E_view, cap_ovf, ovf_bins, n_ovf, ovf_cnt, ovf_cursor, HW,
+                     status);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ovf_gather, dim3(nblk, V), dim3(PB), 0, st, pix_bin, table, E_total,
+                     E_view, HW, n_ovf, ovf_list);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ovf_select, dim3(cap_ovf < 32 ? cap_ovf : 32, V), dim3(256), 0, st, depth, cal, W, HW,
+                     key_axis, geom->max_points_per_voxel, table, E_total, E_view, cap_ovf,
+                     ovf_bins, n_ovf, ovf_cnt, ovf_list);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_rep, dim3(nblk, V), dim3(PB), 0, st, depth, cal, W, HW, key_axis,
+                     E_view, table, E_total, pix_bin, nblk, blk_cnt);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(1024), 0, st, nblk, blk_cnt, n_vox, cap_vox,
+                     status);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_emit, dim3(nblk, V), dim3(PB), 0, st, HW, E_view, table, E_total,
+                     pix_bin, nblk, blk_cnt, cap_vox, vox_bin);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + 255) / 256, V), dim3(256), 0, st, depth, cal,
+                     masks, n_inst, max_inst, W, HW, geom->max_voxels, E_view, table,
+                     E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V,
+                     geom->max_voxels, cap_vox, n_vox, n_ovf, ovf_cursor);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}

@@ -1,0 +1,477 @@
+// segment_stage.hip -- per-instance point sets and the noise-suppression
+// filters that act on them.
+//
+// Layout: every instance segment s = v*max_inst + j owns a contiguous slice of
+// a structure-of-arrays fp64 pool (px,py,pz): LiDAR rows first, voxel
+// representatives directly behind them, so the reference's
+// torch.cat((lidar, pseudo)) (my_loader.py:605) is a no-op in memory.
+// Filters are brute force over LDS-staged 1024-point tiles (24 KB/tile, 8 B/lane
+// coalesced SoA loads); query tiles of 256 points are spread over the chip by a
+// prefix-summed tile list so that one huge instance cannot serialise a launch;
+// a query starts its sweep at the tile it lives in and the workgroup leaves the
+// sweep as soon as every query has its answer (nb_points = 1 makes that the
+// first tile for almost every point).  Survivors are compacted in order with
+// ballot/popcount ranks.
+#include "common.hpp"
+
+namespace {
+
+constexpr int QT = 256;    // queries per workgroup tile
+constexpr int PT = 1024;   // points per LDS tile
+
+// ---------------------------------------------------------------- build
+__global__ __launch_bounds__(256) void k_seg_count(const uint32_t *__restrict__ bits,
+                                                   const int *__restrict__ n_item,
+                                                   int cap_item, int max_inst,
+                                                   int *__restrict__ cnt) {
+  __shared__ int s_c[DFU3D_MAX_INST];
+  const int v = blockIdx.x;
+  if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = min(n_item[v], cap_item);
+  for (int t = threadIdx.x; t < n; t += 256) {
+    uint32_t b = bits[(size_t)v * cap_item + t];
+    while (b) {
+      const int j = __ffs((int)b) - 1;
+      atomicAdd(&s_c[j], 1);
+      b &= b - 1u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < max_inst) cnt[v * max_inst + threadIdx.x] = s_c[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt_a,
+                                                    int *__restrict__ cnt_b,
+                                                    long long *__restrict__ base_a,
+                                                    long long *__restrict__ base_b,
+                                                    long long pool_cap,
+                                                    long long *__restrict__ cursor,
+                                                    uint32_t *__restrict__ status) {
+  __shared__ int s_w[16];
+  long long running = *cursor;
+  bool over = false;
+  for (int b0 = 0; b0 < S; b0 += 1024) {
+    const int s = b0 + threadIdx.x;
+    const int ca = (s < S) ? cnt_a[s] : 0, cb = (s < S) ? cnt_b[s] : 0;
+    int tot;
+    const int ex = block_excl_scan<16>(ca + cb, s_w, tot);
+    if (s < S) {
+      const long long b = running + ex;
+      if (b + ca + cb > pool_cap) {
+        cnt_a[s] = 0;
+        cnt_b[s] = 0;
+        base_a[s] = 0;
+        base_b[s] = 0;
+        over = over || (ca + cb > 0);
+      } else {
+        base_a[s] = b;
+        base_b[s] = b + ca;
+      }
+    }
+    running += tot;
+  }
+  if (over) atomicOr(status, DFU3D_ST_POOL_OVERFLOW);
+  __syncthreads();
+  if (threadIdx.x == 0) *cursor = running < pool_cap ? running : pool_cap;
+}
+
+__global__ __launch_bounds__(256) void k_seg_write(
+    const uint32_t *__restrict__ bits, const double *__restrict__ ix,
+    const double *__restrict__ iy, const double *__restrict__ iz,
+    const int *__restrict__ n_item, int cap_item, int max_inst,
+    const long long *__restrict__ base, const int *__restrict__ cnt,
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz) {
+  __shared__ int s_w[4];
+  const int s = blockIdx.x;
+  const int total = cnt[s];
+  if (total == 0) return;
+  const int v = s / max_inst, j = s - v * max_inst;
+  const int n = min(n_item[v], cap_item);
+  const long long b = base[s];
+  int running = 0;
+  for (int t0 = 0; t0 < n && running < total; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const size_t o = (size_t)v * cap_item + t;
+    const bool f = (t < n) && ((bits[o] >> j) & 1u);
+    int tot;
+    const int r = block_rank<4>(f, s_w, tot);
+    if (f) {
+      const long long d = b + running + r;
+      px[d] = ix[o];
+      py[d] = iy[o];
+      pz[d] = iz[o];
+    }
+    running += tot;
+  }
+}
+
+// ---------------------------------------------------------------- tiles
+__global__ __launch_bounds__(1024) void k_tile_scan(int S, const int *__restrict__ cnt,
+                                                    int *__restrict__ tile_off) {
+  __shared__ int s_w[16];
+  int running = 0;
+  for (int b0 = 0; b0 < S; b0 += 1024) {
+    const int s = b0 + threadIdx.x;
+    const int nt = (s < S) ? (cnt[s] + QT - 1) / QT : 0;
+    int tot;
+    const int ex = block_excl_scan<16>(nt, s_w, tot);
+    if (s < S) tile_off[s] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) tile_off[S] = running;
+}
+
+// largest s with tile_off[s] <= t  (t < tile_off[S])
+__device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
+  int lo = 0, hi = S;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_off[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------- a10 radius
+__global__ __launch_bounds__(QT) void k_radius_flags(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, const long long *__restrict__ seg_base,
+    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S,
+    const int *__restrict__ tile_off, uint8_t *__restrict__ flags) {
+  __shared__ double sx[PT], sy[PT], sz[PT];
+  __shared__ int s_pending;
+  const int t = blockIdx.x;
+  if (t >= tile_off[S]) return;
+  const int s = find_segment(tile_off, S, t);
+  const int q0 = (t - tile_off[s]) * QT;
+  const int n = seg_cnt[s];
+  const long long base = seg_base[s];
+  const double r = radius[s];
+  const int q = q0 + threadIdx.x;
+  const bool valid = q < n;
+  if (!(r > 0.0)) {                 // r == 0: no filter; r < 0 (or NaN): drop all
+    if (valid) flags[base + q] = (r == 0.0) ? 1 : 0;
+    return;
+  }
+  const double r2 = r * r;
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
+  int cnt = 0;
+  const int npt = (n + PT - 1) / PT;
+  const int start = q0 / PT;
+  for (int k = 0; k < npt; k++) {
+    int tile = start + k;
+    if (tile >= npt) tile -= npt;
+    const int j0 = tile * PT;
+    const int m = min(PT, n - j0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_pending = 0;
+    for (int i = threadIdx.x; i < m; i += QT) {
+      sx[i] = px[base + j0 + i];
+      sy[i] = py[base + j0 + i];
+      sz[i] = pz[base + j0 + i];
+    }
+    __syncthreads();
+    if (valid && cnt <= nb) {
+      for (int j = 0; j < m; j++) {
+        const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (d < r2) {
+          if (++cnt > nb) break;
+        }
+      }
+      if (cnt <= nb) s_pending = 1;
+    }
+    __syncthreads();
+    if (!s_pending) break;
+  }
+  if (valid) flags[base + q] = (cnt > nb) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- a12 ball query
+__global__ __launch_bounds__(QT) void k_ball_flags(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, const long long *__restrict__ base_a,
+    const int *__restrict__ cnt_a, const long long *__restrict__ base_b,
+    const int *__restrict__ cnt_b, double C, int S, const int *__restrict__ tile_off,
+    uint8_t *__restrict__ flags) {
+  __shared__ double sx[PT], sy[PT], sz[PT];
+  __shared__ int s_pending;
+  const int t = blockIdx.x;
+  if (t >= tile_off[S]) return;
+  const int s = find_segment(tile_off, S, t);
+  const int q0 = (t - tile_off[s]) * QT;
+  const int nq = cnt_b[s], na = cnt_a[s];
+  const long long bq = base_b[s], ba = base_a[s];
+  const int q = q0 + threadIdx.x;
+  const bool valid = q < nq;
+  if (na == 0) {                       // my_loader.py:602: fuse skipped
+    if (valid) flags[bq + q] = 1;
+    return;
+  }
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
+  bool found = false;
+  for (int j0 = 0; j0 < na; j0 += PT) {
+    const int m = min(PT, na - j0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_pending = 0;
+    for (int i = threadIdx.x; i < m; i += QT) {
+      sx[i] = px[ba + j0 + i];
+      sy[i] = py[ba + j0 + i];
+      sz[i] = pz[ba + j0 + i];
+    }
+    __syncthreads();
+    if (valid && !found) {
+      for (int j = 0; j < m; j++) {
+        const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (sqrt(d) < C) { found = true; break; }
+      }
+      if (!found) s_pending = 1;
+    }
+    __syncthreads();
+    if (!s_pending) break;
+  }
+  if (valid) flags[bq + q] = found ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- compaction
+// In-order compaction of segment s by flags.  dst = src (in place) or, when
+// dst_after_base != nullptr, directly behind another segment
+// (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
+__global__ __launch_bounds__(256) void k_seg_compact(
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+    long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
+    const uint8_t *__restrict__ flags, const long long *__restrict__ dst_after_base,
+    const int *__restrict__ dst_after_cnt) {
+  __shared__ int s_w[4];
+  const int s = blockIdx.x;
+  const int n = seg_cnt[s];
+  const long long src = seg_base[s];
+  const long long dst = dst_after_base ? dst_after_base[s] + dst_after_cnt[s] : src;
+  if (n == 0) {
+    if (dst_after_base && threadIdx.x == 0) seg_base[s] = dst;
+    return;
+  }
+  int running = 0;
+  for (int t0 = 0; t0 < n; t0 += 256) {
+    const int i = t0 + threadIdx.x;
+    const bool f = (i < n) && flags[src + i];
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (f) { x = px[src + i]; y = py[src + i]; z = pz[src + i]; }
+    int tot;
+    const int r = block_rank<4>(f, s_w, tot);   // barriers: loads above complete first
+    if (f) {
+      const long long d = dst + running + r;
+      px[d] = x; py[d] = y; pz[d] = z;
+    }
+    running += tot;
+  }
+  if (threadIdx.x == 0) {
+    seg_cnt[s] = running;
+    if (dst_after_base) seg_base[s] = dst;
+  }
+}
+
+// ---------------------------------------------------------------- a11 statistical
+constexpr int KMAX = 64;
+__global__ __launch_bounds__(QT) void k_knn_mean(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, const long long *__restrict__ seg_base,
+    const int *__restrict__ seg_cnt, const int *__restrict__ enable, int knn, int S,
+    const int *__restrict__ tile_off, double *__restrict__ mean_d) {
+  __shared__ double sx[PT], sy[PT], sz[PT];
+  const int t = blockIdx.x;
+  if (t >= tile_off[S]) return;
+  const int s = find_segment(tile_off, S, t);
+  if (!enable[s]) return;
+  const int q0 = (t - tile_off[s]) * QT;
+  const int n = seg_cnt[s];
+  const long long base = seg_base[s];
+  const int q = q0 + threadIdx.x;
+  const bool valid = q < n;
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
+  const int kk = min(knn, n);
+  double best[KMAX];                 // ascending squared distances
+  int nbest = 0;
+  for (int j0 = 0; j0 < n; j0 += PT) {
+    const int m = min(PT, n - j0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += QT) {
+      sx[i] = px[base + j0 + i];
+      sy[i] = py[base + j0 + i];
+      sz[i] = pz[base + j0 + i];
+    }
+    __syncthreads();
+    if (valid) {
+      for (int j = 0; j < m; j++) {
+        const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (nbest < kk || d < best[nbest - 1]) {
+          int p = (nbest < kk) ? nbest : kk - 1;
+          while (p > 0 && best[p - 1] > d) { best[p] = best[p - 1]; p--; }
+          best[p] = d;
+          if (nbest < kk) nbest++;
+        }
+      }
+    }
+  }
+  if (valid) {
+    double sum = 0.0;
+    for (int i = 0; i < nbest; i++) sum += sqrt(best[i]);
+    mean_d[base + q] = nbest > 0 ? sum / (double)nbest : -1.0;
+  }
+}
+
+// per segment: mu, sigma (Bessel) over mean distances, then flags
+__global__ __launch_bounds__(256) void k_stat_flags(
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt,
+    const int *__restrict__ enable, double std_ratio, const double *__restrict__ mean_d,
+    uint8_t *__restrict__ flags) {
+  __shared__ double s_red[4];
+  const int s = blockIdx.x;
+  const int n = seg_cnt[s];
+  const long long base = seg_base[s];
+  if (!enable[s]) {
+    for (int i = threadIdx.x; i < n; i += 256) flags[base + i] = 1;
+    return;
+  }
+  if (n == 0) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double v = mean_d[base + i];
+    acc += (v > 0.0) ? v : 0.0;
+  }
+  acc = wave_sum_d(acc);
+  if (lane_id() == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const double mu = (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]) / (double)n;
+  __syncthreads();
+  acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double v = mean_d[base + i];
+    acc += (v > 0.0) ? (v - mu) * (v - mu) : 0.0;
+  }
+  acc = wave_sum_d(acc);
+  if (lane_id() == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const double sq = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+  const double sd = sqrt(sq / (double)(n - 1));     // n == 1 -> NaN -> nothing kept
+  const double thr = mu + std_ratio * sd;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double v = mean_d[base + i];
+    flags[base + i] = (v > 0.0 && v < thr) ? 1 : 0;
+  }
+}
+
+inline int tile_grid(int64_t pool_cap, int S) {
+  return (int)((pool_cap + QT - 1) / QT + S);
+}
+
+}  // namespace
+
+extern "C" int dfu3d_segments_build(
+    const uint32_t *a_bits, const double *a_x, const double *a_y, const double *a_z,
+    const int32_t *a_n, int32_t a_cap, const uint32_t *b_bits, const double *b_x,
+    const double *b_y, const double *b_z, const int32_t *b_n, int32_t b_cap, int32_t V,
+    int32_t max_inst, int64_t pool_cap, int64_t *pool_cursor, double *px, double *py,
+    double *pz, int64_t *base_a, int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
+    uint32_t *status, void *stream) {
+  if (!a_bits || !a_x || !a_y || !a_z || !a_n || !b_bits || !b_x || !b_y || !b_z || !b_n ||
+      !pool_cursor || !px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !status)
+    return DFU3D_EINVAL;
+  if (V <= 0 || max_inst <= 0 || a_cap <= 0 || b_cap <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
+  if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = V * max_inst;
+  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(256), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(256), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_alloc, dim3(1), dim3(1024), 0, st, S, cnt_a, cnt_b,
+                     (long long *)base_a, (long long *)base_b, (long long)pool_cap,
+                     (long long *)pool_cursor, status);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_write, dim3(S), dim3(256), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
+                     max_inst, (const long long *)base_a, cnt_a, px, py, pz);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_write, dim3(S), dim3(256), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
+                     max_inst, (const long long *)base_b, cnt_b, px, py, pz);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int64_t *seg_base,
+                                   int32_t *seg_cnt, const double *radius, int32_t nb_points,
+                                   int32_t S, int64_t pool_cap, int32_t *tile_off,
+                                   uint8_t *flags, void *stream) {
+  if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags)
+    return DFU3D_EINVAL;
+  if (S <= 0 || pool_cap <= 0 || nb_points < 0) return DFU3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_radius_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+                     (const long long *)seg_base, seg_cnt, radius, nb_points, S, tile_off, flags);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
+                     (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
+                     (const int *)nullptr);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64_t *seg_base,
+                                 int32_t *seg_cnt, const int32_t *enable, int32_t nb_neighbors,
+                                 double std_ratio, int32_t S, int64_t pool_cap,
+                                 int32_t *tile_off, uint8_t *flags, double *mean_d,
+                                 double *stats, void *stream) {
+  (void)stats;
+  if (!px || !py || !pz || !seg_base || !seg_cnt || !enable || !tile_off || !flags || !mean_d)
+    return DFU3D_EINVAL;
+  if (S <= 0 || pool_cap <= 0 || nb_neighbors < 1) return DFU3D_EINVAL;
+  if (nb_neighbors > KMAX) return DFU3D_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_knn_mean, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+                     (const long long *)seg_base, seg_cnt, enable, nb_neighbors, S, tile_off,
+                     mean_d);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_stat_flags, dim3(S), dim3(256), 0, st, (const long long *)seg_base,
+                     seg_cnt, enable, std_ratio, mean_d, flags);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
+                     (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
+                     (const int *)nullptr);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const int64_t *base_a,
+                                    const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
+                                    double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
+                                    uint8_t *flags, void *stream) {
+  if (!px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !tile_off || !flags)
+    return DFU3D_EINVAL;
+  if (S <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ball_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, C, S,
+                     tile_off, flags);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz, (long long *)base_b,
+                     cnt_b, flags, (const long long *)base_a, cnt_a);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}

@@ -1,0 +1,200 @@
+"""Batched pseudo-box generation on one MI355X.
+
+Drives the C-ABI stages (include/dfu3d.h) over a batch of camera views that is
+resident in HBM.  Mirrors the stage order of the reference's
+depth2pointsrgbpm (tools/PENet/dataloaders/my_loader.py:502-617, SURVEY.md
+A.3):  FOV filter -> plane -> above-plane + label inheritance ->
+[back-projection + spherical voxel sampling] -> per-instance radius filters ->
+BallQuery fuse -> range clustering -> rectangle search -> box rows.
+
+Views are processed in chunks (`views_per_chunk`) so that the workspace is
+bounded; no host synchronisation happens inside a chunk -- counts stay on the
+device -- and one sync at the end of run() collects the row counters.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import stages as st
+from ._lib import Dfu3dError
+from .params import Params
+
+
+@dataclass
+class ViewBatch:
+    """Inputs for V camera views over F LiDAR frames (device tensors)."""
+    points: torch.Tensor        # (N,4) f32, frames packed back to back
+    pt_off: torch.Tensor        # (F+1,) i32
+    view_frame: torch.Tensor    # (V,) i32
+    calib: torch.Tensor         # (V,48) f32  (Calibration.record())
+    masks: torch.Tensor         # (V,M,H,W) u8
+    n_inst: torch.Tensor        # (V,) i32
+    inst_class: torch.Tensor    # (V,M) i32  index into the 10 nuScenes names
+    inst_is_car: torch.Tensor   # (V,M) i32  SEEM name == "Car" (my_loader.py:651)
+    inst_r_lidar: torch.Tensor  # (V,M) f64  Params.instance_radii()[0]
+    inst_r_pseudo: torch.Tensor  # (V,M) f64
+    inst_box: torch.Tensor      # (V,M,4) f32 xyxy
+    inst_score: torch.Tensor    # (V,M) f32
+    view_key: torch.Tensor      # (V,) i64   RANSAC stream key
+    host_pt_off: np.ndarray     # CPU copies for argument validation
+    host_view_frame: np.ndarray
+    depth: Optional[torch.Tensor] = None   # (V,H,W) f32; None = sparse mode (H20)
+    plane: Optional[torch.Tensor] = None   # (V,4) f64; None = fit with RANSAC
+
+
+class PseudoBoxEngine:
+    def __init__(self, params: Params, H: int, W: int, max_inst: int, cap_n: int,
+                 views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
+                 pool_per_view: int = 1 << 16, rows_per_view: int = 64,
+                 device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
+        if tuple(params.bounds_hw) != (int(H), int(W)):
+            raise Dfu3dError("params.bounds_hw %s must equal the mask/depth size (%d,%d) "
+                             "(hazard H11: canonical nuScenes = 900x1600 everywhere)"
+                             % (tuple(params.bounds_hw), H, W))
+        self.p = params
+        self.H, self.W, self.M = int(H), int(W), int(max_inst)
+        self.cap_n = int(cap_n)
+        self.Vc = int(views_per_chunk)
+        self.dense = bool(dense)
+        self.cap_vox = int(cap_vox) if dense else 1
+        self.pool_cap = int(pool_per_view) * self.Vc
+        self.cap_rows = int(rows_per_view) * self.Vc
+        self.dev = torch.device(device)
+        self.n_theta, self.dtheta = params.thetas()
+        V, S = self.Vc, self.Vc * self.M
+        d = self.dev
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=d)
+        f64 = lambda *s: torch.empty(s, dtype=torch.float64, device=d)
+        self.fov_idx, self.cand_idx = i32(V * cap_n), i32(V * cap_n)
+        self.ag_pt, self.ib_pix = i32(V * cap_n), i32(V * cap_n)
+        self.n_fov, self.n_ag, self.K = i32(V), i32(V), i32(V)
+        self.plane = f64(V * 4)
+        self.a_bits = i32(V * cap_n)
+        self.a_x, self.a_y, self.a_z = f64(V * cap_n), f64(V * cap_n), f64(V * cap_n)
+        cv = self.cap_vox
+        self.n_vox = torch.zeros(V, dtype=torch.int32, device=d)
+        self.vox_pix, self.b_bits = i32(V * cv), i32(V * cv)
+        self.b_x, self.b_y, self.b_z = f64(V * cv), f64(V * cv), f64(V * cv)
+        if dense:
+            self.geom, self.E = st.make_geom(
+                params.depth_min, params.z_max, params.theta_min, params.vsize,
+                params.vrange_min, params.vgrid, params.max_points_per_voxel, params.max_voxels)
+            self.table = torch.empty(V * self.E * st.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=d)
+            st.bin_table_init(self.table, V * self.E)
+            pw, bw = st.backproject_scratch_words(V, H, W, cv, params.max_points_per_voxel)
+            self.pix_bin, self.blk_cnt = i32(pw), i32(bw)
+        pc = self.pool_cap
+        self.px, self.py, self.pz = f64(pc), f64(pc), f64(pc)
+        self.sx, self.sy = f64(pc), f64(pc)
+        self.label, self.sroot = i32(pc), i32(pc)
+        self.flags = torch.empty(pc, dtype=torch.uint8, device=d)
+        self.mean_d = f64(pc) if params.stat_filter else None
+        self.base_a = torch.empty(S, dtype=torch.int64, device=d)
+        self.base_b = torch.empty(S, dtype=torch.int64, device=d)
+        self.cnt_a, self.cnt_b, self.cnt_all = i32(S), i32(S), i32(S)
+        self.tile_off = i32(S + 1)
+        self.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
+        self.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
+
+    # ------------------------------------------------------------------
+    def _chunk(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
+        p, V, M, H, W = self.p, v1 - v0, self.M, self.H, self.W
+        if V != self.Vc:
+            raise Dfu3dError("internal: chunk size mismatch")
+        S, cap_n = V * M, self.cap_n
+        vf = b.view_frame[v0:v1]
+        calib = b.calib[v0:v1]
+        masks = b.masks[v0:v1]
+        n_inst = b.n_inst[v0:v1]
+        st.fov_filter(b.points, b.pt_off, vf, calib, V, p.fov_hw, cap_n, self.fov_idx,
+                      self.n_fov, b.host_pt_off, b.host_view_frame[v0:v1])
+        if b.plane is None:
+            st.plane_ransac(b.points, b.pt_off, vf, self.fov_idx, self.n_fov, V, cap_n,
+                            p.plane_max_hs, p.plane_range, p.ransac_trials, p.ransac_seed,
+                            b.view_key[v0:v1], self.cand_idx, self.plane)
+            plane = self.plane
+        else:
+            plane = b.plane[v0:v1].reshape(-1)
+        st.project_label(b.points, b.pt_off, vf, calib, plane, self.fov_idx, self.n_fov, masks,
+                         n_inst, V, M, p.bounds_hw[0], p.bounds_hw[1], cap_n, p.plane_offset,
+                         p.plane_range, self.ag_pt, self.ib_pix, self.n_ag, self.K, self.a_bits,
+                         self.a_x, self.a_y, self.a_z)
+        if self.dense and b.depth is not None:
+            st.backproject_bin(b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
+                               self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
+                               self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
+                               self.b_z, status)
+        else:
+            self.n_vox.zero_()
+        self.pool_cursor.zero_()
+        st.segments_build(self.a_bits, self.a_x, self.a_y, self.a_z, self.K, cap_n, self.b_bits,
+                          self.b_x, self.b_y, self.b_z, self.n_vox, self.cap_vox, V, M,
+                          self.pool_cap, self.pool_cursor, self.px, self.py, self.pz,
+                          self.base_a, self.cnt_a, self.base_b, self.cnt_b, status)
+        rl = b.inst_r_lidar[v0:v1].reshape(-1)
+        rp = b.inst_r_pseudo[v0:v1].reshape(-1)
+        st.radius_filter(self.px, self.py, self.pz, self.base_a, self.cnt_a, rl, p.nb_points, S,
+                         self.pool_cap, self.tile_off, self.flags)
+        st.radius_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, rp, p.nb_points, S,
+                         self.pool_cap, self.tile_off, self.flags)
+        if p.stat_filter:
+            st.stat_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
+                           p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
+                           self.tile_off, self.flags, self.mean_d)
+        st.ballquery_fuse(self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
+                          self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags)
+        torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
+        st.range_cluster(self.px, self.py, self.base_a, self.cnt_all, S, p.R0, p.Rd, self.label,
+                         self.pool_cap)
+        st.lshape_fit(self.px, self.py, self.pz, self.label, self.base_a, self.cnt_all, S, M,
+                      calib, b.inst_class[v0:v1].reshape(-1), b.inst_is_car[v0:v1].reshape(-1),
+                      b.inst_box[v0:v1].reshape(-1), b.inst_score[v0:v1].reshape(-1),
+                      self.n_theta, self.dtheta, p.car_aspect_max, self.sx, self.sy, self.sroot,
+                      self.cap_rows, rows, n_rows, status, self.pool_cap)
+
+    # ------------------------------------------------------------------
+    def run(self, b: ViewBatch, sync: bool = True):
+        """-> (rows (n,18) f64 device tensor sorted by (view, inst, cluster), status word)."""
+        V = b.view_frame.numel()
+        if V % self.Vc:
+            raise Dfu3dError("number of views (%d) must be a multiple of views_per_chunk (%d)"
+                             % (V, self.Vc))
+        if tuple(b.masks.shape) != (V, self.M, self.H, self.W):
+            raise Dfu3dError("masks: expected shape %s" % ((V, self.M, self.H, self.W),))
+        if b.depth is not None and tuple(b.depth.shape) != (V, self.H, self.W):
+            raise Dfu3dError("depth: expected shape %s" % ((V, self.H, self.W),))
+        nch = V // self.Vc
+        d = self.dev
+        rows = torch.empty((nch, self.cap_rows * st.ROW_DOUBLES), dtype=torch.float64, device=d)
+        n_rows = torch.zeros((nch,), dtype=torch.int32, device=d)
+        status = torch.zeros((nch,), dtype=torch.int32, device=d)
+        for c in range(nch):
+            self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
+                        status[c:c + 1])
+        self._last = (rows, n_rows, status)
+        if not sync:
+            return None, None
+        return self.collect()
+
+    def collect(self):
+        rows, n_rows, status = self._last
+        counts = n_rows.cpu().numpy()                   # the one host sync
+        stw = int(np.bitwise_or.reduce(status.cpu().numpy().astype(np.int64)))
+        parts = []
+        for c, n in enumerate(counts):
+            n = int(min(n, self.cap_rows))
+            if n:
+                r = rows[c].view(self.cap_rows, st.ROW_DOUBLES)[:n].clone()
+                r[:, 0] += c * self.Vc
+                parts.append(r)
+        if parts:
+            out = torch.cat(parts, 0)
+            key = (out[:, 0].long() * self.M + out[:, 1].long()) * (1 << 31) + out[:, 2].long()
+            out = out[torch.argsort(key)]
+        else:
+            out = torch.empty((0, st.ROW_DOUBLES), dtype=torch.float64, device=self.dev)
+        return out, stw

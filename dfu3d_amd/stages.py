@@ -1,0 +1,280 @@
+"""Shape-checked Python wrappers over the C ABI (one per entry point of
+include/dfu3d.h).  PyTorch is used for device memory and streams only; every
+operand's dtype, device, contiguity and size is verified on the host before a
+hand-written kernel is launched (a faulting kernel can reset the whole node).
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import BinGeom, Dfu3dError
+
+CALIB_FLOATS = 48
+ROW_DOUBLES = 18
+MAX_INST = 32
+
+ST_POOL_OVERFLOW = 1
+ST_VOX_OVERFLOW = 2
+ST_ROW_OVERFLOW = 4
+ST_BIN_RANGE = 8
+ST_VOX_PTS_OVERFLOW = 16
+STATUS_TEXT = {
+    ST_POOL_OVERFLOW: "instance point pool too small (raise pool_cap)",
+    ST_VOX_OVERFLOW: "more voxels than cap_vox in a view (raise cap_vox; bin table must be re-initialised)",
+    ST_ROW_OVERFLOW: "more box rows than cap_rows",
+    ST_BIN_RANGE: "a spherical bin fell outside the bin table",
+    ST_VOX_PTS_OVERFLOW: "overflow-bin pixel list too small",
+}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype, numel=None, min_numel=None):
+    if not isinstance(t, torch.Tensor):
+        raise Dfu3dError("%s: expected a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise Dfu3dError("%s: must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != dtype:
+        raise Dfu3dError("%s: dtype %s, expected %s" % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise Dfu3dError("%s: must be contiguous" % name)
+    if numel is not None and t.numel() != numel:
+        raise Dfu3dError("%s: %d elements, expected %d" % (name, t.numel(), numel))
+    if min_numel is not None and t.numel() < min_numel:
+        raise Dfu3dError("%s: %d elements, need at least %d" % (name, t.numel(), min_numel))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def make_geom(depth_min=0.001, z_max=1.0, theta_min=1.5,
+              vsize=(200.0, 0.0020000000949949026, 0.0020000000949949026),
+              vrange_min=(-100.0, -5.0, -5.0), vgrid=(1, 5000, 5000),
+              max_points_per_voxel=100, max_voxels=1000000):
+    g = BinGeom()
+    g.vsize_r, g.vsize_t, g.vsize_p = vsize
+    g.rmin_r, g.rmin_t, g.rmin_p = vrange_min
+    g.grid_r, g.grid_t, g.grid_p = vgrid
+    g.max_points_per_voxel = int(max_points_per_voxel)
+    g.max_voxels = int(max_voxels)
+    g.theta_min, g.z_max, g.depth_min = theta_min, z_max, depth_min
+    n = _lib.lib().dfu3d_bin_table_geometry(ctypes.byref(g))
+    if n <= 0:
+        raise Dfu3dError("invalid voxel geometry")
+    return g, int(n)
+
+
+def backproject_scratch_words(V, H, W, cap_vox, max_points):
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = _lib.lib().dfu3d_backproject_scratch_words(V, H, W, cap_vox, max_points,
+                                                    ctypes.byref(a), ctypes.byref(b))
+    if rc != 0:
+        raise Dfu3dError("dfu3d_backproject_scratch_words: invalid sizes")
+    return a.value, b.value
+
+
+TABLE_ENTRY_BYTES = 20
+
+
+def bin_table_init(table, entries_total):
+    p = _chk(table, "table", torch.uint8, min_numel=entries_total * TABLE_ENTRY_BYTES)
+    if table.data_ptr() % 8:
+        raise Dfu3dError("table: must be 8-byte aligned")
+    _lib.check(_lib.lib().dfu3d_bin_table_init(p, entries_total, _stream()), "bin_table_init")
+
+
+def _check_frames(points, pt_off, view_frame, V, cap_n, host_pt_off=None, host_view_frame=None):
+    """host_* are CPU copies used for bounds validation (no device sync)."""
+    if points.dim() != 2 or points.shape[1] != 4:
+        raise Dfu3dError("points: expected (N,4)")
+    if host_pt_off is not None:
+        off = [int(x) for x in host_pt_off]
+        if off[0] < 0 or off[-1] > points.shape[0] or any(b < a for a, b in zip(off, off[1:])):
+            raise Dfu3dError("pt_off: not a monotone partition of points")
+        if max(b - a for a, b in zip(off, off[1:])) > cap_n:
+            raise Dfu3dError("cap_n smaller than the largest frame")
+        if host_view_frame is not None:
+            vf = [int(x) for x in host_view_frame]
+            if len(vf) != V or min(vf) < 0 or max(vf) >= len(off) - 1:
+                raise Dfu3dError("view_frame: frame index out of range")
+
+
+def fov_filter(points, pt_off, view_frame, calib, V, fov_hw, cap_n, fov_idx, n_fov,
+               host_pt_off=None, host_view_frame=None):
+    _check_frames(points, pt_off, view_frame, V, cap_n, host_pt_off, host_view_frame)
+    rc = _lib.lib().dfu3d_fov_filter(
+        _chk(points, "points", torch.float32), _chk(pt_off, "pt_off", torch.int32, min_numel=2),
+        _chk(view_frame, "view_frame", torch.int32, numel=V),
+        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS), V, int(fov_hw[0]),
+        int(fov_hw[1]), cap_n, _chk(fov_idx, "fov_idx", torch.int32, numel=V * cap_n),
+        _chk(n_fov, "n_fov", torch.int32, numel=V), _stream())
+    _lib.check(rc, "dfu3d_fov_filter")
+
+
+def plane_ransac(points, pt_off, view_frame, fov_idx, n_fov, V, cap_n, max_hs, xy_range,
+                 trials, seed, key, cand_idx, plane):
+    rc = _lib.lib().dfu3d_plane_ransac(
+        _chk(points, "points", torch.float32), _chk(pt_off, "pt_off", torch.int32, min_numel=2),
+        _chk(view_frame, "view_frame", torch.int32, numel=V),
+        _chk(fov_idx, "fov_idx", torch.int32, numel=V * cap_n),
+        _chk(n_fov, "n_fov", torch.int32, numel=V), V, cap_n, float(max_hs), float(xy_range),
+        int(trials), ctypes.c_uint64(int(seed) & ((1 << 64) - 1)),
+        _chk(key, "key", torch.int64, numel=V),
+        _chk(cand_idx, "cand_idx", torch.int32, numel=V * cap_n),
+        _chk(plane, "plane", torch.float64, numel=V * 4), _stream())
+    _lib.check(rc, "dfu3d_plane_ransac")
+
+
+def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, masks, n_inst, V,
+                  max_inst, H, W, cap_n, plane_offset, xy_range, ag_pt, ib_pix, n_ag, K,
+                  it_bits, it_x, it_y, it_z):
+    if max_inst < 1 or max_inst > MAX_INST:
+        raise Dfu3dError("max_inst must be in [1, %d]" % MAX_INST)
+    rc = _lib.lib().dfu3d_project_label(
+        _chk(points, "points", torch.float32), _chk(pt_off, "pt_off", torch.int32, min_numel=2),
+        _chk(view_frame, "view_frame", torch.int32, numel=V),
+        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS),
+        _chk(plane, "plane", torch.float64, numel=V * 4),
+        _chk(fov_idx, "fov_idx", torch.int32, numel=V * cap_n),
+        _chk(n_fov, "n_fov", torch.int32, numel=V),
+        _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W),
+        _chk(n_inst, "n_inst", torch.int32, numel=V), V, max_inst, H, W, cap_n,
+        float(plane_offset), float(xy_range),
+        _chk(ag_pt, "ag_pt", torch.int32, numel=V * cap_n),
+        _chk(ib_pix, "ib_pix", torch.int32, numel=V * cap_n),
+        _chk(n_ag, "n_ag", torch.int32, numel=V), _chk(K, "K", torch.int32, numel=V),
+        _chk(it_bits, "it_bits", torch.int32, numel=V * cap_n),
+        _chk(it_x, "it_x", torch.float64, numel=V * cap_n),
+        _chk(it_y, "it_y", torch.float64, numel=V * cap_n),
+        _chk(it_z, "it_z", torch.float64, numel=V * cap_n), _stream())
+    _lib.check(rc, "dfu3d_project_label")
+
+
+def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_entries,
+                    key_axis, table, pix_bin, blk_cnt, cap_vox, n_vox, vox_pix, it_bits, it_x,
+                    it_y, it_z, status):
+    pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel)
+    if table.data_ptr() % 8:
+        raise Dfu3dError("table: must be 8-byte aligned")
+    if pix_bin.data_ptr() % 16 or depth.data_ptr() % 16:
+        raise Dfu3dError("depth / pix_bin: must be 16-byte aligned")
+    if (H * W) % 4:
+        raise Dfu3dError("H*W must be a multiple of 4 (float4 depth loads)")
+    mp = _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W) if masks is not None else None
+    ni = _chk(n_inst, "n_inst", torch.int32, numel=V) if n_inst is not None else None
+    rc = _lib.lib().dfu3d_backproject_bin(
+        _chk(depth, "depth", torch.float32, numel=V * H * W),
+        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS), mp, ni, V, max_inst, H, W,
+        ctypes.byref(geom), int(key_axis),
+        _chk(table, "table", torch.uint8, min_numel=V * table_entries * TABLE_ENTRY_BYTES),
+        _chk(pix_bin, "pix_bin", torch.int32, min_numel=pw),
+        _chk(blk_cnt, "blk_cnt", torch.int32, min_numel=bw), cap_vox,
+        _chk(n_vox, "n_vox", torch.int32, numel=V),
+        _chk(vox_pix, "vox_pix", torch.int32, numel=V * cap_vox),
+        _chk(it_bits, "it_bits", torch.int32, numel=V * cap_vox),
+        _chk(it_x, "it_x", torch.float64, numel=V * cap_vox),
+        _chk(it_y, "it_y", torch.float64, numel=V * cap_vox),
+        _chk(it_z, "it_z", torch.float64, numel=V * cap_vox),
+        _chk(status, "status", torch.int32, min_numel=1), _stream())
+    _lib.check(rc, "dfu3d_backproject_bin")
+
+
+def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n, b_cap, V,
+                   max_inst, pool_cap, pool_cursor, px, py, pz, base_a, cnt_a, base_b, cnt_b,
+                   status):
+    S = V * max_inst
+    rc = _lib.lib().dfu3d_segments_build(
+        _chk(a_bits, "a_bits", torch.int32, numel=V * a_cap),
+        _chk(a_x, "a_x", torch.float64, numel=V * a_cap),
+        _chk(a_y, "a_y", torch.float64, numel=V * a_cap),
+        _chk(a_z, "a_z", torch.float64, numel=V * a_cap), _chk(a_n, "a_n", torch.int32, numel=V),
+        a_cap, _chk(b_bits, "b_bits", torch.int32, numel=V * b_cap),
+        _chk(b_x, "b_x", torch.float64, numel=V * b_cap),
+        _chk(b_y, "b_y", torch.float64, numel=V * b_cap),
+        _chk(b_z, "b_z", torch.float64, numel=V * b_cap), _chk(b_n, "b_n", torch.int32, numel=V),
+        b_cap, V, max_inst, pool_cap, _chk(pool_cursor, "pool_cursor", torch.int64, numel=1),
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap),
+        _chk(base_a, "base_a", torch.int64, numel=S), _chk(cnt_a, "cnt_a", torch.int32, numel=S),
+        _chk(base_b, "base_b", torch.int64, numel=S), _chk(cnt_b, "cnt_b", torch.int32, numel=S),
+        _chk(status, "status", torch.int32, min_numel=1), _stream())
+    _lib.check(rc, "dfu3d_segments_build")
+
+
+def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap, tile_off, flags):
+    rc = _lib.lib().dfu3d_radius_filter(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap),
+        _chk(seg_base, "seg_base", torch.int64, numel=S),
+        _chk(seg_cnt, "seg_cnt", torch.int32, numel=S),
+        _chk(radius, "radius", torch.float64, numel=S), int(nb_points), S, pool_cap,
+        _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
+        _chk(flags, "flags", torch.uint8, numel=pool_cap), _stream())
+    _lib.check(rc, "dfu3d_radius_filter")
+
+
+def stat_filter(px, py, pz, seg_base, seg_cnt, enable, nb_neighbors, std_ratio, S, pool_cap,
+                tile_off, flags, mean_d):
+    rc = _lib.lib().dfu3d_stat_filter(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap),
+        _chk(seg_base, "seg_base", torch.int64, numel=S),
+        _chk(seg_cnt, "seg_cnt", torch.int32, numel=S),
+        _chk(enable, "enable", torch.int32, numel=S), int(nb_neighbors), float(std_ratio), S,
+        pool_cap, _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
+        _chk(flags, "flags", torch.uint8, numel=pool_cap),
+        _chk(mean_d, "mean_d", torch.float64, numel=pool_cap), None, _stream())
+    _lib.check(rc, "dfu3d_stat_filter")
+
+
+def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off, flags):
+    rc = _lib.lib().dfu3d_ballquery_fuse(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap),
+        _chk(base_a, "base_a", torch.int64, numel=S), _chk(cnt_a, "cnt_a", torch.int32, numel=S),
+        _chk(base_b, "base_b", torch.int64, numel=S), _chk(cnt_b, "cnt_b", torch.int32, numel=S),
+        float(C), S, pool_cap, _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
+        _chk(flags, "flags", torch.uint8, numel=pool_cap), _stream())
+    _lib.check(rc, "dfu3d_ballquery_fuse")
+
+
+def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap):
+    rc = _lib.lib().dfu3d_range_cluster(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(seg_base, "seg_base", torch.int64, numel=S),
+        _chk(seg_cnt, "seg_cnt", torch.int32, numel=S), S, float(R0), float(Rd),
+        _chk(label, "label", torch.int32, numel=pool_cap), _stream())
+    _lib.check(rc, "dfu3d_range_cluster")
+
+
+def lshape_fit(px, py, pz, label, seg_base, seg_cnt, S, max_inst, calib, inst_class,
+               inst_is_car, inst_box, inst_score, n_theta, dtheta, car_aspect_max, sx, sy,
+               sroot, cap_rows, rows, n_rows, status, pool_cap):
+    if S % max_inst:
+        raise Dfu3dError("S must be V*max_inst")
+    V = S // max_inst
+    rc = _lib.lib().dfu3d_lshape_fit(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap),
+        _chk(label, "label", torch.int32, numel=pool_cap),
+        _chk(seg_base, "seg_base", torch.int64, numel=S),
+        _chk(seg_cnt, "seg_cnt", torch.int32, numel=S), S, max_inst,
+        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS),
+        _chk(inst_class, "inst_class", torch.int32, numel=S),
+        _chk(inst_is_car, "inst_is_car", torch.int32, numel=S),
+        _chk(inst_box, "inst_box", torch.float32, numel=S * 4),
+        _chk(inst_score, "inst_score", torch.float32, numel=S), int(n_theta), float(dtheta),
+        float(car_aspect_max), _chk(sx, "sx", torch.float64, numel=pool_cap),
+        _chk(sy, "sy", torch.float64, numel=pool_cap),
+        _chk(sroot, "sroot", torch.int32, numel=pool_cap), cap_rows,
+        _chk(rows, "rows", torch.float64, numel=cap_rows * ROW_DOUBLES),
+        _chk(n_rows, "n_rows", torch.int32, numel=1),
+        _chk(status, "status", torch.int32, min_numel=1), _stream())
+    _lib.check(rc, "dfu3d_lshape_fit")
+
+
+def status_message(word):
+    return "; ".join(t for b, t in STATUS_TEXT.items() if word & b) or "ok"

@@ -1,0 +1,228 @@
+/*
+ * dfu3d.h -- C ABI of libdfu3d_hip.so: the MI355X (gfx950) implementation of
+ * DFU3D's pseudo-box generation hot path.
+ *
+ * The reference has no FFI layer on this path: it is pure Python/NumPy calling
+ * third-party natives.  Each entry point below therefore
+ * replaces one reference *function body* (cited as file:line under
+ * tools/PENet/ of the reference) and is what the reference's Python would bind
+ * with ctypes (binding stubs: INTEGRATION.md).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never
+ *     allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - returns DFU3D_OK or a negative DFU3D_E* code for host-detectable argument
+ *     errors; device-detected conditions (capacity overflow) set bits in the
+ *     caller's `status` word(s) -- see DFU3D_ST_*;
+ *   - re-entrant across streams as long as the buffers differ; no global state.
+ *
+ * Data model.  A launch covers V camera *views*; view v looks at LiDAR frame
+ * view_frame[v] whose points are rows pt_off[f] .. pt_off[f+1] of the packed
+ * (N,4) float32 tensor `points`.  Per-view calibration is 48 floats
+ * (DFU3D_CALIB_FLOATS): M43[12] = (V2C^T @ R0^T) row-major (4,3); P2[12] row-major
+ * (3,4); cu,cv,fu,fv,tx,ty; Minv[12] = rows 0..3 x cols 0..2 of
+ * inv((R0_ext @ V2C_ext)^T); 6 pad  (calibration_kitti.py:62-102).
+ * Instance *segments* are indexed s = v*max_inst + j.  Per-instance point sets
+ * live in a structure-of-arrays fp64 pool (px,py,pz) at [seg_base[s],
+ * seg_base[s]+seg_cnt[s]).
+ */
+#ifndef DFU3D_H
+#define DFU3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFU3D_VERSION 100          /* 0.1.0 */
+#define DFU3D_CALIB_FLOATS 48
+#define DFU3D_ROW_DOUBLES 18       /* see dfu3d_lshape_fit */
+#define DFU3D_MAX_INST 32
+
+#define DFU3D_OK 0
+#define DFU3D_EINVAL (-1)          /* bad argument (null pointer, size <= 0 ...) */
+#define DFU3D_ELAUNCH (-2)         /* hipLaunch failed (see hipGetLastError)    */
+#define DFU3D_ERANGE (-3)          /* size exceeds a compiled-in limit          */
+
+/* bits OR-ed into *status by kernels */
+#define DFU3D_ST_POOL_OVERFLOW 1u   /* instance pool too small (seg_alloc)      */
+#define DFU3D_ST_VOX_OVERFLOW 2u    /* more voxels than cap_vox in a view       */
+#define DFU3D_ST_ROW_OVERFLOW 4u    /* more box rows than cap_rows              */
+#define DFU3D_ST_BIN_RANGE 8u       /* a spherical bin fell outside the table   */
+#define DFU3D_ST_VOX_PTS_OVERFLOW 16u /* overflow-bin list too small            */
+
+int dfu3d_version(void);
+const char *dfu3d_strerror(int code);
+
+/* Geometry of the spherical-bin table used by dfu3d_backproject_bin.  Filled by
+ * dfu3d_bin_table_geometry from the voxel parameters (my_loader.py:69-83). */
+typedef struct dfu3d_bin_geom {
+  double vsize_r, vsize_t, vsize_p;   /* voxel size (r, theta, phi)           */
+  double rmin_r, rmin_t, rmin_p;      /* range minimum                        */
+  int32_t grid_r, grid_t, grid_p;     /* grid size (1, 5000, 5000)            */
+  int32_t t_lo, t_n;                  /* table rows cover theta bins [t_lo, t_lo+t_n) */
+  int32_t p_lo, p_n;                  /* table cols cover phi bins            */
+  int32_t max_points_per_voxel;       /* 100                                   */
+  int32_t max_voxels;                 /* 1000000                               */
+  double theta_min;                   /* 1.5  (my_loader.py:175)               */
+  double z_max;                       /* 1.0  (my_loader.py:540)               */
+  double depth_min;                   /* 0.001 (my_loader.py:507)              */
+} dfu3d_bin_geom;
+
+/* Host helper (no GPU work): fills t_lo/t_n/p_lo/p_n so that every bin
+ * reachable with theta in (theta_min, pi], phi in [-pi/2, pi/2] is inside the
+ * table; returns the number of table entries per view (t_n * p_n). */
+int64_t dfu3d_bin_table_geometry(dfu3d_bin_geom *g);
+
+/* ---- a4: get_fov_flag (vis_utils.py:108-123, 152-154) ----------------------
+ * fov_idx[v*cap_n + k] = frame-local index of the k-th point of view v's frame
+ * with 0<=u<fov_w, 0<=v<fov_h, depth>=0 (unrounded float32 u,v); n_fov[v] = count. */
+int dfu3d_fov_filter(const float *points, const int32_t *pt_off,
+                     const int32_t *view_frame, const float *calib, int32_t V,
+                     int32_t fov_h, int32_t fov_w, int32_t cap_n,
+                     int32_t *fov_idx, int32_t *n_fov, void *stream);
+
+/* ---- a5: estimate_plane (my_loader.py:448-469), seeded RANSAC (hazard H1) ---
+ * plane[v][4] (fp64, unit normal up, offset).  cand_idx: int32 scratch
+ * (V*cap_n).  key[v] seeds the per-view sample stream. */
+int dfu3d_plane_ransac(const float *points, const int32_t *pt_off,
+                       const int32_t *view_frame, const int32_t *fov_idx,
+                       const int32_t *n_fov, int32_t V, int32_t cap_n,
+                       double max_hs, double xy_range, int32_t trials,
+                       uint64_t seed, const int64_t *key, int32_t *cand_idx,
+                       double *plane, void *stream);
+
+/* ---- a5/a6: above_plane + point->pixel label inheritance
+ * (my_loader.py:471-477, 517-530; hazard H3) ---------------------------------
+ * For view v: rows t < K[v] are the first K above-plane FOV points; row t gets
+ * the instance bits of the t-th IN-BOUNDS rounded pixel.  Outputs per row:
+ * it_bits (bit j = uint8 mask_j > 0), it_x/y/z (fp64 coordinates of the row's
+ * point), all at [v*cap_n + t]; n_ag[v], K[v].
+ * masks: uint8 (V, max_inst, H, W); n_inst[v] <= max_inst <= 32.
+ * ag_pt / ib_pix: int32 scratch (V*cap_n each). */
+int dfu3d_project_label(const float *points, const int32_t *pt_off,
+                        const int32_t *view_frame, const float *calib,
+                        const double *plane, const int32_t *fov_idx,
+                        const int32_t *n_fov, const uint8_t *masks,
+                        const int32_t *n_inst, int32_t V, int32_t max_inst,
+                        int32_t H, int32_t W, int32_t cap_n,
+                        double plane_offset, double xy_range,
+                        int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag,
+                        int32_t *K, uint32_t *it_bits, double *it_x,
+                        double *it_y, double *it_z, void *stream);
+
+/* ---- a7/a8/a9: back-projection + spherical voxel sampling
+ * (my_loader.py:507-509, 532-557, 166-180, 247-275) --------------------------
+ * depth: float32 (V,H,W).  For every view: back-project all pixels with
+ * depth >= depth_min (fp64), keep z_lidar < z_max and theta > theta_min, bin
+ * (r,theta,phi), keep at most max_points_per_voxel points per bin in pixel
+ * order, choose the first argmin of KEY among them (key_axis 1 = y:
+ * la_sampling20, 2 = z: la_sampling2), emit voxels in first-seen order.
+ * Outputs per voxel k < n_vox[v] at [v*cap_vox + k]: vox_pix (pixel index of
+ * the representative), it_x/y/z (its fp64 LiDAR coordinates), it_bits
+ * (instance bits at that pixel; masks may be NULL -> 0).
+ * `geom` is a HOST pointer (read at call time).
+ * Scratch: pix_bin (uint32 words) and blk_cnt (int32 words) sized by
+ * dfu3d_backproject_scratch_words; table: V*table_entries entries of 20 B
+ * (uint64 min-key plane, then uint32 count / first-pixel / representative
+ * planes), initialised once with dfu3d_bin_table_init and left clean by every
+ * call that returns without DFU3D_ST_VOX_OVERFLOW. */
+int dfu3d_bin_table_init(void *table, int64_t table_entries_total, void *stream);
+int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
+                                        int32_t cap_vox, int32_t max_points,
+                                        int64_t *pix_words, int64_t *blk_words);
+int dfu3d_backproject_bin(const float *depth, const float *calib,
+                          const uint8_t *masks, const int32_t *n_inst,
+                          int32_t V, int32_t max_inst, int32_t H, int32_t W,
+                          const dfu3d_bin_geom *geom, int32_t key_axis,
+                          void *table, uint32_t *pix_bin, int32_t *blk_cnt,
+                          int32_t cap_vox, int32_t *n_vox, uint32_t *vox_pix,
+                          uint32_t *it_bits, double *it_x, double *it_y,
+                          double *it_z, uint32_t *status, void *stream);
+
+/* ---- per-instance point sets (my_loader.py:547-565) ------------------------
+ * Builds, for every segment s = v*max_inst + j, the ordered list of LiDAR rows
+ * (items A) and voxel representatives (items B) whose bit j is set, in the
+ * fp64 pool: [base_a[s], +cnt_a[s]) followed directly by [base_b[s], +cnt_b[s]).
+ * pool_cursor: device int64 (in/out) next free pool slot. */
+int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
+                         const double *a_y, const double *a_z,
+                         const int32_t *a_n, int32_t a_cap,
+                         const uint32_t *b_bits, const double *b_x,
+                         const double *b_y, const double *b_z,
+                         const int32_t *b_n, int32_t b_cap, int32_t V,
+                         int32_t max_inst, int64_t pool_cap,
+                         int64_t *pool_cursor, double *px, double *py,
+                         double *pz, int64_t *base_a, int32_t *cnt_a,
+                         int64_t *base_b, int32_t *cnt_b, uint32_t *status,
+                         void *stream);
+
+/* ---- a10: Open3D remove_radius_outlier (my_loader.py:581-599) --------------
+ * In-place, order-preserving: keeps point i of segment s iff
+ * #{j in s : |p_i-p_j|^2 < radius[s]^2, j == i included} > nb_points.
+ * radius[s] < 0 drops the whole segment (hazard H4), radius[s] == 0 keeps it.
+ * Scratch: tile_off int32 (S+1), flags uint8 (pool_cap). */
+int dfu3d_radius_filter(double *px, double *py, double *pz,
+                        const int64_t *seg_base, int32_t *seg_cnt,
+                        const double *radius, int32_t nb_points, int32_t S,
+                        int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
+                        void *stream);
+
+/* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
+ * keep i iff 0 < mean_knn_dist_i < mu + std_ratio * sigma (self included in
+ * the k nearest; Bessel sigma).  Scratch: mean_d fp64 (pool_cap), stats fp64
+ * (S*4), tile_off, flags as above.  Segments with enable[s]==0 are untouched. */
+int dfu3d_stat_filter(double *px, double *py, double *pz,
+                      const int64_t *seg_base, int32_t *seg_cnt,
+                      const int32_t *enable, int32_t nb_neighbors,
+                      double std_ratio, int32_t S, int64_t pool_cap,
+                      int32_t *tile_off, uint8_t *flags, double *mean_d,
+                      double *stats, void *stream);
+
+/* ---- a12: BallQuery fuse (my_loader.py:489-494, 601-605) -------------------
+ * Keeps query point i of segment B iff min_j |q_i - a_j| < C over segment A
+ * (strict; skipped -- all kept -- when either set is empty), then moves the
+ * survivors to directly follow segment A: on return the instance's points are
+ * [base_a[s], base_a[s] + cnt_a[s] + cnt_b[s]) and base_b[s] is updated. */
+int dfu3d_ballquery_fuse(double *px, double *py, double *pz,
+                         const int64_t *base_a, const int32_t *cnt_a,
+                         int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
+                         int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
+                         void *stream);
+
+/* ---- a13: _adoptive_range_segmentation (rectangle_fitting.py:161-191) ------
+ * label[seg_base[s] + i] = smallest in-segment index of the cluster that
+ * contains point i (clusters = connected components of d_ij <= R_i or
+ * d_ij <= R_j, R = R0 + Rd*|p|_xy).  No wall-clock abort (hazard H2). */
+int dfu3d_range_cluster(const double *px, const double *py,
+                        const int64_t *seg_base, const int32_t *seg_cnt,
+                        int32_t S, double R0, double Rd, int32_t *label,
+                        void *stream);
+
+/* ---- a14/a15: _rectangle_search + GenerateAnns
+ * (rectangle_fitting.py:83-159; my_loader.py:633-702) ------------------------
+ * One row per (segment, cluster) in rows[DFU3D_ROW_DOUBLES]:
+ *   0 view, 1 inst j, 2 cluster k, 3 class index, 4 alpha, 5..8 bbox x1 y1 x2 y2,
+ *   9 h, 10 w, 11 l, 12 x, 13 y, 14 z (rect camera), 15 ry, 16 score,
+ *   17 number of cluster points.
+ * Rows are appended in arbitrary order (sort by cols 0..2); n_rows is a device
+ * counter.  inst_class/inst_is_car: int32 (S); inst_box: float32 (S,4);
+ * inst_score float32 (S).  Scratch: sx, sy fp64 (pool_cap), sroot int32
+ * (pool_cap). */
+int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
+                     const int32_t *label, const int64_t *seg_base,
+                     const int32_t *seg_cnt, int32_t S, int32_t max_inst,
+                     const float *calib, const int32_t *inst_class,
+                     const int32_t *inst_is_car, const float *inst_box,
+                     const float *inst_score, int32_t n_theta, double dtheta,
+                     double car_aspect_max, double *sx, double *sy,
+                     int32_t *sroot, int32_t cap_rows, double *rows,
+                     int32_t *n_rows, uint32_t *status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFU3D_H */

@@ -1,0 +1,68 @@
+"""CPU-only tests of the host logic: calibration record, parameters, synthetic
+scene generator (no GPU compute)."""
+import numpy as np
+import pytest
+
+from oracle import penet_oracle as O
+
+
+def test_calibration_record_matches_oracle(golden_dir, tmp_path):
+    from dfu3d_amd.calibration import Calibration
+    g = np.load(golden_dir + "/g1_calib.npz")
+    for tag in ("a", "b"):
+        p = tmp_path / (tag + ".txt")
+        p.write_bytes(bytes(g[tag + "_text"]))
+        c = Calibration(str(p))
+        o = O.Calibration(str(p))
+        assert np.array_equal(c.P2, g[tag + "_P2"]) and np.array_equal(c.V2C, g[tag + "_V2C"])
+        assert np.array_equal(c.M43, o.M43)                     # explicit FMA chain == C fmaf chain
+        assert np.array_equal(c.M43, np.dot(c.V2C.T, c.R0.T))   # == the reference's np.dot here
+        assert np.array_equal(c.Minv, o.Minv)
+        r = c.record()
+        assert r.shape == (48,) and r.dtype == np.float32
+        assert np.array_equal(r[24:30], g[tag + "_scal"])
+
+
+def test_round_f32_is_exact():
+    from fractions import Fraction
+    from dfu3d_amd.calibration import _round_f32
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        a, b, c = rng.normal(0, 10, 3).astype(np.float32)
+        q = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+        r = _round_f32(q)
+        lo, hi = np.nextafter(r, np.float32(-np.inf)), np.nextafter(r, np.float32(np.inf))
+        assert abs(Fraction(float(r)) - q) <= abs(Fraction(float(lo)) - q)
+        assert abs(Fraction(float(r)) - q) <= abs(Fraction(float(hi)) - q)
+
+
+def test_params_match_oracle_defaults():
+    from dfu3d_amd.params import Params
+    p, o = Params(), O.Params()
+    for k in O.Params.__dataclass_fields__:
+        assert getattr(p, k) == getattr(o, k), k
+    assert p.thetas()[0] == 89
+    assert p.instance_radii("Car") == (3.0, 3.0)
+    assert p.instance_radii("Pedestrian") == (-1.0, 0.6)
+    assert p.instance_radii("Person ride a bike") == (0.0, 0.0)
+
+
+def test_synthetic_scene_shapes_and_oracle_runs():
+    from dfu3d_amd import synth
+    from dfu3d_amd.params import Params
+    s = synth.make_scene(7, H=90, W=160, M=4, cams=2, dense=True, k_min=10, k_max=12)
+    assert s.points.shape == (34720, 4) and s.depth.shape == (2, 90, 160)
+    assert s.masks.shape == (2, 4, 90, 160)
+    p = Params(bounds_hw=(90, 160), fov_hw=(90, 160))
+    b = synth.to_view_batch([s], p, "cpu")
+    assert b.calib.shape == (2, 48) and b.view_frame.tolist() == [0, 0]
+    cal = s.calibs[0]
+    oc = O.Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
+    lid, _ = O.fov_filter(s.points.numpy(), oc, p.fov_hw)
+    n = int(s.n_inst[0])
+    op = O.Params(bounds_hw=(90, 160), fov_hw=(90, 160))
+    res = O.depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], None, oc, lid, O.NUSC_CLASSES,
+                              s.masks[0][:n].numpy().astype(np.float32), s.inst_class[0][:n].numpy(),
+                              s.inst_box[0][:n].numpy(), op, want_points=False)
+    assert res.plane.shape == (4,)
+    assert abs(res.plane[3] - 1.84) < 0.1       # ground at z = -1.84
