@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- pseudo-box frames/s on synthetic 34k-point, 6x1600x900 scenes.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step = one pass of the whole hot path (FOV filter, plane RANSAC, label
+inheritance, back-projection + spherical voxel sampling, radius filters,
+BallQuery fuse, clustering, L-shape fit, box rows) over one batch of
+`--frames` synthetic frames per GPU that is resident in HBM, followed for N > 1
+by the all-gather of the box rows.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dfu3d_amd import dist as D            # noqa: E402
+from dfu3d_amd import synth                # noqa: E402
+from dfu3d_amd.engine import PseudoBoxEngine  # noqa: E402
+from dfu3d_amd.params import Params        # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+H, W, CAMS, MAX_INST, N_PTS = 900, 1600, 6, 8, 34720
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_batch(frames, seed0, device, dense, k_boxes):
+    scenes = [synth.make_scene(seed0 + f, H=H, W=W, M=MAX_INST, cams=CAMS, dense=dense,
+                               device=device, k_min=k_boxes[0], k_max=k_boxes[1])
+              for f in range(frames)]
+    # masks/depth are produced on the device already; keep only what the engine needs
+    return scenes
+
+
+def cpu_baseline(scenes_cpu, params, dense, max_seconds=25.0):
+    """The oracle (NumPy + C restatement, single thread) on a bounded sample of
+    the same workload, on this box's host cores."""
+    from oracle import penet_oracle as O
+    op = O.Params()
+    t0 = time.time()
+    done = 0
+    for s in scenes_cpu:
+        pts = s.points.numpy()
+        for c, cal in enumerate(s.calibs):
+            oc = O.Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
+            lid, _ = O.fov_filter(pts, oc, params.fov_hw)
+            n = int(s.n_inst[c])
+            d = s.depth[c].numpy().copy() if dense else np.zeros((H, W), np.float32)
+            O.depth2pointsrgbpm(d[:, :, None], None, oc, lid, O.NUSC_CLASSES,
+                                s.masks[c][:n].numpy().astype(np.float32),
+                                s.inst_class[c][:n].numpy(), s.inst_box[c][:n].numpy(), op,
+                                plane_key=c, want_points=False)
+        done += 1
+        if time.time() - t0 > max_seconds:
+            break
+    dt = time.time() - t0
+    return done / dt, done, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--chunk-frames", type=int, default=8, help="frames per kernel-launch chunk")
+    ap.add_argument("--sparse", action="store_true", help="depth off (hazard H20 extension)")
+    ap.add_argument("--boxes", type=int, nargs=2, default=[30, 40], help="objects per scene (min max)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump", type=str, default="", help="write per-kernel timing JSON here")
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dense = not args.sparse
+    params = Params()
+    frames = args.frames
+    if frames % args.chunk_frames:
+        raise SystemExit("--frames must be a multiple of --chunk-frames")
+
+    t0 = time.time()
+    # weak scaling: every rank labels its own `frames` frames; global frame ids are
+    # interleaved over ranks exactly like dist.shard_frames(world*frames, rank, world)
+    my_frames = D.shard_frames(world * frames, rank, world)
+    scenes = [synth.make_scene(fid, H=H, W=W, M=MAX_INST, cams=CAMS, dense=dense, device=dev,
+                               k_min=args.boxes[0], k_max=args.boxes[1]) for fid in my_frames]
+    batch = synth.to_view_batch(scenes, params, dev, dense=dense)
+    cpu_scenes = None
+    if rank == 0 and not args.no_cpu_baseline:
+        keep = scenes[:4]
+        cpu_scenes = [synth.Scene(s.points.cpu(), s.calibs, s.depth.cpu(), s.masks.cpu(), s.n_inst,
+                                  s.inst_class, s.inst_box, s.inst_score, s.boxes3d) for s in keep]
+    del scenes
+    torch.cuda.synchronize()
+    log("[rank %d] %d frames generated in %.1fs" % (rank, frames, time.time() - t0))
+
+    eng = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=args.chunk_frames * CAMS,
+                          dense=dense, cap_vox=1 << 18, pool_per_view=1 << 17, device=dev)
+
+    def step():
+        rows, status = eng.run(batch)
+        if status:
+            from dfu3d_amd.stages import status_message
+            raise SystemExit("device status: " + status_message(status))
+        return D.allgather_rows(rows)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rows = step()
+    eng.timing = not args.no_kernel_timing
+    eng.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    n_boxes = int(rows.shape[0])
+
+    kern = eng.timing_summary() if eng.timing else {}
+    if rank == 0:
+        total_frames = args.steps * frames * world
+        value = total_frames / dt
+        out = {
+            "metric": "pseudo-box frames/sec (34k pts, 6 cams)", "value": round(value, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1] with depth back-projection %s: %d synthetic frames/GPU/step, "
+                                   "%d-pt sweep, %d cams x %dx%d depth + %d instance masks, %d-%d objects/scene"
+                                   % ("on (dense)" if dense else "off (sparse)", frames, N_PTS, CAMS, W, H,
+                                      MAX_INST, args.boxes[0], args.boxes[1]),
+                       "frames_per_gpu_per_step": frames, "views_per_launch_chunk": args.chunk_frames * CAMS,
+                       "boxes_per_step_all_ranks": n_boxes, "parallelism": "frames sharded x%d" % world},
+        }
+        if kern:
+            # algorithmic bytes per launch (DESIGN.md §kernels / SURVEY.md §8d)
+            views_per_launch = args.chunk_frames * CAMS
+            rf_pts = int(eng._rf_points.item())
+            n_rf_launch = kern.get("rf_flags", (0, 1))[1]
+            alg = {
+                "bp_bin": views_per_launch * H * W * 4,                  # depth read
+                "bp_rep": views_per_launch * H * W * 4,                  # bin-id read
+                "bp_emit": views_per_launch * H * W * 4,                 # bin-id read
+                "rf_flags": 21.0 * rf_pts / max(n_rf_launch, 1),          # 16n + 4n + 1n
+                "fov_filter": views_per_launch * N_PTS * 16,
+                "project_label": views_per_launch * N_PTS * 16,
+            }
+            table = []
+            for name, (ms, n) in sorted(kern.items(), key=lambda kv: -kv[1][0]):
+                avg = ms / n
+                row = {"kernel": name, "total_ms": round(ms, 3), "launches": n, "avg_ms": round(avg, 4)}
+                if name in alg:
+                    row["alg_bytes_per_launch"] = int(alg[name])
+                    row["achieved_GBs"] = round(alg[name] / (avg * 1e-3) / 1e9, 2)
+                table.append(row)
+            out["kernels"] = table
+            dom = next((r for r in table if "achieved_GBs" in r), None)
+            if dom is not None:
+                out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5), "traffic": None}
+            rf = next((r for r in table if r["kernel"] == "rf_flags"), None)
+            if rf is not None:
+                out["radius_filter_roofline"] = {"achieved": rf["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": round(rf["achieved_GBs"] / HBM_PEAK_GBS, 6),
+                                                 "points_per_launch": int(rf_pts / max(n_rf_launch, 1))}
+        if cpu_scenes is not None and world == 1:
+            fps, nf, secs = cpu_baseline(cpu_scenes, params, dense)
+            out["cpu_baseline"] = {"value": round(fps, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d of the same synthetic frames (6 cams each) through oracle/penet_oracle.py "
+                                             "(NumPy + C, 1 thread) in %.1fs; host has %d cores" % (nf, secs, os.cpu_count())}
+        if args.dump:
+            with open(args.dump, "w") as f:
+                json.dump(out, f, indent=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

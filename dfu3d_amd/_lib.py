@@ -48,11 +48,12 @@ SIGNATURES = {
                                                 ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, _P, c_i32, c_i32, c_i32, c_i32,
                                       ctypes.POINTER(BinGeom), c_i32, _P, _P, _P, c_i32, _P,
-                                      _P, _P, _P, _P, _P, _P, _P]),
+                                      _P, _P, _P, _P, _P, _P, c_i32, _P]),
     "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,
                                      c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P]),
-    "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P]),
+    "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P,
+                                    c_i32, _P]),
     "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,
                                   _P, _P, _P]),
     "dfu3d_ballquery_fuse": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,

@@ -7,7 +7,7 @@
 //      the graph {i--j : d_ij <= R_i or d_ij <= R_j}; the merge loop leaves them
 //      ordered by their smallest index.  Here: one workgroup per instance, a
 //      lock-free union-find whose roots are always the smallest index of their
-//      set (atomicMin link), x/y tiles staged through LDS.
+//      set (atomicMin link), parents / group summaries / group boxes in LDS.
 // a14  rectangle_fitting.py:83-159: 89 candidate headings; one wave per heading,
 //      lanes stride the cluster's points, three sweeps (extent, mean, variance)
 //      with fp64 wave reductions; first strict maximum wins.
@@ -17,91 +17,290 @@
 namespace {
 
 constexpr int CT = 512;            // threads per clustering workgroup
-constexpr int TJ = 1024;           // j-tile
-constexpr int LDS_PARENT = 12288;  // parents kept in LDS up to this many points
+constexpr int GRP = 32;            // points per summary / bounding-box group
+constexpr int BLK = 32;            // groups per block (1024 points): second pruning level
+constexpr int SMALL_N = 4096;      // segments up to this size: 32-bit parents, 20 KB of LDS
+constexpr int LARGE_N = 61440;     // up to this size: 16-bit parents in LDS (120 KB)
+constexpr int LARGE_GRP = LARGE_N / GRP;
 
-__device__ __forceinline__ int ld_parent(const int *p, int i) {
-  return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int uf_find(const int *parent, int a) {
-  int p = ld_parent(parent, a);
-  while (p != a) { a = p; p = ld_parent(parent, a); }
+// ---- parent-array accessors: 32-bit (LDS or global) and 16-bit (LDS only) ----
+struct ParI {
+  int *p;
+  bool global;
+  __device__ __forceinline__ int load(int i) const {
+    return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ void init(int i) const { p[i] = i; }
+  __device__ __forceinline__ void flatten(int i, int r) const {
+    if (global) atomicMin(p + i, r); else p[i] = r;
+  }
+  __device__ __forceinline__ int amin(int i, int v) const { return atomicMin(p + i, v); }
+};
+struct ParH {
+  unsigned short *p;
+  __device__ __forceinline__ int load(int i) const {
+    return (int)*(volatile unsigned short *)(p + i);
+  }
+  __device__ __forceinline__ void init(int i) const { p[i] = (unsigned short)i; }
+  __device__ __forceinline__ void flatten(int i, int r) const { p[i] = (unsigned short)r; }
+  // 16-bit atomic min through a 32-bit compare-and-swap on the containing word
+  __device__ __forceinline__ int amin(int i, int v) const {
+    unsigned int *w = (unsigned int *)p + (i >> 1);
+    const int sh = (i & 1) * 16;
+    unsigned int old = *(volatile unsigned int *)w;
+    while (true) {
+      const unsigned int cur = (old >> sh) & 0xFFFFu;
+      if ((int)cur <= v) return (int)cur;
+      const unsigned int nw = (old & ~(0xFFFFu << sh)) | ((unsigned int)v << sh);
+      const unsigned int seen = atomicCAS(w, old, nw);
+      if (seen == old) return (int)cur;
+      old = seen;
+    }
+  }
+};
+
+template <class P>
+__device__ __forceinline__ int uf_find(const P &par, int a) {
+  int p = par.load(a);
+  while (p != a) { a = p; p = par.load(a); }
   return a;
 }
 // returns the root of the merged set as seen by this thread
-__device__ __forceinline__ int uf_unite(int *parent, int a, int b) {
+template <class P>
+__device__ __forceinline__ int uf_unite(const P &par, int a, int b) {
   while (true) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
+    a = uf_find(par, a);
+    b = uf_find(par, b);
     if (a == b) return a;
     if (a < b) { const int t = a; a = b; b = t; }   // a > b: hang a under b
-    const int old = atomicMin(parent + a, b);
+    const int old = par.amin(a, b);
     if (old == a) return b;
     a = old;                                        // someone re-linked a: retry
   }
 }
 
-__global__ __launch_bounds__(CT) void k_range_cluster(
+// One workgroup per instance.  Points are taken in chunks of CT queries (thread
+// i owns point c0+tid and looks at every j < i).  Three exact prunes keep the
+// O(n^2) pair loop cheap:
+//  (1) before a chunk starts all earlier points are flattened (parent = root)
+//      and every aligned group of 32 earlier points whose roots agree gets a
+//      one-word summary; a query skips a group whose summary equals its own
+//      current root;
+//  (2) every group carries an outward-rounded bounding box; a group whose box
+//      is farther than the largest radius of the instance cannot hold a
+//      neighbour and is skipped;
+//  (3) inside a group roots are compared before coordinates are touched, and
+//      the squared distance s decides alone when s <= S_LO (sqrt(s) <= R0 <= R)
+//      or s > S_HI (sqrt(s) > every R); only the thin band in between evaluates
+//      the reference's sqrt expression (rectangle_fitting.py:167-170).
+// None of the prunes changes a decision, so the labels equal the reference's.
+template <class P, int NGRP>
+__device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s_box,
+                                             int *s_summ2, float4 *s_box2,
+                                             double *s_red, const double *X, const double *Y,
+                                             int n, double R0, double Rd, int *glabel,
+                                             bool write_labels) {
+  constexpr int NBLK = (NGRP + BLK - 1) / BLK;
+  const int ngrp_all = min((n + GRP - 1) / GRP, NGRP);
+  double r2max = 0.0;
+  for (int i = threadIdx.x; i < n; i += CT) {
+    par.init(i);
+    const double x = X[i], y = Y[i];
+    r2max = fmax(r2max, x * x + y * y);
+  }
+  for (int g = threadIdx.x; g < ngrp_all; g += CT) {
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    const int je = min(g * GRP + GRP, n);
+    for (int j = g * GRP; j < je; j++) {
+      const double x = X[j], y = Y[j];
+      x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+    }
+    s_box[g] = make_float4(__double2float_rd(x0), __double2float_ru(x1),
+                           __double2float_rd(y0), __double2float_ru(y1));
+  }
+  r2max = wave_max_d(r2max);
+  if (lane_id() == 0) s_red[threadIdx.x >> 6] = r2max;
+  __syncthreads();
+  r2max = s_red[0];
+#pragma unroll
+  for (int w = 1; w < CT / 64; w++) r2max = fmax(r2max, s_red[w]);
+  for (int B = threadIdx.x; B * BLK < ngrp_all; B += CT) {     // boxes of 1024-point blocks
+    float4 b = s_box[B * BLK];
+    const int ge = min(B * BLK + BLK, ngrp_all);
+    for (int g = B * BLK + 1; g < ge; g++) {
+      const float4 q = s_box[g];
+      b.x = fminf(b.x, q.x); b.y = fmaxf(b.y, q.y); b.z = fminf(b.z, q.z); b.w = fmaxf(b.w, q.w);
+    }
+    s_box2[B] = b;
+  }
+  const double Rmax = (R0 + Rd * sqrt(r2max)) * (1.0 + 1e-9) + 1e-9;
+  const double S_HI = Rmax * Rmax * (1.0 + 1e-9);      // s > S_HI  => sqrt(s) > every R_i
+  const double S_LO = R0 * R0 * (1.0 - 1e-12);         // s <= S_LO => sqrt(s) <= R0 <= R_i
+
+  for (int c0 = 0; c0 < n; c0 += CT) {
+    // flatten + summarise everything before this chunk
+    for (int k = threadIdx.x; k < c0; k += CT) par.flatten(k, uf_find(par, k));
+    __syncthreads();
+    const int ngrp = min(c0 / GRP, NGRP);
+    for (int g = threadIdx.x; g < ngrp; g += CT) {
+      const int r = par.load(g * GRP);
+      bool same = true;
+      for (int k = 1; k < GRP; k++) same = same && (par.load(g * GRP + k) == r);
+      s_summ[g] = same ? r : -1;
+    }
+    __syncthreads();
+    for (int B = threadIdx.x; B < ngrp / BLK; B += CT) {        // fully flattened blocks only
+      const int r = s_summ[B * BLK];
+      bool same = r >= 0;
+      for (int k = 1; k < BLK; k++) same = same && (s_summ[B * BLK + k] == r);
+      s_summ2[B] = same ? r : -1;
+    }
+    __syncthreads();
+    const int nblk_sum = ngrp / BLK;
+    const int i = c0 + threadIdx.x;
+    const bool act = i < n;
+    const int lane = lane_id();
+    double xi = 0.0, yi = 0.0, Ri = 0.0;
+    if (act) {
+      xi = X[i];
+      yi = Y[i];
+      Ri = R0 + Rd * sqrt(xi * xi + yi * yi);                   // rectangle_fitting.py:167
+    }
+    int ri = act ? i : -2;
+    // groups holding some j < i for any lane of this wave (wave-uniform bound)
+    const int wave_hi = min(n, c0 + (int)(threadIdx.x | 63) + 1);
+    const int gend = (wave_hi - 1 + GRP - 1) / GRP;
+    // Order of the walk: first the flattened points (j < c0) backwards -- nearest
+    // in input order first, so a point usually meets the (already merged) set it
+    // belongs to within a few groups and can then skip whole 1024-point blocks --
+    // and afterwards the points of its own chunk.
+    const int gc = c0 / GRP;                                    // first group of this chunk
+    auto visit_group = [&](int g, bool need_in) {
+      const int jg = g * GRP;
+      bool need = need_in && (jg < i);
+      if (need && g < NGRP) {
+        if (jg + GRP <= c0 && s_summ[g] == ri) need = false;    // (1) whole group is mine
+        else {
+          const float4 b = s_box[g];                            // (2) box too far
+          const double ddx = fmax(fmax((double)b.x - xi, xi - (double)b.y), 0.0);
+          const double ddy = fmax(fmax((double)b.z - yi, yi - (double)b.w), 0.0);
+          if (ddx * ddx + ddy * ddy > S_HI) need = false;
+        }
+      }
+      if (!__any(need)) return;                                 // wave-uniform
+      // the wave fetches the group's 32 points once (one coalesced load each)
+      const int jl = jg + (lane & (GRP - 1));
+      const bool in = jl < n;
+      const int pg = in ? par.load(jl) : -3;
+      // cheap exit: every query of the wave that still needs this group sits in
+      // one set and all 32 points already belong to it (own-chunk groups mostly)
+      const int r_first = __shfl(ri, __ffsll((unsigned long long)__ballot(need)) - 1, 64);
+      if (__all(!need || ri == r_first) && __all(!in || pg == r_first)) return;
+      const double xg = in ? X[jl] : 0.0, yg = in ? Y[jl] : 0.0;
+#pragma unroll 4
+      for (int k = GRP - 1; k >= 0; k--) {
+        const int pj = __shfl(pg, k, 64);
+        const double xj = __shfl(xg, k, 64), yj = __shfl(yg, k, 64);
+        if (need && (jg + k < i) && pj != ri) {                 // (3) not in my set (yet)
+          const double dx = xi - xj, dy = yi - yj;
+          const double sq = dx * dx + dy * dy;
+          bool adj;
+          if (sq <= S_LO) adj = true;
+          else if (sq > S_HI) adj = false;
+          else {
+            const double d = sqrt(sq);                          // rectangle_fitting.py:169
+            adj = (d <= Ri) || (d <= R0 + Rd * sqrt(xj * xj + yj * yj));
+          }
+          if (adj) ri = uf_unite(par, ri, jg + k);
+        }
+      }
+    };
+    for (int B = (gc + BLK - 1) / BLK - 1; B >= 0; B--) {
+      const int g_lo = B * BLK, g_hi = min(g_lo + BLK, gc);
+      bool need2 = act;
+      if (need2 && B < NBLK) {
+        if (B < nblk_sum && s_summ2[B] == ri) need2 = false;    // (1) whole block is mine
+        else {
+          const float4 b = s_box2[B];                           // (2) block too far
+          const double ddx = fmax(fmax((double)b.x - xi, xi - (double)b.y), 0.0);
+          const double ddy = fmax(fmax((double)b.z - yi, yi - (double)b.w), 0.0);
+          if (ddx * ddx + ddy * ddy > S_HI) need2 = false;
+        }
+      }
+      if (!__any(need2)) continue;                              // wave-uniform
+      for (int g = g_hi - 1; g >= g_lo; g--) visit_group(g, need2);
+    }
+    for (int g = gc; g < gend; g++) visit_group(g, act);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += CT) {
+    const int r = uf_find(par, i);
+    if (write_labels) glabel[i] = r;
+    else atomicMin(glabel + i, r);                  // parents live in glabel: compress
+  }
+}
+
+__global__ __launch_bounds__(CT) void k_range_cluster_small(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
     double Rd, int *__restrict__ label) {
-  __shared__ double sxj[TJ], syj[TJ], sRj[TJ];
-  __shared__ int s_parent[LDS_PARENT];
+  __shared__ int s_parent[SMALL_N];
+  __shared__ int s_summ[SMALL_N / GRP];
+  __shared__ float4 s_box[SMALL_N / GRP];
+  __shared__ int s_summ2[SMALL_N / GRP / BLK];
+  __shared__ float4 s_box2[SMALL_N / GRP / BLK];
+  __shared__ double s_red[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
-  if (n == 0) return;
+  if (n == 0 || n > SMALL_N) return;
   const long long base = seg_base[s];
-  int *glabel = label + base;
-  int *parent = (n <= LDS_PARENT) ? s_parent : glabel;
-  for (int i = threadIdx.x; i < n; i += CT) parent[i] = i;
-  __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += CT) {
-    const int i = c0 + threadIdx.x;
-    const bool valid = i < n;
-    double xi = 0.0, yi = 0.0, Ri = 0.0;
-    if (valid) {
-      xi = px[base + i];
-      yi = py[base + i];
-      Ri = R0 + Rd * sqrt(xi * xi + yi * yi);       // rectangle_fitting.py:167
-    }
-    int ri = valid ? uf_find(parent, i) : -1;
-    const int jend = min(n, c0 + CT);               // only j < i matter
-    for (int t0 = 0; t0 < jend; t0 += TJ) {
-      const int m = min(TJ, jend - t0);
-      __syncthreads();
-      for (int k = threadIdx.x; k < m; k += CT) {
-        const double xj = px[base + t0 + k], yj = py[base + t0 + k];
-        sxj[k] = xj;
-        syj[k] = yj;
-        sRj[k] = R0 + Rd * sqrt(xj * xj + yj * yj);
-      }
-      __syncthreads();
-      if (valid) {
-        const int lim = min(m, i - t0);
-        for (int k = 0; k < lim; k++) {
-          const double dx = xi - sxj[k], dy = yi - syj[k];
-          const double d = sqrt(dx * dx + dy * dy);   // rectangle_fitting.py:169
-          if (d <= Ri || d <= sRj[k]) {
-            const int j = t0 + k;
-            if (ld_parent(parent, j) != ri) ri = uf_unite(parent, ri, j);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += CT) {
-    const int r = uf_find(parent, i);
-    if (parent == s_parent) glabel[i] = r;
-    else atomicMin(glabel + i, r);                  // compress towards the root
+  ParI par{s_parent, false};
+  cluster_body<ParI, SMALL_N / GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
+                                    label + base, true);
+}
+
+__global__ __launch_bounds__(CT) void k_range_cluster_large(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
+    double Rd, int *__restrict__ label) {
+  __shared__ unsigned short s_parent[LARGE_N];
+  __shared__ int s_summ[LARGE_GRP];
+  __shared__ float4 s_box[LARGE_GRP];
+  __shared__ int s_summ2[LARGE_GRP / BLK];
+  __shared__ float4 s_box2[LARGE_GRP / BLK];
+  __shared__ double s_red[CT / 64];
+  const int s = blockIdx.x;
+  const int n = seg_cnt[s];
+  if (n <= SMALL_N) return;
+  const long long base = seg_base[s];
+  if (n <= LARGE_N) {
+    ParH par{s_parent};
+    cluster_body<ParH, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
+                                  label + base, true);
+  } else {          // parents in global memory (the label array itself)
+    ParI par{label + base, true};
+    cluster_body<ParI, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
+                                  label + base, false);
   }
 }
 
 // ---------------------------------------------------------------- a14/a15
-constexpr int FT = 256;
+constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
-constexpr int LDS_MEMBERS = 3072;   // cluster members cached in LDS (48 KB)
+constexpr int LDS_MEMBERS = 2048;   // clusters up to this size: members cached in LDS, one wave per heading
+constexpr int TB = 8;               // larger clusters: headings per point-parallel sweep
+
+// block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
+struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
+struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
+struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
+template <class OP>
+__device__ __forceinline__ double wave_red(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = OP::f(v, shfl_xor_d(v, m));
+  return v;
+}
 
 struct Ext { double c1min, c1max, c2min, c2max; };
 
@@ -122,7 +321,8 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
     double *__restrict__ gsx, double *__restrict__ gsy, int *__restrict__ sroot, int cap_rows,
     double *__restrict__ rows, int *__restrict__ n_rows, uint32_t *__restrict__ status) {
   __shared__ double lx[LDS_MEMBERS], ly[LDS_MEMBERS];
-  __shared__ double s_cost[MAXTH];
+  __shared__ double s_cost[MAXTH], s_ct[MAXTH + TB], s_st[MAXTH + TB];
+  __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
   __shared__ double s_red[FW];
   __shared__ double s_ext[FW][4];
   __shared__ int s_w[FW];
@@ -132,6 +332,11 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
   const long long base = seg_base[s];
   const int v = s / max_inst, jinst = s - v * max_inst;
   const int wave = threadIdx.x >> 6, lane = lane_id();
+  if (threadIdx.x < MAXTH + TB) {              // heading table (rectangle_fitting.py:119-122)
+    const double theta = (double)threadIdx.x * dtheta;
+    s_ct[threadIdx.x] = cos(theta);
+    s_st[threadIdx.x] = sin(theta);
+  }
 
   // max z over ALL instance points (my_loader.py:647-648)
   double zm = -INFINITY;
@@ -139,7 +344,9 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
   zm = wave_max_d(zm);
   if (lane == 0) s_red[wave] = zm;
   __syncthreads();
-  const double zmax = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  double zmax = s_red[0];
+#pragma unroll
+  for (int w = 1; w < FW; w++) zmax = fmax(zmax, s_red[w]);
   __syncthreads();
 
   // ordered list of cluster roots
@@ -177,10 +384,10 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
     const double *mx = in_lds ? lx : gsx + base;
     const double *my = in_lds ? ly : gsy + base;
 
+    if (in_lds) {
     // 89 headings, one wave each (rectangle_fitting.py:119-136)
     for (int th = wave; th < n_theta; th += FW) {
-      const double theta = (double)th * dtheta;
-      const double ct = cos(theta), st = sin(theta);
+      const double ct = s_ct[th], st = s_st[th];
       double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
       for (int i = lane; i < m; i += 64) {
         const double x = mx[i], y = my[i];
@@ -220,6 +427,104 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
       if (n1) V1 = -(q1 / (double)n1);
       if (n2) V2 = -(q2 / (double)n2);
       if (lane == 0) s_cost[th] = V1 + V2;
+    }
+    } else {
+    // Large cluster: all 512 threads split the POINTS; TB headings per sweep
+    // keep their running extents / sums in registers (3 sweeps per batch instead
+    // of 3 sweeps per heading over the member list in L2).
+    for (int tb = 0; tb < n_theta; tb += TB) {
+      const int nt = min(TB, n_theta - tb);
+      double acc[4 * TB];
+#pragma unroll
+      for (int t = 0; t < TB; t++) { acc[4 * t] = INFINITY; acc[4 * t + 1] = -INFINITY; acc[4 * t + 2] = INFINITY; acc[4 * t + 3] = -INFINITY; }
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[tb + t], st = s_st[tb + t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          acc[4 * t] = fmin(acc[4 * t], c1); acc[4 * t + 1] = fmax(acc[4 * t + 1], c1);
+          acc[4 * t + 2] = fmin(acc[4 * t + 2], c2); acc[4 * t + 3] = fmax(acc[4 * t + 3], c2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) {
+        const double r = (k & 1) ? wave_red<OpMax>(acc[k]) : wave_red<OpMin>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4 * TB) {
+        const int k = threadIdx.x;
+        double r = s_part[0][k];
+        for (int w = 1; w < FW; w++) r = (k & 1) ? fmax(r, s_part[w][k]) : fmin(r, s_part[w][k]);
+        s_bext[k] = r;
+      }
+      __syncthreads();
+      // sums and counts of E1 / E2
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) acc[k] = 0.0;
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[tb + t], st = s_st[tb + t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
+          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
+          if (d1 < d2) { acc[4 * t] += d1; acc[4 * t + 1] += 1.0; }
+          else { acc[4 * t + 2] += d2; acc[4 * t + 3] += 1.0; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) {
+        const double r = wave_red<OpSum>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4 * TB) {
+        const int k = threadIdx.x;
+        double r = s_part[0][k];
+        for (int w = 1; w < FW; w++) r += s_part[w][k];
+        s_bsum[k] = r;
+      }
+      __syncthreads();
+      // squared deviations from the means
+#pragma unroll
+      for (int k = 0; k < 2 * TB; k++) acc[k] = 0.0;
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[tb + t], st = s_st[tb + t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
+          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
+          const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
+          if (d1 < d2) { const double u = d1 - (n1 > 0.0 ? s_bsum[4 * t] / n1 : 0.0); acc[2 * t] += u * u; }
+          else { const double u = d2 - (n2 > 0.0 ? s_bsum[4 * t + 2] / n2 : 0.0); acc[2 * t + 1] += u * u; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2 * TB; k++) {
+        const double r = wave_red<OpSum>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < nt) {
+        const int t = threadIdx.x;
+        double q1 = s_part[0][2 * t], q2 = s_part[0][2 * t + 1];
+        for (int w = 1; w < FW; w++) { q1 += s_part[w][2 * t]; q2 += s_part[w][2 * t + 1]; }
+        const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
+        double V1 = 0.0, V2 = 0.0;
+        if (n1 > 0.0) V1 = -(q1 / n1);
+        if (n2 > 0.0) V2 = -(q2 / n2);
+        s_cost[tb + t] = V1 + V2;
+      }
+      __syncthreads();
+    }
     }
     __syncthreads();
     // first strict maximum (rectangle_fitting.py:135-136)
@@ -319,7 +624,12 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
                                    int32_t *label, void *stream) {
   if (!px || !py || !seg_base || !seg_cnt || !label) return DFU3D_EINVAL;
   if (S <= 0) return DFU3D_EINVAL;
-  hipLaunchKernelGGL(k_range_cluster, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
+  // two LDS footprints: small instances (<= SMALL_N points, several workgroups per
+  // CU) and large ones; each kernel returns at once for the other's segments
+  hipLaunchKernelGGL(k_range_cluster_small, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
+                     (const long long *)seg_base, seg_cnt, R0, Rd, label);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_range_cluster_large, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
                      (const long long *)seg_base, seg_cnt, R0, Rd, label);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;

@@ -471,7 +471,7 @@ extern "C" int dfu3d_backproject_bin(
     int32_t V, int32_t max_inst, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
     int32_t key_axis, void *table, uint32_t *pix_bin, int32_t *blk_cnt, int32_t cap_vox,
     int32_t *n_vox, uint32_t *vox_pix, uint32_t *it_bits, double *it_x, double *it_y,
-    double *it_z, uint32_t *status, void *stream) {
+    double *it_z, uint32_t *status, int32_t phases, void *stream) {
   if (!depth || !calib || !geom || !table || !pix_bin || !blk_cnt || !n_vox || !vox_pix ||
       !it_bits || !it_x || !it_y || !it_z || !status)
     return DFU3D_EINVAL;
@@ -496,11 +496,14 @@ extern "C" int dfu3d_backproject_bin(
   uint32_t *vox_bin = pix_bin + 2 * (size_t)V * HW;
   const ViewCalib *cal = (const ViewCalib *)calib;
 
+  if (phases & DFU3D_BP_BIN) {
   if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 2 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
   hipLaunchKernelGGL(k_bp_bin, dim3(nblk, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
                      key_axis, E_view, table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf,
                      status);
   DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_REPAIR) {
   // exact repair of bins that saw more than max_points points (no-ops otherwise)
   hipLaunchKernelGGL(k_ovf_alloc, dim3((cap_ovf + 255) / 256, V), dim3(256), 0, st, table,
                      E_total, E_view, cap_ovf, ovf_bins, n_ovf, ovf_cnt, ovf_cursor, HW,
@@ -513,15 +516,21 @@ extern "C" int dfu3d_backproject_bin(
                      key_axis, geom->max_points_per_voxel, table, E_total, E_view, cap_ovf,
                      ovf_bins, n_ovf, ovf_cnt, ovf_list);
   DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_REP) {
   hipLaunchKernelGGL(k_bp_rep, dim3(nblk, V), dim3(PB), 0, st, depth, cal, W, HW, key_axis,
                      E_view, table, E_total, pix_bin, nblk, blk_cnt);
   DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_EMIT) {
   hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(1024), 0, st, nblk, blk_cnt, n_vox, cap_vox,
                      status);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bp_emit, dim3(nblk, V), dim3(PB), 0, st, HW, E_view, table, E_total,
                      pix_bin, nblk, blk_cnt, cap_vox, vox_bin);
   DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_VOX) {
   hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + 255) / 256, V), dim3(256), 0, st, depth, cal,
                      masks, n_inst, max_inst, W, HW, geom->max_voxels, E_view, table,
                      E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z);
@@ -529,5 +538,6 @@ extern "C" int dfu3d_backproject_bin(
   hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V,
                      geom->max_voxels, cap_vox, n_vox, n_ovf, ovf_cursor);
   DFU3D_LAUNCH_CHECK();
+  }
   return DFU3D_OK;
 }

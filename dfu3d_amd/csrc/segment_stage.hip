@@ -133,13 +133,15 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 }
 
 // ---------------------------------------------------------------- a10 radius
+// Phase A: every query sweeps only the 1024-point tile it lives in (its
+// neighbours in input order).  With nb_points = 1 that settles all but the
+// isolated points; those (and only those) are appended to a queue.
 __global__ __launch_bounds__(QT) void k_radius_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ seg_base,
     const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S,
-    const int *__restrict__ tile_off, uint8_t *__restrict__ flags) {
+    const int *__restrict__ tile_off, uint8_t *__restrict__ flags, int *__restrict__ queue) {
   __shared__ double sx[PT], sy[PT], sz[PT];
-  __shared__ int s_pending;
   const int t = blockIdx.x;
   if (t >= tile_off[S]) return;
   const int s = find_segment(tile_off, S, t);
@@ -154,40 +156,67 @@ __global__ __launch_bounds__(QT) void k_radius_flags(
     return;
   }
   const double r2 = r * r;
-  double x = 0.0, y = 0.0, z = 0.0;
-  if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
+  const int j0 = (q0 / PT) * PT;
+  const int m = min(PT, n - j0);
+  for (int i = threadIdx.x; i < m; i += QT) {
+    sx[i] = px[base + j0 + i];
+    sy[i] = py[base + j0 + i];
+    sz[i] = pz[base + j0 + i];
+  }
+  __syncthreads();
+  if (!valid) return;
+  const double x = sx[q - j0], y = sy[q - j0], z = sz[q - j0];
   int cnt = 0;
-  const int npt = (n + PT - 1) / PT;
-  const int start = q0 / PT;
-  for (int k = 0; k < npt; k++) {
-    int tile = start + k;
-    if (tile >= npt) tile -= npt;
-    const int j0 = tile * PT;
-    const int m = min(PT, n - j0);
-    __syncthreads();
-    if (threadIdx.x == 0) s_pending = 0;
-    for (int i = threadIdx.x; i < m; i += QT) {
-      sx[i] = px[base + j0 + i];
-      sy[i] = py[base + j0 + i];
-      sz[i] = pz[base + j0 + i];
+  for (int j = 0; j < m; j++) {
+    const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+    double d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    if (d < r2) {
+      if (++cnt > nb) break;
     }
-    __syncthreads();
-    if (valid && cnt <= nb) {
-      for (int j = 0; j < m; j++) {
-        const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+  }
+  if (cnt > nb || n <= PT) {
+    flags[base + q] = (cnt > nb) ? 1 : 0;
+  } else {                          // undecided: the rest of the segment must be seen
+    const int slot = atomicAdd(&queue[0], 1);
+    queue[2 + 2 * slot] = s;
+    queue[3 + 2 * slot] = q;
+  }
+}
+
+// Phase B: one wave per undecided query; the 64 lanes stride the whole segment
+// (coalesced 8 B/lane loads) and leave together as soon as the count is reached.
+__global__ __launch_bounds__(256) void k_radius_resolve(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, const long long *__restrict__ seg_base,
+    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb,
+    uint8_t *__restrict__ flags, const int *__restrict__ queue) {
+  const int nq = queue[0];
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const int lane = lane_id();
+  for (int e = wave; e < nq; e += nwaves) {
+    const int s = queue[2 + 2 * e], q = queue[3 + 2 * e];
+    const int n = seg_cnt[s];
+    const long long base = seg_base[s];
+    const double r = radius[s], r2 = r * r;
+    const double x = px[base + q], y = py[base + q], z = pz[base + q];
+    int cnt = 0;
+    for (int j0 = 0; j0 < n && cnt <= nb; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      if (j < n) {
+        const double dx = x - px[base + j], dy = y - py[base + j], dz = z - pz[base + j];
         double d = dx * dx;
         d += dy * dy;
         d += dz * dz;
-        if (d < r2) {
-          if (++cnt > nb) break;
-        }
+        hit = d < r2;
       }
-      if (cnt <= nb) s_pending = 1;
+      cnt += __popcll(__ballot(hit));
     }
-    __syncthreads();
-    if (!s_pending) break;
+    if (lane == 0) flags[base + q] = (cnt > nb) ? 1 : 0;
   }
-  if (valid) flags[base + q] = (cnt > nb) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- a12 ball query
@@ -412,20 +441,34 @@ extern "C" int dfu3d_segments_build(
 extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int64_t *seg_base,
                                    int32_t *seg_cnt, const double *radius, int32_t nb_points,
                                    int32_t S, int64_t pool_cap, int32_t *tile_off,
-                                   uint8_t *flags, void *stream) {
-  if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags)
+                                   uint8_t *flags, int32_t *queue, int32_t phases,
+                                   void *stream) {
+  if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags || !queue)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || nb_points < 0) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_radius_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
-                     (const long long *)seg_base, seg_cnt, radius, nb_points, S, tile_off, flags);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
-                     (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
-                     (const int *)nullptr);
-  DFU3D_LAUNCH_CHECK();
+  if (phases & DFU3D_RF_TILES) {
+    if (hipMemsetAsync(queue, 0, 2 * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_RF_FLAGS) {
+    hipLaunchKernelGGL(k_radius_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+                       (const long long *)seg_base, seg_cnt, radius, nb_points, S, tile_off, flags,
+                       queue);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_RF_RESOLVE) {
+    hipLaunchKernelGGL(k_radius_resolve, dim3(2048), dim3(256), 0, st, px, py, pz,
+                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_RF_COMPACT) {
+    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
+                       (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
+                       (const int *)nullptr);
+    DFU3D_LAUNCH_CHECK();
+  }
   return DFU3D_OK;
 }
 

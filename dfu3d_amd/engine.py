@@ -97,8 +97,44 @@ class PseudoBoxEngine:
         self.base_b = torch.empty(S, dtype=torch.int64, device=d)
         self.cnt_a, self.cnt_b, self.cnt_all = i32(S), i32(S), i32(S)
         self.tile_off = i32(S + 1)
+        self.queue = i32(2 + 2 * pc)
         self.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
         self.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
+        # optional per-kernel timing with HIP events on the launch stream
+        self.timing = False
+        self._events = []
+        self._rf_points = torch.zeros(1, dtype=torch.int64, device=d)
+
+    # ------------------------------------------------------------------
+    def _run(self, name, fn, *a, **k):
+        if not self.timing:
+            return fn(*a, **k)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*a, **k)
+        e1.record()
+        self._events.append((name, e0, e1))
+
+    def _phased(self, prefix, fn, phases, *a):
+        """Issue a multi-kernel stage phase by phase so each kernel is bracketed."""
+        if not self.timing:
+            return fn(*a)
+        for tag, bit in phases:
+            self._run(prefix + tag, fn, *a, phases=bit)
+
+    def timing_summary(self):
+        """-> {name: (total_ms, launches)}; synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self._events:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + e0.elapsed_time(e1), n + 1)
+        return out
+
+    def reset_timing(self):
+        self._events = []
+        self._rf_points.zero_()
 
     # ------------------------------------------------------------------
     def _chunk(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
@@ -110,47 +146,57 @@ class PseudoBoxEngine:
         calib = b.calib[v0:v1]
         masks = b.masks[v0:v1]
         n_inst = b.n_inst[v0:v1]
-        st.fov_filter(b.points, b.pt_off, vf, calib, V, p.fov_hw, cap_n, self.fov_idx,
-                      self.n_fov, b.host_pt_off, b.host_view_frame[v0:v1])
+        R = self._run
+        R("fov_filter", st.fov_filter, b.points, b.pt_off, vf, calib, V, p.fov_hw, cap_n,
+          self.fov_idx, self.n_fov, b.host_pt_off, b.host_view_frame[v0:v1])
         if b.plane is None:
-            st.plane_ransac(b.points, b.pt_off, vf, self.fov_idx, self.n_fov, V, cap_n,
+            R("plane_ransac", st.plane_ransac, b.points, b.pt_off, vf, self.fov_idx, self.n_fov, V, cap_n,
                             p.plane_max_hs, p.plane_range, p.ransac_trials, p.ransac_seed,
                             b.view_key[v0:v1], self.cand_idx, self.plane)
             plane = self.plane
         else:
             plane = b.plane[v0:v1].reshape(-1)
-        st.project_label(b.points, b.pt_off, vf, calib, plane, self.fov_idx, self.n_fov, masks,
+        R("project_label", st.project_label, b.points, b.pt_off, vf, calib, plane, self.fov_idx, self.n_fov, masks,
                          n_inst, V, M, p.bounds_hw[0], p.bounds_hw[1], cap_n, p.plane_offset,
                          p.plane_range, self.ag_pt, self.ib_pix, self.n_ag, self.K, self.a_bits,
                          self.a_x, self.a_y, self.a_z)
         if self.dense and b.depth is not None:
-            st.backproject_bin(b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
-                               self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
-                               self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
-                               self.b_z, status)
+            self._phased("bp_", st.backproject_bin,
+                         (("bin", st.BP_BIN), ("repair", st.BP_REPAIR), ("rep", st.BP_REP),
+                          ("emit", st.BP_EMIT), ("vox", st.BP_VOX)),
+                         b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
+                         self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
+                         self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
+                         self.b_z, status)
         else:
             self.n_vox.zero_()
         self.pool_cursor.zero_()
-        st.segments_build(self.a_bits, self.a_x, self.a_y, self.a_z, self.K, cap_n, self.b_bits,
+        R("segments_build", st.segments_build, self.a_bits, self.a_x, self.a_y, self.a_z, self.K, cap_n, self.b_bits,
                           self.b_x, self.b_y, self.b_z, self.n_vox, self.cap_vox, V, M,
                           self.pool_cap, self.pool_cursor, self.px, self.py, self.pz,
                           self.base_a, self.cnt_a, self.base_b, self.cnt_b, status)
         rl = b.inst_r_lidar[v0:v1].reshape(-1)
         rp = b.inst_r_pseudo[v0:v1].reshape(-1)
-        st.radius_filter(self.px, self.py, self.pz, self.base_a, self.cnt_a, rl, p.nb_points, S,
-                         self.pool_cap, self.tile_off, self.flags)
-        st.radius_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, rp, p.nb_points, S,
-                         self.pool_cap, self.tile_off, self.flags)
+        rf_ph = (("tiles", st.RF_TILES), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE),
+                 ("compact", st.RF_COMPACT))
+        if self.timing:
+            self._rf_points += self.cnt_a.sum() + self.cnt_b.sum()
+        self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
+                     self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
+                     self.queue)
+        self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_b,
+                     self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
+                     self.queue)
         if p.stat_filter:
-            st.stat_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
+            R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
                            self.tile_off, self.flags, self.mean_d)
-        st.ballquery_fuse(self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
+        R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
                           self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags)
         torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
-        st.range_cluster(self.px, self.py, self.base_a, self.cnt_all, S, p.R0, p.Rd, self.label,
+        R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0, p.Rd, self.label,
                          self.pool_cap)
-        st.lshape_fit(self.px, self.py, self.pz, self.label, self.base_a, self.cnt_all, S, M,
+        R("lshape_fit", st.lshape_fit, self.px, self.py, self.pz, self.label, self.base_a, self.cnt_all, S, M,
                       calib, b.inst_class[v0:v1].reshape(-1), b.inst_is_car[v0:v1].reshape(-1),
                       b.inst_box[v0:v1].reshape(-1), b.inst_score[v0:v1].reshape(-1),
                       self.n_theta, self.dtheta, p.car_aspect_max, self.sx, self.sy, self.sroot,

@@ -16,6 +16,9 @@ CALIB_FLOATS = 48
 ROW_DOUBLES = 18
 MAX_INST = 32
 
+BP_BIN, BP_REPAIR, BP_REP, BP_EMIT, BP_VOX, BP_ALL = 1, 2, 4, 8, 16, 31
+RF_TILES, RF_FLAGS, RF_COMPACT, RF_RESOLVE, RF_ALL = 1, 2, 4, 8, 15
+
 ST_POOL_OVERFLOW = 1
 ST_VOX_OVERFLOW = 2
 ST_ROW_OVERFLOW = 4
@@ -155,7 +158,7 @@ def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, mask
 
 def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_entries,
                     key_axis, table, pix_bin, blk_cnt, cap_vox, n_vox, vox_pix, it_bits, it_x,
-                    it_y, it_z, status):
+                    it_y, it_z, status, phases=BP_ALL):
     pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel)
     if table.data_ptr() % 8:
         raise Dfu3dError("table: must be 8-byte aligned")
@@ -178,7 +181,7 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
         _chk(it_x, "it_x", torch.float64, numel=V * cap_vox),
         _chk(it_y, "it_y", torch.float64, numel=V * cap_vox),
         _chk(it_z, "it_z", torch.float64, numel=V * cap_vox),
-        _chk(status, "status", torch.int32, min_numel=1), _stream())
+        _chk(status, "status", torch.int32, min_numel=1), int(phases), _stream())
     _lib.check(rc, "dfu3d_backproject_bin")
 
 
@@ -204,7 +207,8 @@ def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n
     _lib.check(rc, "dfu3d_segments_build")
 
 
-def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap, tile_off, flags):
+def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap, tile_off, flags,
+                  queue, phases=RF_ALL):
     rc = _lib.lib().dfu3d_radius_filter(
         _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
         _chk(pz, "pz", torch.float64, numel=pool_cap),
@@ -212,7 +216,8 @@ def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap,
         _chk(seg_cnt, "seg_cnt", torch.int32, numel=S),
         _chk(radius, "radius", torch.float64, numel=S), int(nb_points), S, pool_cap,
         _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
-        _chk(flags, "flags", torch.uint8, numel=pool_cap), _stream())
+        _chk(flags, "flags", torch.uint8, numel=pool_cap),
+        _chk(queue, "queue", torch.int32, min_numel=2 + 2 * pool_cap), int(phases), _stream())
     _lib.check(rc, "dfu3d_radius_filter")
 
 

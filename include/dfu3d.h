@@ -141,7 +141,17 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
                           void *table, uint32_t *pix_bin, int32_t *blk_cnt,
                           int32_t cap_vox, int32_t *n_vox, uint32_t *vox_pix,
                           uint32_t *it_bits, double *it_x, double *it_y,
-                          double *it_z, uint32_t *status, void *stream);
+                          double *it_z, uint32_t *status, int32_t phases,
+                          void *stream);
+/* `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
+ * production; single phases let a caller bracket one kernel with HIP events
+ * on its stream).  The phases of one pass must be issued in this order. */
+#define DFU3D_BP_BIN 1     /* k_bp_bin: back-project + bin + table atomics      */
+#define DFU3D_BP_REPAIR 2  /* overflow-bin repair (no-op kernels when unused)   */
+#define DFU3D_BP_REP 4     /* k_bp_rep: representative + first-pixel counts     */
+#define DFU3D_BP_EMIT 8    /* k_bp_scan + k_bp_emit: ordered voxel list         */
+#define DFU3D_BP_VOX 16    /* k_bp_vox + finalize: outputs, table reset         */
+#define DFU3D_BP_ALL 31
 
 /* ---- per-instance point sets (my_loader.py:547-565) ------------------------
  * Builds, for every segment s = v*max_inst + j, the ordered list of LiDAR rows
@@ -164,12 +174,18 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
  * In-place, order-preserving: keeps point i of segment s iff
  * #{j in s : |p_i-p_j|^2 < radius[s]^2, j == i included} > nb_points.
  * radius[s] < 0 drops the whole segment (hazard H4), radius[s] == 0 keeps it.
- * Scratch: tile_off int32 (S+1), flags uint8 (pool_cap). */
+ * Scratch: tile_off int32 (S+1), flags uint8 (pool_cap), queue int32
+ * (2 + 2*pool_cap: undecided (segment, point) pairs between the two kernels). */
 int dfu3d_radius_filter(double *px, double *py, double *pz,
                         const int64_t *seg_base, int32_t *seg_cnt,
                         const double *radius, int32_t nb_points, int32_t S,
                         int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
-                        void *stream);
+                        int32_t *queue, int32_t phases, void *stream);
+#define DFU3D_RF_TILES 1    /* k_tile_scan: query-tile list, queue reset        */
+#define DFU3D_RF_FLAGS 2    /* k_radius_flags: neighbour count in the own tile  */
+#define DFU3D_RF_COMPACT 4  /* k_seg_compact: ordered in-place compaction       */
+#define DFU3D_RF_RESOLVE 8  /* k_radius_resolve: isolated points, whole segment */
+#define DFU3D_RF_ALL 15
 
 /* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
  * keep i iff 0 < mean_knn_dist_i < mu + std_ratio * sigma (self included in

@@ -80,7 +80,8 @@ def test_radius_filter_matches_oracle(st):
         seg_cnt = _t(cnt)
         st.radius_filter(px, py, pz, _t(base), seg_cnt, _t(radius), nb, S, cap,
                          torch.zeros(S + 1, dtype=torch.int32, device=DEV),
-                         torch.zeros(cap, dtype=torch.uint8, device=DEV))
+                         torch.zeros(cap, dtype=torch.uint8, device=DEV),
+                         torch.zeros(2 + 2 * cap, dtype=torch.int32, device=DEV))
         torch.cuda.synchronize()
         out_cnt = seg_cnt.cpu().numpy()
         X = torch.stack([px, py, pz], 1).cpu().numpy()
@@ -170,8 +171,11 @@ def _cluster_cases(rng):
     cases.append(np.stack([np.arange(40) * 2.99 + 1.0, np.zeros(40)], 1)[rng.permutation(40)])   # chain
     cases.append(np.stack([np.arange(40) * 3.2 + 1.0, np.zeros(40)], 1))                        # all apart
     cases.append(np.zeros((0, 2)))
-    big = rng.uniform(-60, 60, (13000, 2))                       # > LDS parent capacity
-    cases.append(big)
+    cases.append(rng.uniform(-60, 60, (13000, 2)))               # large-LDS variant
+    two = np.concatenate([rng.normal(0, 1.0, (2500, 2)), rng.normal(0, 1.0, (2600, 2)) + [40.0, 0.0]])
+    cases.append(two[rng.permutation(len(two))])                 # two dense blobs, interleaved
+    cases.append(np.concatenate([rng.normal(0, 2.0, (29000, 2)), rng.uniform(-200, 200, (600, 2))]))  # 16-bit LDS parents
+    cases.append(np.concatenate([rng.normal(0, 3.0, (61000, 2)), rng.uniform(-300, 300, (700, 2))]))  # parents in global memory
     return cases
 
 
