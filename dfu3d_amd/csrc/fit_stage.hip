@@ -608,6 +608,8 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
           o[9] = height; o[10] = width; o[11] = length;
           o[12] = rx; o[13] = ry; o[14] = rz; o[15] = rotation;
           o[16] = (double)inst_score[s]; o[17] = (double)m;
+          o[18] = thb; o[19] = c1min; o[20] = c2min; o[21] = c1max; o[22] = c2max;
+          o[23] = (double)root;
         } else {
           atomicOr(status, DFU3D_ST_ROW_OVERFLOW);
         }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ base_a,
     const int *__restrict__ cnt_a, const long long *__restrict__ base_b,
-    const int *__restrict__ cnt_b, double C, int S, const int *__restrict__ tile_off,
+    const int *__restrict__ cnt_b, double T, int S, const int *__restrict__ tile_off,
     uint8_t *__restrict__ flags) {
   __shared__ double sx[PT], sy[PT], sz[PT];
   __shared__ int s_pending;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
         double d = dx * dx;
         d += dy * dy;
         d += dz * dz;
-        if (sqrt(d) < C) { found = true; break; }
+        if (d < T) { found = true; break; }      // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
       }
       if (!found) s_pending = 1;
     }
@@ -506,11 +506,18 @@ extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const in
   if (!px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !tile_off || !flags)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
+  if (!(C > 0.0) || !(C < 1e150)) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // The reference tests sqrt(d2) < C (my_loader.py:490-493).  sqrt is monotone
+  // and correctly rounded, so that is d2 < T with T the smallest double whose
+  // rounded square root reaches C; T is found exactly here, once, on the host.
+  double T = C * C;
+  while (__builtin_sqrt(T) >= C) T = __builtin_nextafter(T, 0.0);
+  while (__builtin_sqrt(T) < C) T = __builtin_nextafter(T, __builtin_inf());
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_ball_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
-                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, C, S,
+                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, S,
                      tile_off, flags);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz, (long long *)base_b,

@@ -48,7 +48,7 @@ class PseudoBoxEngine:
     def __init__(self, params: Params, H: int, W: int, max_inst: int, cap_n: int,
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
-                 device="cuda:0"):
+                 device="cuda:0", apply_fov: bool = True):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         if tuple(params.bounds_hw) != (int(H), int(W)):
@@ -56,6 +56,7 @@ class PseudoBoxEngine:
                              "(hazard H11: canonical nuScenes = 900x1600 everywhere)"
                              % (tuple(params.bounds_hw), H, W))
         self.p = params
+        self.apply_fov = bool(apply_fov)   # False: the caller already FOV-filtered (vis_utils.py:152-154)
         self.H, self.W, self.M = int(H), int(W), int(max_inst)
         self.cap_n = int(cap_n)
         self.Vc = int(views_per_chunk)
@@ -147,8 +148,15 @@ class PseudoBoxEngine:
         masks = b.masks[v0:v1]
         n_inst = b.n_inst[v0:v1]
         R = self._run
-        R("fov_filter", st.fov_filter, b.points, b.pt_off, vf, calib, V, p.fov_hw, cap_n,
-          self.fov_idx, self.n_fov, b.host_pt_off, b.host_view_frame[v0:v1])
+        if self.apply_fov:
+            R("fov_filter", st.fov_filter, b.points, b.pt_off, vf, calib, V, p.fov_hw, cap_n,
+              self.fov_idx, self.n_fov, b.host_pt_off, b.host_view_frame[v0:v1])
+        else:                       # every point of the frame, in order
+            st._check_frames(b.points, b.pt_off, vf, V, cap_n, b.host_pt_off, b.host_view_frame[v0:v1])
+            sizes = (b.pt_off[1:] - b.pt_off[:-1])[vf.long()]
+            self.n_fov.copy_(sizes)
+            self.fov_idx.view(V, cap_n).copy_(
+                torch.arange(cap_n, dtype=torch.int32, device=self.dev).expand(V, cap_n))
         if b.plane is None:
             R("plane_ransac", st.plane_ransac, b.points, b.pt_off, vf, self.fov_idx, self.n_fov, V, cap_n,
                             p.plane_max_hs, p.plane_range, p.ransac_trials, p.ransac_seed,
@@ -225,6 +233,20 @@ class PseudoBoxEngine:
         if not sync:
             return None, None
         return self.collect()
+
+    def virtual_points(self, b: ViewBatch, v0: int = 0):
+        """Voxel representatives under la_sampling2's rule (argmin z, my_loader.py:247-260)
+        for the chunk of views starting at v0 -> (n_vox (Vc,), pixel (Vc,cap_vox), xyz (Vc,cap_vox,3))."""
+        if not self.dense or b.depth is None:
+            raise Dfu3dError("virtual_points needs the dense path")
+        V = self.Vc
+        status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        st.backproject_bin(b.depth[v0:v0 + V], b.calib[v0:v0 + V], None, None, V, self.M, self.H,
+                           self.W, self.geom, self.E, 2, self.table, self.pix_bin, self.blk_cnt,
+                           self.cap_vox, self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
+                           self.b_z, status)
+        xyz = torch.stack([self.b_x, self.b_y, self.b_z], 1).view(V, self.cap_vox, 3)
+        return self.n_vox.clone(), self.vox_pix.view(V, self.cap_vox).clone(), xyz, int(status.item())
 
     def collect(self):
         rows, n_rows, status = self._last

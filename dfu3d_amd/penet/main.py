@@ -1,0 +1,74 @@
+"""CLI mirror of `python main.py --command evaluate ...`
+(tools/PENet/main.py:38-180, README.md:75-78).
+
+Keeps the reference's flags (model flags are accepted and ignored: SEEM and
+DepthAnything are input providers outside this path) and adds
+--seg-dir/--depth-dir for precomputed inputs, --label-out, --start/--end and
+--skip-existing.  Frames are the sorted stems of <detpath>/velodyne
+(my_loader_KittiPandasetWaymo.py:1083-1090); with torchrun every rank takes
+frames rank, rank+world, ... and writes its own label files."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description='DFU3D pseudo-box generation (MI355X)')
+    ap.add_argument('--command', default="evaluate")
+    ap.add_argument('-n', '--network-model', type=str, default="pe", choices=["e", "pe"])
+    ap.add_argument('--workers', default=4, type=int)
+    ap.add_argument('--detpath', default='../../data/kitti/training', type=str)
+    ap.add_argument('-e', '--evaluate', default='pe.pth.tar', type=str)
+    ap.add_argument('--test', action="store_true", default=True)
+    ap.add_argument('--cpu', action="store_true", default=False,
+                    help='the reference\'s flag; this build has no CPU path and refuses it')
+    ap.add_argument('--model', type=str, default='zoedepth')
+    ap.add_argument('--pretrained_resource', type=str, default='')
+    ap.add_argument('--conf_files', nargs='+', default=[])
+    ap.add_argument('--user_dir', default=None)
+    ap.add_argument('--config_overrides', nargs='*')
+    ap.add_argument('--overrides', nargs=argparse.REMAINDER, default=[])
+    # additive
+    ap.add_argument('--depth-dir', default=None, help='<dir>/<idx>.npy dense metric depth (H,W); default <detpath>/depth_2')
+    ap.add_argument('--label-out', default=None, help='default <detpath>/label_2')
+    ap.add_argument('--start', type=int, default=0)
+    ap.add_argument('--end', type=int, default=None)
+    ap.add_argument('--skip-existing', action='store_true')
+    return ap
+
+
+def frame_list(detpath):
+    return sorted(f[:-4] for f in os.listdir(os.path.join(detpath, 'velodyne')) if f.endswith('.bin'))
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.cpu:
+        raise SystemExit("--cpu: this build has no CPU path (the oracle under oracle/ is test-only)")
+    from .. import dist as D
+    from .vis_utils import save_depth_as_points
+    rank, world, local = D.init_from_env()
+    frames = frame_list(args.detpath)[args.start:args.end]
+    mine = [frames[i] for i in D.shard_frames(len(frames), rank, world)]
+    depth_dir = args.depth_dir or os.path.join(args.detpath, 'depth_2')
+    label_out = args.label_out or os.path.join(args.detpath, 'label_2')
+    t0 = time.time()
+    for k, idx in enumerate(mine):
+        if args.skip_existing and os.path.exists(os.path.join(label_out, idx + '.txt')):
+            continue
+        depth = np.load(os.path.join(depth_dir, idx + '.npy')).astype(np.float32)
+        save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
+                             device="cuda:%d" % (local if world > 1 else 0))
+        if rank == 0 and (k + 1) % 10 == 0:
+            print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import BinGeom, Dfu3dError
 
 CALIB_FLOATS = 48
-ROW_DOUBLES = 18
+ROW_DOUBLES = 24
 MAX_INST = 32
 
 BP_BIN, BP_REPAIR, BP_REP, BP_EMIT, BP_VOX, BP_ALL = 1, 2, 4, 8, 16, 31

@@ -39,7 +39,7 @@ extern "C" {
 
 #define DFU3D_VERSION 100          /* 0.1.0 */
 #define DFU3D_CALIB_FLOATS 48
-#define DFU3D_ROW_DOUBLES 18       /* see dfu3d_lshape_fit */
+#define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_MAX_INST 32
 
 #define DFU3D_OK 0
@@ -223,7 +223,9 @@ int dfu3d_range_cluster(const double *px, const double *py,
  * One row per (segment, cluster) in rows[DFU3D_ROW_DOUBLES]:
  *   0 view, 1 inst j, 2 cluster k, 3 class index, 4 alpha, 5..8 bbox x1 y1 x2 y2,
  *   9 h, 10 w, 11 l, 12 x, 13 y, 14 z (rect camera), 15 ry, 16 score,
- *   17 number of cluster points.
+ *   17 number of cluster points, 18 best heading theta*, 19..22 rectangle
+ *   offsets c (min c1, min c2, max c1, max c2: RectangleData.c,
+ *   rectangle_fitting.py:145-157), 23 smallest point index of the cluster.
  * Rows are appended in arbitrary order (sort by cols 0..2); n_rows is a device
  * counter.  inst_class/inst_is_car: int32 (S); inst_box: float32 (S,4);
  * inst_score float32 (S).  Scratch: sx, sy fp64 (pool_cap), sroot int32

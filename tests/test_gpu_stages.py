@@ -235,7 +235,7 @@ def test_lshape_fit_matches_oracle(st):
     label = torch.zeros(cap, dtype=torch.int32, device=DEV)
     st.range_cluster(px, py, tb, tc, S, p.R0, p.Rd, label, cap)
     cap_rows = 64
-    rows = torch.zeros(cap_rows * 18, dtype=torch.float64, device=DEV)
+    rows = torch.zeros(cap_rows * st.ROW_DOUBLES, dtype=torch.float64, device=DEV)
     n_rows = torch.zeros(1, dtype=torch.int32, device=DEV)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     calib = _t(np.stack([cal.record()] * V))
@@ -249,7 +249,7 @@ def test_lshape_fit_matches_oracle(st):
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     n = int(n_rows.item())
-    R = rows.view(cap_rows, 18)[:n].cpu().numpy()
+    R = rows.view(cap_rows, st.ROW_DOUBLES)[:n].cpu().numpy()
     R = R[np.lexsort((R[:, 2], R[:, 1], R[:, 0]))]
     exp = []
     for s, pts in enumerate(segs):
