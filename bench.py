@@ -73,8 +73,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
-    ap.add_argument("--chunk-frames", type=int, default=8, help="frames per kernel-launch chunk")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--chunk-frames", type=int, default=16, help="frames per kernel-launch chunk")
+    ap.add_argument("--lanes", type=int, default=4, help="concurrent HIP streams (one chunk each)")
     ap.add_argument("--sparse", action="store_true", help="depth off (hazard H20 extension)")
     ap.add_argument("--boxes", type=int, nargs=2, default=[30, 40], help="objects per scene (min max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,7 +112,8 @@ def main():
     log("[rank %d] %d frames generated in %.1fs" % (rank, frames, time.time() - t0))
 
     eng = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=args.chunk_frames * CAMS,
-                          dense=dense, cap_vox=1 << 18, pool_per_view=1 << 17, device=dev)
+                          dense=dense, cap_vox=1 << 18, pool_per_view=1 << 17, device=dev,
+                          lanes=args.lanes)
 
     def step():
         rows, status = eng.run(batch)
@@ -155,12 +157,13 @@ def main():
                                    % ("on (dense)" if dense else "off (sparse)", frames, N_PTS, CAMS, W, H,
                                       MAX_INST, args.boxes[0], args.boxes[1]),
                        "frames_per_gpu_per_step": frames, "views_per_launch_chunk": args.chunk_frames * CAMS,
+                       "streams": args.lanes,
                        "boxes_per_step_all_ranks": n_boxes, "parallelism": "frames sharded x%d" % world},
         }
         if kern:
             # algorithmic bytes per launch (DESIGN.md §kernels / SURVEY.md §8d)
             views_per_launch = args.chunk_frames * CAMS
-            rf_pts = int(eng._rf_points.item())
+            rf_pts = eng.rf_points_total()
             n_rf_launch = kern.get("rf_flags", (0, 1))[1]
             alg = {
                 "bp_bin": views_per_launch * H * W * 4,                  # depth read

@@ -35,6 +35,14 @@ struct ParI {
     if (global) atomicMin(p + i, r); else p[i] = r;
   }
   __device__ __forceinline__ int amin(int i, int v) const { return atomicMin(p + i, v); }
+  // root shared by the 32 points of group g, or -1
+  __device__ __forceinline__ int group_root(int g) const {
+    const int r = load(g * 32);
+    int diff = 0;
+#pragma unroll 8
+    for (int k = 1; k < 32; k++) diff |= load(g * 32 + k) ^ r;
+    return diff ? -1 : r;
+  }
 };
 struct ParH {
   unsigned short *p;
@@ -56,6 +64,15 @@ struct ParH {
       if (seen == old) return (int)cur;
       old = seen;
     }
+  }
+  __device__ __forceinline__ int group_root(int g) const {     // 32 halfwords = 4 x 16 B
+    const uint4 *w = (const uint4 *)(p + g * 32);
+    const uint4 a = w[0], b = w[1], c = w[2], d = w[3];
+    const unsigned int e = (a.x & 0xFFFFu) * 0x10001u;
+    const unsigned int diff = (a.x ^ e) | (a.y ^ e) | (a.z ^ e) | (a.w ^ e) | (b.x ^ e) | (b.y ^ e) |
+                              (b.z ^ e) | (b.w ^ e) | (c.x ^ e) | (c.y ^ e) | (c.z ^ e) | (c.w ^ e) |
+                              (d.x ^ e) | (d.y ^ e) | (d.z ^ e) | (d.w ^ e);
+    return diff ? -1 : (int)(a.x & 0xFFFFu);
   }
 };
 
@@ -98,8 +115,8 @@ template <class P, int NGRP>
 __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s_box,
                                              int *s_summ2, float4 *s_box2,
                                              double *s_red, const double *X, const double *Y,
-                                             int n, double R0, double Rd, int *glabel,
-                                             bool write_labels) {
+                                             int n, double R0, double Rd, const int *perm,
+                                             int *tmp, int *glabel) {
   constexpr int NBLK = (NGRP + BLK - 1) / BLK;
   const int ngrp_all = min((n + GRP - 1) / GRP, NGRP);
   double r2max = 0.0;
@@ -142,18 +159,14 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
     for (int k = threadIdx.x; k < c0; k += CT) par.flatten(k, uf_find(par, k));
     __syncthreads();
     const int ngrp = min(c0 / GRP, NGRP);
-    for (int g = threadIdx.x; g < ngrp; g += CT) {
-      const int r = par.load(g * GRP);
-      bool same = true;
-      for (int k = 1; k < GRP; k++) same = same && (par.load(g * GRP + k) == r);
-      s_summ[g] = same ? r : -1;
-    }
+    for (int g = threadIdx.x; g < ngrp; g += CT) s_summ[g] = par.group_root(g);
     __syncthreads();
     for (int B = threadIdx.x; B < ngrp / BLK; B += CT) {        // fully flattened blocks only
       const int r = s_summ[B * BLK];
-      bool same = r >= 0;
-      for (int k = 1; k < BLK; k++) same = same && (s_summ[B * BLK + k] == r);
-      s_summ2[B] = same ? r : -1;
+      int diff = 0;
+#pragma unroll 8
+      for (int k = 1; k < BLK; k++) diff |= s_summ[B * BLK + k] ^ r;
+      s_summ2[B] = (r >= 0 && !diff) ? r : -1;
     }
     __syncthreads();
     const int nblk_sum = ngrp / BLK;
@@ -228,59 +241,160 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         }
       }
       if (!__any(need2)) continue;                              // wave-uniform
-      for (int g = g_hi - 1; g >= g_lo; g--) visit_group(g, need2);
+      if (g_lo >= NGRP) {                                       // beyond the summarised range
+        for (int g = g_hi - 1; g >= g_lo; g--) visit_group(g, need2);
+        continue;
+      }
+      // per lane: the groups of this block that are neither wholly mine nor too far
+      unsigned int cand = 0u;
+      if (need2) {
+        unsigned int mm = 0u;
+        const int ng = g_hi - g_lo;
+#pragma unroll 8
+        for (int q = 0; q < BLK; q++)
+          mm |= (q < ng && s_summ[g_lo + q] != ri) ? (1u << q) : 0u;
+        while (mm) {
+          const int q = __ffs((int)mm) - 1;
+          mm &= mm - 1u;
+          const float4 b = s_box[g_lo + q];
+          const double ddx = fmax(fmax((double)b.x - xi, xi - (double)b.y), 0.0);
+          const double ddy = fmax(fmax((double)b.z - yi, yi - (double)b.w), 0.0);
+          if (!(ddx * ddx + ddy * ddy > S_HI)) cand |= 1u << q;
+        }
+      }
+      unsigned int U = cand;                                    // union over the wave
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) U |= (unsigned int)__shfl_xor((int)U, m, 64);
+      while (U) {                                               // wave-uniform, backwards
+        const int q = 31 - __clz((int)U);
+        U &= ~(1u << q);
+        visit_group(g_lo + q, need2 && ((cand >> q) & 1u));
+      }
     }
     for (int g = gc; g < gend; g++) visit_group(g, act);
     __syncthreads();
   }
+  // Back to the reference's labelling: smallest ORIGINAL index of each cluster.
   for (int i = threadIdx.x; i < n; i += CT) {
-    const int r = uf_find(par, i);
-    if (write_labels) glabel[i] = r;
-    else atomicMin(glabel + i, r);                  // parents live in glabel: compress
+    par.flatten(i, uf_find(par, i));
+    tmp[i] = 0x7FFFFFFF;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += CT) atomicMin(&tmp[par.load(i)], perm[i]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += CT)
+    glabel[perm[i]] = __hip_atomic_load(&tmp[par.load(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Counting sort of one instance's points by spatial cell (row-major cells of
+// side >= 1.5 m over the instance's bounding box).  In sorted order 32
+// consecutive points are spatial neighbours, so the group summaries and boxes
+// of cluster_body prune almost everything even when clusters interleave in
+// input order (salt outliers along the same camera rays do exactly that).
+// hist: LDS ints (aliases the parent array, dead until the sort is done).
+template <int NCELL>
+__device__ __forceinline__ void cell_sort(const double *X, const double *Y, int n, int *hist,
+                                          double *s_red, int *s_w, double *SX, double *SY,
+                                          int *perm) {
+  double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += CT) {
+    const double x = X[i], y = Y[i];
+    x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+  }
+  x0 = wave_min_d(x0); x1 = wave_max_d(x1); y0 = wave_min_d(y0); y1 = wave_max_d(y1);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0) { s_red[4 * w] = x0; s_red[4 * w + 1] = x1; s_red[4 * w + 2] = y0; s_red[4 * w + 3] = y1; }
+  __syncthreads();
+  for (int k = 0; k < CT / 64; k++) {
+    x0 = fmin(x0, s_red[4 * k]); x1 = fmax(x1, s_red[4 * k + 1]);
+    y0 = fmin(y0, s_red[4 * k + 2]); y1 = fmax(y1, s_red[4 * k + 3]);
+  }
+  __syncthreads();
+  double ex = fmax(x1 - x0, 1e-6), ey = fmax(y1 - y0, 1e-6);
+  if (!(ex < 1e12)) ex = 1e12;
+  if (!(ey < 1e12)) ey = 1e12;
+  double g = 1.5;
+  if ((ex / g + 1.0) * (ey / g + 1.0) > (double)NCELL) g = sqrt(ex * ey / (double)NCELL) * 1.05 + 1e-9;
+  int nx = (int)(ex / g) + 1, ny = (int)(ey / g) + 1;
+  while ((long long)nx * ny > NCELL) { g *= 1.1; nx = (int)(ex / g) + 1; ny = (int)(ey / g) + 1; }
+  const int ncell = nx * ny;
+  const double inv = 1.0 / g;
+  for (int c = threadIdx.x; c < ncell; c += CT) hist[c] = 0;
+  __syncthreads();
+  auto cell_of = [&](double x, double y) {
+    const int cx = (int)fmin(fmax((x - x0) * inv, 0.0), (double)(nx - 1));
+    const int cy = (int)fmin(fmax((y - y0) * inv, 0.0), (double)(ny - 1));
+    return cy * nx + cx;
+  };
+  for (int i = threadIdx.x; i < n; i += CT) atomicAdd(&hist[cell_of(X[i], Y[i])], 1);
+  __syncthreads();
+  // exclusive scan of the cell counts (each thread owns a contiguous run of cells)
+  const int per = (ncell + CT - 1) / CT;
+  const int c_lo = min(threadIdx.x * per, ncell), c_hi = min(c_lo + per, ncell);
+  int mine = 0;
+  for (int c = c_lo; c < c_hi; c++) mine += hist[c];
+  int tot;
+  int run = block_excl_scan<CT / 64>(mine, s_w, tot);
+  for (int c = c_lo; c < c_hi; c++) { const int h = hist[c]; hist[c] = run; run += h; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += CT) {
+    const double x = X[i], y = Y[i];
+    const int pos = atomicAdd(&hist[cell_of(x, y)], 1);
+    SX[pos] = x;
+    SY[pos] = y;
+    perm[pos] = i;
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(CT) void k_range_cluster_small(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
-    double Rd, int *__restrict__ label) {
-  __shared__ int s_parent[SMALL_N];
+    double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
+    int *__restrict__ si, long long pool_cap) {
+  __shared__ __attribute__((aligned(16))) int s_parent[SMALL_N];
   __shared__ int s_summ[SMALL_N / GRP];
   __shared__ float4 s_box[SMALL_N / GRP];
   __shared__ int s_summ2[SMALL_N / GRP / BLK];
   __shared__ float4 s_box2[SMALL_N / GRP / BLK];
-  __shared__ double s_red[CT / 64];
+  __shared__ double s_red[4 * (CT / 64)];
+  __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0 || n > SMALL_N) return;
   const long long base = seg_base[s];
+  cell_sort<SMALL_N>(px + base, py + base, n, s_parent, s_red, s_w, sx + base, sy + base, si + base);
   ParI par{s_parent, false};
-  cluster_body<ParI, SMALL_N / GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
-                                    label + base, true);
+  cluster_body<ParI, SMALL_N / GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, sx + base, sy + base,
+                                    n, R0, Rd, si + base, si + pool_cap + base, label + base);
 }
 
 __global__ __launch_bounds__(CT) void k_range_cluster_large(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
-    double Rd, int *__restrict__ label) {
-  __shared__ unsigned short s_parent[LARGE_N];
+    double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
+    int *__restrict__ si, long long pool_cap) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_parent[LARGE_N];
   __shared__ int s_summ[LARGE_GRP];
   __shared__ float4 s_box[LARGE_GRP];
   __shared__ int s_summ2[LARGE_GRP / BLK];
   __shared__ float4 s_box2[LARGE_GRP / BLK];
-  __shared__ double s_red[CT / 64];
+  __shared__ double s_red[4 * (CT / 64)];
+  __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n <= SMALL_N) return;
   const long long base = seg_base[s];
+  cell_sort<LARGE_N / 2>(px + base, py + base, n, (int *)s_parent, s_red, s_w, sx + base, sy + base,
+                         si + base);
   if (n <= LARGE_N) {
     ParH par{s_parent};
-    cluster_body<ParH, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
-                                  label + base, true);
-  } else {          // parents in global memory (the label array itself)
-    ParI par{label + base, true};
-    cluster_body<ParI, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, px + base, py + base, n, R0, Rd,
-                                  label + base, false);
+    cluster_body<ParH, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, sx + base, sy + base,
+                                  n, R0, Rd, si + base, si + pool_cap + base, label + base);
+  } else {          // parents in global memory: the third scratch plane is free until the epilogue
+    ParI par{si + 2 * pool_cap + base, true};
+    cluster_body<ParI, LARGE_GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, sx + base, sy + base,
+                                  n, R0, Rd, si + base, si + pool_cap + base, label + base);
   }
 }
 
@@ -623,16 +737,19 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
 
 extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int64_t *seg_base,
                                    const int32_t *seg_cnt, int32_t S, double R0, double Rd,
-                                   int32_t *label, void *stream) {
-  if (!px || !py || !seg_base || !seg_cnt || !label) return DFU3D_EINVAL;
-  if (S <= 0) return DFU3D_EINVAL;
+                                   int32_t *label, double *sx, double *sy, int32_t *si,
+                                   int64_t pool_cap, void *stream) {
+  if (!px || !py || !seg_base || !seg_cnt || !label || !sx || !sy || !si) return DFU3D_EINVAL;
+  if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // two LDS footprints: small instances (<= SMALL_N points, several workgroups per
   // CU) and large ones; each kernel returns at once for the other's segments
   hipLaunchKernelGGL(k_range_cluster_small, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
-                     (const long long *)seg_base, seg_cnt, R0, Rd, label);
+                     (const long long *)seg_base, seg_cnt, R0, Rd, label, sx, sy, si,
+                     (long long)pool_cap);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_range_cluster_large, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
-                     (const long long *)seg_base, seg_cnt, R0, Rd, label);
+                     (const long long *)seg_base, seg_cnt, R0, Rd, label, sx, sy, si,
+                     (long long)pool_cap);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }

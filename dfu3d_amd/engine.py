@@ -48,7 +48,7 @@ class PseudoBoxEngine:
     def __init__(self, params: Params, H: int, W: int, max_inst: int, cap_n: int,
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
-                 device="cuda:0", apply_fov: bool = True):
+                 device="cuda:0", apply_fov: bool = True, lanes: int = 1):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         if tuple(params.bounds_hw) != (int(H), int(W)):
@@ -66,45 +66,68 @@ class PseudoBoxEngine:
         self.cap_rows = int(rows_per_view) * self.Vc
         self.dev = torch.device(device)
         self.n_theta, self.dtheta = params.thetas()
-        V, S = self.Vc, self.Vc * self.M
-        d = self.dev
-        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=d)
-        f64 = lambda *s: torch.empty(s, dtype=torch.float64, device=d)
-        self.fov_idx, self.cand_idx = i32(V * cap_n), i32(V * cap_n)
-        self.ag_pt, self.ib_pix = i32(V * cap_n), i32(V * cap_n)
-        self.n_fov, self.n_ag, self.K = i32(V), i32(V), i32(V)
-        self.plane = f64(V * 4)
-        self.a_bits = i32(V * cap_n)
-        self.a_x, self.a_y, self.a_z = f64(V * cap_n), f64(V * cap_n), f64(V * cap_n)
-        cv = self.cap_vox
-        self.n_vox = torch.zeros(V, dtype=torch.int32, device=d)
-        self.vox_pix, self.b_bits = i32(V * cv), i32(V * cv)
-        self.b_x, self.b_y, self.b_z = f64(V * cv), f64(V * cv), f64(V * cv)
-        if dense:
-            self.geom, self.E = st.make_geom(
-                params.depth_min, params.z_max, params.theta_min, params.vsize,
-                params.vrange_min, params.vgrid, params.max_points_per_voxel, params.max_voxels)
-            self.table = torch.empty(V * self.E * st.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=d)
-            st.bin_table_init(self.table, V * self.E)
-            pw, bw = st.backproject_scratch_words(V, H, W, cv, params.max_points_per_voxel)
-            self.pix_bin, self.blk_cnt = i32(pw), i32(bw)
-        pc = self.pool_cap
-        self.px, self.py, self.pz = f64(pc), f64(pc), f64(pc)
-        self.sx, self.sy = f64(pc), f64(pc)
-        self.label, self.sroot = i32(pc), i32(pc)
-        self.flags = torch.empty(pc, dtype=torch.uint8, device=d)
-        self.mean_d = f64(pc) if params.stat_filter else None
-        self.base_a = torch.empty(S, dtype=torch.int64, device=d)
-        self.base_b = torch.empty(S, dtype=torch.int64, device=d)
-        self.cnt_a, self.cnt_b, self.cnt_all = i32(S), i32(S), i32(S)
-        self.tile_off = i32(S + 1)
-        self.queue = i32(2 + 2 * pc)
-        self.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
-        self.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
+        # `lanes` independent workspaces, each with its own HIP stream: chunks are
+        # dealt round-robin so that the long single-workgroup tails of one chunk
+        # (clustering / L-shape of a huge instance) overlap the streaming kernels
+        # of the others.
+        self.lanes = [self._make_lane(i, cap_n) for i in range(max(1, int(lanes)))]
+        self._bind(self.lanes[0])
         # optional per-kernel timing with HIP events on the launch stream
         self.timing = False
         self._events = []
-        self._rf_points = torch.zeros(1, dtype=torch.int64, device=d)
+
+
+    class _Lane:
+        pass
+
+    def _make_lane(self, index, cap_n):
+        L = PseudoBoxEngine._Lane()
+        L.stream = torch.cuda.current_stream(self.dev) if index == 0 else torch.cuda.Stream(self.dev)
+        with torch.cuda.stream(L.stream):
+            V, S = self.Vc, self.Vc * self.M
+            d = self.dev
+            i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=d)
+            f64 = lambda *s: torch.empty(s, dtype=torch.float64, device=d)
+            L.fov_idx, L.cand_idx = i32(V * cap_n), i32(V * cap_n)
+            L.ag_pt, L.ib_pix = i32(V * cap_n), i32(V * cap_n)
+            L.n_fov, L.n_ag, L.K = i32(V), i32(V), i32(V)
+            L.plane = f64(V * 4)
+            L.a_bits = i32(V * cap_n)
+            L.a_x, L.a_y, L.a_z = f64(V * cap_n), f64(V * cap_n), f64(V * cap_n)
+            cv = self.cap_vox
+            L.n_vox = torch.zeros(V, dtype=torch.int32, device=d)
+            L.vox_pix, L.b_bits = i32(V * cv), i32(V * cv)
+            L.b_x, L.b_y, L.b_z = f64(V * cv), f64(V * cv), f64(V * cv)
+            if self.dense:
+                L.geom, L.E = st.make_geom(
+                    self.p.depth_min, self.p.z_max, self.p.theta_min, self.p.vsize,
+                    self.p.vrange_min, self.p.vgrid, self.p.max_points_per_voxel, self.p.max_voxels)
+                L.table = torch.empty(V * L.E * st.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=d)
+                st.bin_table_init(L.table, V * L.E)
+                pw, bw = st.backproject_scratch_words(V, self.H, self.W, cv, self.p.max_points_per_voxel)
+                L.pix_bin, L.blk_cnt = i32(pw), i32(bw)
+            pc = self.pool_cap
+            L.px, L.py, L.pz = f64(pc), f64(pc), f64(pc)
+            L.sx, L.sy = f64(pc), f64(pc)
+            L.label, L.sroot = i32(pc), i32(pc)
+            L.si3 = i32(3 * pc)
+            L.flags = torch.empty(pc, dtype=torch.uint8, device=d)
+            L.mean_d = f64(pc) if self.p.stat_filter else None
+            L.base_a = torch.empty(S, dtype=torch.int64, device=d)
+            L.base_b = torch.empty(S, dtype=torch.int64, device=d)
+            L.cnt_a, L.cnt_b, L.cnt_all = i32(S), i32(S), i32(S)
+            L.tile_off = i32(S + 1)
+            L.queue = i32(2 + 2 * pc)
+            L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
+            L.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
+            L.rf_points = torch.zeros(1, dtype=torch.int64, device=d)   # timing mode only
+        return L
+
+    def _bind(self, L):
+        """Make lane L's buffers the ones the stage calls use."""
+        for k, v in L.__dict__.items():
+            if k != "stream":
+                setattr(self, k, v)
 
     # ------------------------------------------------------------------
     def _run(self, name, fn, *a, **k):
@@ -135,7 +158,11 @@ class PseudoBoxEngine:
 
     def reset_timing(self):
         self._events = []
-        self._rf_points.zero_()
+        for L in self.lanes:
+            L.rf_points.zero_()
+
+    def rf_points_total(self):
+        return int(sum(int(L.rf_points.item()) for L in self.lanes))
 
     # ------------------------------------------------------------------
     def _chunk(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
@@ -188,7 +215,7 @@ class PseudoBoxEngine:
         rf_ph = (("tiles", st.RF_TILES), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE),
                  ("compact", st.RF_COMPACT))
         if self.timing:
-            self._rf_points += self.cnt_a.sum() + self.cnt_b.sum()
+            self.rf_points += self.cnt_a.sum() + self.cnt_b.sum()
         self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
                      self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
                      self.queue)
@@ -202,8 +229,8 @@ class PseudoBoxEngine:
         R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
                           self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags)
         torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
-        R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0, p.Rd, self.label,
-                         self.pool_cap)
+        R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0,
+          p.Rd, self.label, self.pool_cap, self.sx, self.sy, self.si3)
         R("lshape_fit", st.lshape_fit, self.px, self.py, self.pz, self.label, self.base_a, self.cnt_all, S, M,
                       calib, b.inst_class[v0:v1].reshape(-1), b.inst_is_car[v0:v1].reshape(-1),
                       b.inst_box[v0:v1].reshape(-1), b.inst_score[v0:v1].reshape(-1),
@@ -226,9 +253,19 @@ class PseudoBoxEngine:
         rows = torch.empty((nch, self.cap_rows * st.ROW_DOUBLES), dtype=torch.float64, device=d)
         n_rows = torch.zeros((nch,), dtype=torch.int32, device=d)
         status = torch.zeros((nch,), dtype=torch.int32, device=d)
+        main = torch.cuda.current_stream(self.dev)
+        for L in self.lanes[1:]:
+            L.stream.wait_stream(main)              # inputs / row buffers are ready
+            for t in (rows, n_rows, status):
+                t.record_stream(L.stream)
         for c in range(nch):
-            self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
-                        status[c:c + 1])
+            L = self.lanes[c % len(self.lanes)]
+            self._bind(L)
+            with torch.cuda.stream(L.stream if len(self.lanes) > 1 else main):
+                self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
+                            status[c:c + 1])
+        for L in self.lanes[1:]:
+            main.wait_stream(L.stream)
         self._last = (rows, n_rows, status)
         if not sync:
             return None, None

@@ -246,12 +246,18 @@ def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, til
     _lib.check(rc, "dfu3d_ballquery_fuse")
 
 
-def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap):
+def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap, sx=None, sy=None, si=None):
+    dev = px.device
+    sx = sx if sx is not None else torch.empty(pool_cap, dtype=torch.float64, device=dev)
+    sy = sy if sy is not None else torch.empty(pool_cap, dtype=torch.float64, device=dev)
+    si = si if si is not None else torch.empty(3 * pool_cap, dtype=torch.int32, device=dev)
     rc = _lib.lib().dfu3d_range_cluster(
         _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
         _chk(seg_base, "seg_base", torch.int64, numel=S),
         _chk(seg_cnt, "seg_cnt", torch.int32, numel=S), S, float(R0), float(Rd),
-        _chk(label, "label", torch.int32, numel=pool_cap), _stream())
+        _chk(label, "label", torch.int32, numel=pool_cap),
+        _chk(sx, "sx", torch.float64, numel=pool_cap), _chk(sy, "sy", torch.float64, numel=pool_cap),
+        _chk(si, "si", torch.int32, numel=3 * pool_cap), pool_cap, _stream())
     _lib.check(rc, "dfu3d_range_cluster")
 
 

@@ -212,10 +212,13 @@ int dfu3d_ballquery_fuse(double *px, double *py, double *pz,
 /* ---- a13: _adoptive_range_segmentation (rectangle_fitting.py:161-191) ------
  * label[seg_base[s] + i] = smallest in-segment index of the cluster that
  * contains point i (clusters = connected components of d_ij <= R_i or
- * d_ij <= R_j, R = R0 + Rd*|p|_xy).  No wall-clock abort (hazard H2). */
+ * d_ij <= R_j, R = R0 + Rd*|p|_xy).  No wall-clock abort (hazard H2).
+ * Scratch: sx, sy fp64 (pool_cap each), si int32 (3*pool_cap): the points of
+ * each instance are counting-sorted by spatial cell before they are merged. */
 int dfu3d_range_cluster(const double *px, const double *py,
                         const int64_t *seg_base, const int32_t *seg_cnt,
                         int32_t S, double R0, double Rd, int32_t *label,
+                        double *sx, double *sy, int32_t *si, int64_t pool_cap,
                         void *stream);
 
 /* ---- a14/a15: _rectangle_search + GenerateAnns

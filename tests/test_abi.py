@@ -28,7 +28,7 @@ def test_argument_validation_without_gpu():
     """Null pointers / bad sizes are rejected on the host before any launch."""
     L = _lib.lib()
     assert L.dfu3d_fov_filter(None, None, None, None, 1, 900, 1600, 10, None, None, None) == -1
-    assert L.dfu3d_range_cluster(None, None, None, None, 0, 3.0, 0.001, None, None) == -1
+    assert L.dfu3d_range_cluster(None, None, None, None, 0, 3.0, 0.001, None, None, None, None, 8, None) == -1
 
 
 def test_bin_table_geometry_covers_reachable_bins():

@@ -37,3 +37,26 @@ none = torch.zeros_like(cnt)
 print("empty launch: %.3f ms" % timeit(lambda: st.range_cluster(eng.px, eng.py, eng.base_a, none, S, p.R0, p.Rd, eng.label, eng.pool_cap)))
 small = cnt.clone(); small[cnt > 4096] = 0
 print("only n<=4096: %.3f ms" % timeit(lambda: st.range_cluster(eng.px, eng.py, eng.base_a, small, S, p.R0, p.Rd, eng.label, eng.pool_cap)))
+large = cnt.clone(); large[cnt <= 4096] = 0
+print("only n>4096 (%d segs): %.3f ms" % (int((large > 0).sum()), timeit(lambda: st.range_cluster(eng.px, eng.py, eng.base_a, large, S, p.R0, p.Rd, eng.label, eng.pool_cap))))
+for k in (2, 4, 8, 16):
+    sel = torch.zeros_like(cnt); sel[order[:k]] = cnt[order[:k]]
+    print("top-%d together: %.3f ms" % (k, timeit(lambda: st.range_cluster(eng.px, eng.py, eng.base_a, sel, S, p.R0, p.Rd, eng.label, eng.pool_cap))))
+print("segment ids of top:", order)
+allorder = torch.argsort(cnt, descending=True).tolist()
+for s_ in allorder[12:30]:
+    if int(cnt[s_]) <= 3000: break
+    one = torch.zeros_like(cnt); one[s_] = cnt[s_]
+    t = timeit(lambda: st.range_cluster(eng.px, eng.py, eng.base_a, one, S, p.R0, p.Rd, eng.label, eng.pool_cap))
+    b0 = int(eng.base_a[s_]); n_ = int(cnt[s_])
+    lab = eng.label[b0:b0 + n_]
+    roots, sizes = torch.unique(lab, return_counts=True)
+    xs = eng.px[b0:b0+n_]; ys = eng.py[b0:b0+n_]
+    print("seg %4d n=%6d clusters=%3d top sizes %s extent %.1f x %.1f  %.3f ms" % (s_, n_, roots.numel(), sorted(sizes.tolist())[::-1][:5], float(xs.max()-xs.min()), float(ys.max()-ys.min()), t))
+import os
+os.makedirs("gpurun_out", exist_ok=True)
+dump = {}
+for s_ in (123, 168, 28, 18):
+    b0 = int(eng.base_a[s_]); n_ = int(cnt[s_])
+    dump["seg%d" % s_] = torch.stack([eng.px[b0:b0+n_], eng.py[b0:b0+n_]], 1).cpu().numpy()
+np.savez_compressed("gpurun_out/slow_segments.npz", **dump)
