@@ -118,3 +118,23 @@ def test_cli_on_kitti_directory_matches_oracle(tmp_path):
         assert np.array_equal(vp, exp[f].all_points.astype(np.float16))
     # a second run with --skip-existing leaves the files alone
     assert cli.main(["--detpath", root, "--skip-existing", "--conf_files", "x.yaml"]) == 0
+
+
+def test_integration_md_ctypes_example_runs_and_matches_oracle(monkeypatch):
+    """The ctypes binding printed in INTEGRATION.md §2 is executed as written."""
+    _need_gpu()
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "def filter_and_fuse" in b)
+    monkeypatch.chdir(root)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(77)
+    L = rng.normal(0, 1.5, (300, 3)); L[:5] += 40.0                 # a few isolated LiDAR points
+    P = np.concatenate([L[rng.integers(5, 300, 900)] + rng.normal(0, 0.05, (900, 3)),
+                        rng.normal(0, 1.5, (600, 3)), rng.uniform(-60, 60, (20, 3))])
+    out = ns["filter_and_fuse"](torch.from_numpy(L).cuda(), torch.from_numpy(P).cuda()).cpu().numpy()
+    exp, _, _ = O.instance_points("Car", L, P, O.Params())
+    assert np.array_equal(out, exp)
