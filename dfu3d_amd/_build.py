@@ -37,7 +37,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", OUT]
+    extra = os.environ.get("DFU3D_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -108,48 +108,195 @@ __device__ __forceinline__ void load4(const float *p, int base, int n, float d[P
 }
 
 // ---- P1 ---------------------------------------------------------------------
+// table update shared by the two classification kernels
+__device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key,
+                                             uint32_t b, int v, int max_points, int cap_ovf,
+                                             uint32_t *ovf_bins, int *n_ovf) {
+#ifdef DFU3D_DBG_NOATOMIC
+  if (pix == -12345) T.cnt[e] = 1;   // experiment: classification cost without table atomics
+  return;
+#endif
+  const uint32_t old = atomicAdd(&T.cnt[e], 1u);
+  atomicMin(&T.first[e], (uint32_t)pix);
+  atomicMin(&T.kmin[e], ordered_key(key));
+  if (old == (uint32_t)max_points) {               // the (cap+1)-th arrival
+    const int slot = atomicAdd(&n_ovf[v], 1);
+    if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
+  }
+}
+
+constexpr uint32_t AMBIG = 0xFFFFFFFEu;
+
+// Tier 1 of the classification.  x,y,z come from the exact fp64 back-projection;
+// the spherical angles are estimated in fp32 and accepted only when the
+// estimate is farther from every decision boundary (theta_min, bin edges,
+// r range) than a rigorous bound on |fp32 estimate - fp64 value|, in which case
+// the fp64 path of pixel_bin() would decide identically.  Everything else
+// returns AMBIG and is classified by pixel_bin() in k_bp_bin_amb.
+__device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const dfu3d_bin_geom &g,
+                                                   double inv_t, double inv_p, int W, int pix,
+                                                   float d, int key_axis, double &key) {
+  if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
+  const int row = pix / W, col = pix - row * W;
+  double x, y, z;
+  pixel_to_lidar(c, col, row, d, x, y, z);
+  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
+  key = (key_axis == 2) ? z : y;
+  if (key == 0.0) key = 0.0;
+  const float xf = (float)x, yf = (float)y, zf = (float)z;
+  const float r2 = xf * xf + yf * yf + zf * zf;
+  const float rf = sqrtf(r2);
+  // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
+  if (!(rf > 1e-3f) || g.grid_r != 1 || !((double)rf * 1.0001 < g.rmin_r + g.vsize_r) ||
+      !((double)rf > g.rmin_r + 1e-3))
+    return AMBIG;
+  const float cz = zf / rf;                                       // |err| <= 5e-7
+  const float s2 = 1.0f - cz * cz;
+  if (!(s2 > 1e-4f)) return AMBIG;                                // near the poles: d(acos) blows up
+  const float th = acosf(cz);
+  const float eps_t = 2e-5f + 4e-6f * rsqrtf(s2);                 // >= 5e-7/sin(theta) + acosf error, with margin
+  if (th < (float)g.theta_min - eps_t) return NOBIN;              // certainly theta <= theta_min
+  if (!(th > (float)g.theta_min + eps_t)) return AMBIG;
+  if (!(fabsf(xf) > 1e-20f)) return AMBIG;
+  const float ph = atanf(yf / xf);                                // |err| <= 2e-6
+  const float eps_p = 2e-5f;
+  const double qt = ((double)th - g.rmin_t) * inv_t, qp = ((double)ph - g.rmin_p) * inv_p;
+  const double ft = qt - floor(qt), fp = qp - floor(qp);
+  const double mt = (double)eps_t * inv_t + 1e-6, mp = (double)eps_p * inv_p + 1e-6;
+  if (!(ft > mt && ft < 1.0 - mt && fp > mp && fp < 1.0 - mp)) return AMBIG;
+  const int it = (int)floor(qt) - g.t_lo, ip = (int)floor(qp) - g.p_lo;
+  if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) return AMBIG;
+  return (uint32_t)(it * g.p_n + ip);
+}
+
+// Pass 1 works on 2-D image tiles (TILE_W x TILE_H pixels, one float4 per
+// thread): neighbouring pixels share spherical bins (~2.5 x 2.5 pixels per
+// 0.002 rad bin), so the tile first aggregates count / first pixel / min key in
+// an LDS window over the bins it touches and then issues one set of global
+// atomics per touched bin instead of one per pixel (6x fewer for dense depth).
+constexpr int TILE_W = 64, TILE_H = 16;            // 1024 pixels, 256 threads x 4
+constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
+
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
-    dfu3d_bin_geom g, int W, int HW, int key_axis, int64_t E_view, void *table,
-    int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
-    uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf,
-    uint32_t *__restrict__ status) {
+    dfu3d_bin_geom g, double inv_t, double inv_p, int W, int H, int tiles_x, int key_axis,
+    int64_t E_view, void *table, int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
+    uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf, uint32_t *__restrict__ amb_list,
+    int *__restrict__ n_amb) {
+  __shared__ uint32_t s_amb[PBLK];
+  __shared__ unsigned long long s_kmin[WIN_T * WIN_P];
+  __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
+  __shared__ int s_namb, s_base, s_t0, s_p0;
   const int v = blockIdx.y;
+  const int HW = H * W;
   const ViewCalib c = calib[v];
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
-  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
-  if (base >= HW) return;
-  const float *dv = depth + (size_t)v * HW;
-  float d[PPT];
-  load4(dv, base, HW, d);
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int row = ty * TILE_H + (threadIdx.x >> 4);
+  const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
+  if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
+  for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
+  __syncthreads();
   uint32_t bins[PPT];
-  bool rerr = false;
+  double keys[PPT];
+  const bool inside = (row < H) && (col < W);
+  const int base = row * W + col;
+  if (inside) {
+    const float *dv = depth + (size_t)v * HW;
+    float d[PPT];
+    load4(dv + (size_t)row * W, col, W, d);
+    int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
 #pragma unroll
-  for (int k = 0; k < PPT; k++) {
-    bins[k] = NOBIN;
-    const int pix = base + k;
-    if (pix < HW) {
-      double key;
-      const uint32_t b = pixel_bin(c, g, W, pix, d[k], key_axis, key, rerr);
-      bins[k] = b;
-      if (b != NOBIN) {
+    for (int k = 0; k < PPT; k++) {
+      bins[k] = NOBIN;
+      keys[k] = 0.0;
+      if (col + k < W) {
+        const uint32_t b = pixel_bin_fast(c, g, inv_t, inv_p, W, base + k, d[k], key_axis, keys[k]);
+        if (b == AMBIG) {
+          s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
+        } else {
+          bins[k] = b;
+          if (b != NOBIN) { tmin = min(tmin, (int)(b / (uint32_t)g.p_n)); pmin = min(pmin, (int)(b % (uint32_t)g.p_n)); }
+        }
+      }
+    }
+    if (tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
+    if (col + PPT <= W) {
+      *(uint4 *)(pix_bin + (size_t)v * HW + base) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
+    } else {
+      for (int k = 0; k < PPT; k++)
+        if (col + k < W) pix_bin[(size_t)v * HW + base + k] = bins[k];
+    }
+  }
+  __syncthreads();
+  const int t0 = s_t0, p0 = s_p0;
+  if (inside) {
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const uint32_t b = bins[k];
+      if (b == NOBIN) continue;
+      const int lt = (int)(b / (uint32_t)g.p_n) - t0, lp = (int)(b % (uint32_t)g.p_n) - p0;
+      if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
+        const int w = lt * WIN_P + lp;
+        atomicAdd(&s_cnt[w], 1u);
+        atomicMin(&s_first[w], (uint32_t)(base + k));
+        atomicMin(&s_kmin[w], ordered_key(keys[k]));
+      } else {                                                    // outside the window: direct
         const int64_t e = tb0 + b;
         const uint32_t old = atomicAdd(&T.cnt[e], 1u);
-        atomicMin(&T.first[e], (uint32_t)pix);
-        atomicMin(&T.kmin[e], ordered_key(key));
-        if (old == (uint32_t)g.max_points_per_voxel) {   // the (cap+1)-th arrival
+        atomicMin(&T.first[e], (uint32_t)(base + k));
+        atomicMin(&T.kmin[e], ordered_key(keys[k]));
+        if (old == (uint32_t)g.max_points_per_voxel) {
           const int slot = atomicAdd(&n_ovf[v], 1);
           if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
         }
       }
     }
   }
-  if (base + PPT <= HW) {
-    *(uint4 *)(pix_bin + (size_t)v * HW + base) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
-  } else {
-    for (int k = 0; k < PPT; k++)
-      if (base + k < HW) pix_bin[(size_t)v * HW + base + k] = bins[k];
+  __syncthreads();
+  // flush the window: one set of global atomics per touched bin
+  for (int w = threadIdx.x; w < WIN_T * WIN_P; w += PB) {
+    const uint32_t cw = s_cnt[w];
+    if (cw == 0u) continue;
+    const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
+    const int64_t e = tb0 + b;
+    const uint32_t old = atomicAdd(&T.cnt[e], cw);
+    atomicMin(&T.first[e], s_first[w]);
+    atomicMin(&T.kmin[e], s_kmin[w]);
+    const uint32_t mx = (uint32_t)g.max_points_per_voxel;
+    if (old <= mx && old + cw > mx) {                             // this add crossed the cap
+      const int slot = atomicAdd(&n_ovf[v], 1);
+      if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
+    }
+  }
+  const int na = s_namb;
+  if (na == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
+  __syncthreads();
+  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + s_base + i] = s_amb[i];
+}
+
+// Tier 2: the undecided pixels, full fp64 classification (pixel_bin).
+__global__ __launch_bounds__(256) void k_bp_bin_amb(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
+    int HW, int key_axis, int64_t E_view, void *table, int64_t E_total,
+    uint32_t *__restrict__ pix_bin, int cap_ovf, uint32_t *__restrict__ ovf_bins,
+    int *__restrict__ n_ovf, const uint32_t *__restrict__ amb_list, const int *__restrict__ n_amb,
+    uint32_t *__restrict__ status) {
+  const int v = blockIdx.y;
+  const int na = n_amb[v];
+  const ViewCalib c = calib[v];
+  const Table T = table_view(table, E_total);
+  const int64_t tb0 = (int64_t)v * E_view;
+  bool rerr = false;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < na; e += gridDim.x * 256) {
+    const int pix = (int)amb_list[(size_t)v * HW + e];
+    double key;
+    const uint32_t b = pixel_bin(c, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
+    pix_bin[(size_t)v * HW + pix] = b;
+    if (b != NOBIN)
+      commit_pixel(T, tb0 + b, pix, key, b, v, g.max_points_per_voxel, cap_ovf, ovf_bins, n_ovf);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -451,7 +598,7 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 
 // Scratch carve-up of blk_cnt (int32):
 //   [0, V*(nblk+1))                       block counts / offsets
-//   then n_ovf[V], ovf_cursor[V], ovf_cnt[V*cap_ovf], ovf_bins[V*cap_ovf]
+//   then n_ovf[V], ovf_cursor[V], n_amb[V], ovf_cnt[V*cap_ovf], ovf_bins[V*cap_ovf]
 // and of pix_bin (uint32): [0, V*HW) bin ids, [V*HW, 2*V*HW) overflow pixel
 // lists, [2*V*HW, 2*V*HW + V*cap_vox) voxel bin list.
 extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
@@ -462,7 +609,7 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   const int64_t nblk = (HW + PBLK - 1) / PBLK;
   const int64_t cap_ovf = HW / (max_points + 1) + 1;
   if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
-  if (blk_words) *blk_words = V * (nblk + 1) + 2 * (int64_t)V + 2 * V * cap_ovf;
+  if (blk_words) *blk_words = V * (nblk + 1) + 3 * (int64_t)V + 2 * V * cap_ovf;
   return 0;
 }
 
@@ -481,6 +628,7 @@ extern "C" int dfu3d_backproject_bin(
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
   const int64_t HW64 = (int64_t)H * W;
   if (HW64 >= (1ll << 24)) return DFU3D_ERANGE;     // 24-bit pixel radix select
+  if (W % 4) return DFU3D_EINVAL;                    // float4 row loads
   if (geom->max_points_per_voxel < 1) return DFU3D_EINVAL;
   const int HW = (int)HW64;
   const int nblk = (HW + PBLK - 1) / PBLK;
@@ -490,17 +638,25 @@ extern "C" int dfu3d_backproject_bin(
   hipStream_t st = (hipStream_t)stream;
   int *n_ovf = blk_cnt + (size_t)V * (nblk + 1);
   int *ovf_cursor = n_ovf + V;
-  int *ovf_cnt = ovf_cursor + V;
+  int *n_amb = ovf_cursor + V;
+  int *ovf_cnt = n_amb + V;
   uint32_t *ovf_bins = (uint32_t *)(ovf_cnt + (size_t)V * cap_ovf);
   uint32_t *ovf_list = pix_bin + (size_t)V * HW;
   uint32_t *vox_bin = pix_bin + 2 * (size_t)V * HW;
   const ViewCalib *cal = (const ViewCalib *)calib;
 
   if (phases & DFU3D_BP_BIN) {
-  if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 2 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_bp_bin, dim3(nblk, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
+  // n_ovf | ovf_cursor | n_amb  (3 x V ints); the undecided-pixel lists share the
+  // overflow pixel-list plane (consumed before k_ovf_gather fills it)
+  if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 3 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
+                     1.0 / geom->vsize_t, 1.0 / geom->vsize_p, W, H, tiles_x, key_axis, E_view,
+                     table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf, ovf_list, n_amb);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
                      key_axis, E_view, table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf,
-                     status);
+                     ovf_list, n_amb, status);
   DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {

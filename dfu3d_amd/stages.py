@@ -164,8 +164,8 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
         raise Dfu3dError("table: must be 8-byte aligned")
     if pix_bin.data_ptr() % 16 or depth.data_ptr() % 16:
         raise Dfu3dError("depth / pix_bin: must be 16-byte aligned")
-    if (H * W) % 4:
-        raise Dfu3dError("H*W must be a multiple of 4 (float4 depth loads)")
+    if W % 4:
+        raise Dfu3dError("W must be a multiple of 4 (float4 depth loads)")
     mp = _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W) if masks is not None else None
     ni = _chk(n_inst, "n_inst", torch.int32, numel=V) if n_inst is not None else None
     rc = _lib.lib().dfu3d_backproject_bin(
