@@ -43,7 +43,26 @@ def build_batch(frames, seed0, device, dense, k_boxes):
     return scenes
 
 
-def cpu_baseline(scenes_cpu, params, dense, max_seconds=25.0):
+PMC_NAMES = {"bp_bin": "k_bp_bin", "bp_rep": "k_bp_rep", "bp_emit": "k_bp_emit", "rf_flags": "k_radius_flags",
+             "fov_filter": "k_fov_filter", "project_label": "k_project_rows"}
+
+
+def pmc_traffic(kernel, views_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), scaled
+    linearly when this run's launch covers a different number of views; None if unknown."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        k = pm["kernels"][PMC_NAMES[kernel]]
+        if k["fetch_bytes"] is None or k["write_bytes"] is None:
+            return None
+        return int((k["fetch_bytes"] + k["write_bytes"]) * views_per_launch / pm["views_per_launch"])
+    except Exception:
+        return None
+
+
+def cpu_baseline(scenes_cpu, params, dense, max_seconds=18.0):
     """The oracle (NumPy + C restatement, single thread) on a bounded sample of
     the same workload, on this box's host cores."""
     from oracle import penet_oracle as O
@@ -71,8 +90,8 @@ def cpu_baseline(scenes_cpu, params, dense, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--chunk-frames", type=int, default=16, help="frames per kernel-launch chunk")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent HIP streams (one chunk each)")
@@ -104,7 +123,7 @@ def main():
     batch = synth.to_view_batch(scenes, params, dev, dense=dense)
     cpu_scenes = None
     if rank == 0 and not args.no_cpu_baseline:
-        keep = scenes[:4]
+        keep = scenes[:10]
         cpu_scenes = [synth.Scene(s.points.cpu(), s.calibs, s.depth.cpu(), s.masks.cpu(), s.n_inst,
                                   s.inst_class, s.inst_box, s.inst_score, s.boxes3d) for s in keep]
     del scenes
@@ -186,7 +205,8 @@ def main():
             if dom is not None:
                 out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5), "traffic": None}
+                                   "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
+                                   "traffic": pmc_traffic(dom["kernel"], views_per_launch)}
             rf = next((r for r in table if r["kernel"] == "rf_flags"), None)
             if rf is not None:
                 out["radius_filter_roofline"] = {"achieved": rf["achieved_GBs"], "peak": HBM_PEAK_GBS,
