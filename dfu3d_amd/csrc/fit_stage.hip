@@ -425,6 +425,68 @@ __device__ __forceinline__ void cross_point(double a0, double a1, double b0, dou
   y = (a1 * -c0 - a0 * -c1) / (a0 * b1 - a1 * b0);
 }
 
+// rectangle (best heading + extents) -> KITTI box row (my_loader.py:633-702); one thread
+__device__ void emit_box(double thb, double sin_s, double cos_s, double c1min, double c1max,
+                         double c2min, double c2max, double zmax, int s, int v, int jinst, int kc,
+                         int root, int m, const ViewCalib *calib, const int *inst_class,
+                         const int *inst_is_car, const float *inst_box, const float *inst_score,
+                         double car_aspect_max, int cap_rows, double *rows, int *n_rows,
+                         uint32_t *status) {
+  const double a[4] = {cos_s, -sin_s, cos_s, -sin_s};
+  const double b[4] = {sin_s, cos_s, sin_s, cos_s};
+  const double c[4] = {c1min, c2min, c1max, c2max};
+  double cx[4], cy[4];                         // my_loader.py:686-697
+  cross_point(a[0], a[1], b[0], b[1], c[0], c[1], cx[0], cy[0]);
+  cross_point(a[1], a[2], b[1], b[2], c[1], c[2], cx[1], cy[1]);
+  cross_point(a[2], a[3], b[2], b[3], c[2], c[3], cx[2], cy[2]);
+  cross_point(a[3], a[0], b[3], b[0], c[3], c[0], cx[3], cy[3]);
+  double center_x = (cx[0] + cx[2]) / 2.0;
+  double center_y = (cy[0] + cy[2]) / 2.0;
+  const double center_z = zmax / 2.0 - 1.5;
+  const double height = zmax;
+  const double e03x = cx[0] - cx[3], e03y = cy[0] - cy[3];
+  const double e01x = cx[0] - cx[1], e01y = cy[0] - cy[1];
+  const double l1 = sqrt(e03x * e03x + e03y * e03y);
+  const double l2 = sqrt(e01x * e01x + e01y * e01y);
+  bool skip = false;
+  if (inst_is_car[s] && (l1 / l2 > car_aspect_max || l2 / l1 > car_aspect_max)) skip = true;
+  double length = 0.0, width = 0.0, rotation = 0.0;
+  if (l1 >= l2) {
+    length = l1; width = l2;
+    rotation = atan((cy[3] - cy[0]) / (cx[3] - cx[0] + 1e-8));
+  } else if (l1 < l2) {
+    length = l2; width = l1;
+    rotation = atan((cy[1] - cy[0]) / (cx[1] - cx[0] + 1e-8));
+  } else {
+    skip = true;                               // NaN extents
+  }
+  if (!skip) {
+    const double kPi = 3.141592653589793;
+    rotation = -rotation - kPi / 2.0;
+    const double theta = atan(-center_x / (center_y + 1e-8));
+    const double alpha = rotation - theta;
+    const float *M = calib[v].M43;             // calibration_kitti.py:104-112 (fp64 in)
+    const double rx = ((center_x * (double)M[0] + center_y * (double)M[3]) + center_z * (double)M[6]) + (double)M[9];
+    const double ry = ((center_x * (double)M[1] + center_y * (double)M[4]) + center_z * (double)M[7]) + (double)M[10];
+    const double rz = ((center_x * (double)M[2] + center_y * (double)M[5]) + center_z * (double)M[8]) + (double)M[11];
+    const int slot = atomicAdd(n_rows, 1);
+    if (slot < cap_rows) {
+      double *o = rows + (size_t)slot * DFU3D_ROW_DOUBLES;
+      o[0] = (double)v; o[1] = (double)jinst; o[2] = (double)kc;
+      o[3] = (double)inst_class[s]; o[4] = alpha;
+      o[5] = (double)inst_box[s * 4 + 0]; o[6] = (double)inst_box[s * 4 + 1];
+      o[7] = (double)inst_box[s * 4 + 2]; o[8] = (double)inst_box[s * 4 + 3];
+      o[9] = height; o[10] = width; o[11] = length;
+      o[12] = rx; o[13] = ry; o[14] = rz; o[15] = rotation;
+      o[16] = (double)inst_score[s]; o[17] = (double)m;
+      o[18] = thb; o[19] = c1min; o[20] = c2min; o[21] = c1max; o[22] = c2max;
+      o[23] = (double)root;
+    } else {
+      atomicOr(status, DFU3D_ST_ROW_OVERFLOW);
+    }
+  }
+}
+
 __global__ __launch_bounds__(FT) void k_lshape_fit(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const int *__restrict__ label,
@@ -433,10 +495,10 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
     const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
     const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
     double *__restrict__ gsx, double *__restrict__ gsy, int *__restrict__ sroot, int cap_rows,
-    double *__restrict__ rows, int *__restrict__ n_rows, uint32_t *__restrict__ status) {
+    double *__restrict__ rows, int *__restrict__ n_rows, uint32_t *__restrict__ status,
+    double *__restrict__ fit_ws, int cap_big) {
   __shared__ double lx[LDS_MEMBERS], ly[LDS_MEMBERS];
   __shared__ double s_cost[MAXTH], s_ct[MAXTH + TB], s_st[MAXTH + TB];
-  __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
   __shared__ double s_red[FW];
   __shared__ double s_ext[FW][4];
   __shared__ int s_w[FW];
@@ -475,6 +537,7 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
   }
   __syncthreads();
 
+  long long goff = 0;                     // members of cluster kc live at gsx/gsy[base + goff ...]
   for (int kc = 0; kc < nroots; kc++) {
     const int root = sroot[base + kc];
     // gather the cluster's members in index order
@@ -487,18 +550,31 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
       if (f) {
         const int d = m + r;
         const double x = px[base + i], y = py[base + i];
-        gsx[base + d] = x;
-        gsy[base + d] = y;
+        gsx[base + goff + d] = x;
+        gsy[base + goff + d] = y;
         if (d < LDS_MEMBERS) { lx[d] = x; ly[d] = y; }
       }
       m += tot;
     }
     __syncthreads();
-    const bool in_lds = m <= LDS_MEMBERS;
-    const double *mx = in_lds ? lx : gsx + base;
-    const double *my = in_lds ? ly : gsy + base;
-
-    if (in_lds) {
+    if (m > LDS_MEMBERS) {
+      // large cluster: hand it to the chip-wide kernels (k_fit_big_cost / k_fit_big_box)
+      if (threadIdx.x == 0) {
+        const int c = atomicAdd((int *)fit_ws, 1);
+        if (c < cap_big) {
+          double *dsc = fit_ws + 2 + (size_t)c * 8;
+          dsc[0] = (double)s; dsc[1] = (double)kc; dsc[2] = (double)root; dsc[3] = (double)m;
+          dsc[4] = (double)(base + goff); dsc[5] = zmax;
+        }
+      }
+      goff += m;
+      __syncthreads();
+      continue;
+    }
+    goff += m;
+    const double *mx = lx;
+    const double *my = ly;
+    {
     // 89 headings, one wave each (rectangle_fitting.py:119-136)
     for (int th = wave; th < n_theta; th += FW) {
       const double ct = s_ct[th], st = s_st[th];
@@ -542,103 +618,6 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
       if (n2) V2 = -(q2 / (double)n2);
       if (lane == 0) s_cost[th] = V1 + V2;
     }
-    } else {
-    // Large cluster: all 512 threads split the POINTS; TB headings per sweep
-    // keep their running extents / sums in registers (3 sweeps per batch instead
-    // of 3 sweeps per heading over the member list in L2).
-    for (int tb = 0; tb < n_theta; tb += TB) {
-      const int nt = min(TB, n_theta - tb);
-      double acc[4 * TB];
-#pragma unroll
-      for (int t = 0; t < TB; t++) { acc[4 * t] = INFINITY; acc[4 * t + 1] = -INFINITY; acc[4 * t + 2] = INFINITY; acc[4 * t + 3] = -INFINITY; }
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[tb + t], st = s_st[tb + t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          acc[4 * t] = fmin(acc[4 * t], c1); acc[4 * t + 1] = fmax(acc[4 * t + 1], c1);
-          acc[4 * t + 2] = fmin(acc[4 * t + 2], c2); acc[4 * t + 3] = fmax(acc[4 * t + 3], c2);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) {
-        const double r = (k & 1) ? wave_red<OpMax>(acc[k]) : wave_red<OpMin>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < 4 * TB) {
-        const int k = threadIdx.x;
-        double r = s_part[0][k];
-        for (int w = 1; w < FW; w++) r = (k & 1) ? fmax(r, s_part[w][k]) : fmin(r, s_part[w][k]);
-        s_bext[k] = r;
-      }
-      __syncthreads();
-      // sums and counts of E1 / E2
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) acc[k] = 0.0;
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[tb + t], st = s_st[tb + t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
-          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
-          if (d1 < d2) { acc[4 * t] += d1; acc[4 * t + 1] += 1.0; }
-          else { acc[4 * t + 2] += d2; acc[4 * t + 3] += 1.0; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) {
-        const double r = wave_red<OpSum>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < 4 * TB) {
-        const int k = threadIdx.x;
-        double r = s_part[0][k];
-        for (int w = 1; w < FW; w++) r += s_part[w][k];
-        s_bsum[k] = r;
-      }
-      __syncthreads();
-      // squared deviations from the means
-#pragma unroll
-      for (int k = 0; k < 2 * TB; k++) acc[k] = 0.0;
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[tb + t], st = s_st[tb + t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
-          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
-          const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
-          if (d1 < d2) { const double u = d1 - (n1 > 0.0 ? s_bsum[4 * t] / n1 : 0.0); acc[2 * t] += u * u; }
-          else { const double u = d2 - (n2 > 0.0 ? s_bsum[4 * t + 2] / n2 : 0.0); acc[2 * t + 1] += u * u; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2 * TB; k++) {
-        const double r = wave_red<OpSum>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < nt) {
-        const int t = threadIdx.x;
-        double q1 = s_part[0][2 * t], q2 = s_part[0][2 * t + 1];
-        for (int w = 1; w < FW; w++) { q1 += s_part[w][2 * t]; q2 += s_part[w][2 * t + 1]; }
-        const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
-        double V1 = 0.0, V2 = 0.0;
-        if (n1 > 0.0) V1 = -(q1 / n1);
-        if (n2 > 0.0) V2 = -(q2 / n2);
-        s_cost[tb + t] = V1 + V2;
-      }
-      __syncthreads();
-    }
     }
     __syncthreads();
     // first strict maximum (rectangle_fitting.py:135-136)
@@ -675,61 +654,178 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
         c1min = fmin(c1min, s_ext[w][0]); c1max = fmax(c1max, s_ext[w][1]);
         c2min = fmin(c2min, s_ext[w][2]); c2max = fmax(c2max, s_ext[w][3]);
       }
-      const double a[4] = {cos_s, -sin_s, cos_s, -sin_s};
-      const double b[4] = {sin_s, cos_s, sin_s, cos_s};
-      const double c[4] = {c1min, c2min, c1max, c2max};
-      double cx[4], cy[4];                         // my_loader.py:686-697
-      cross_point(a[0], a[1], b[0], b[1], c[0], c[1], cx[0], cy[0]);
-      cross_point(a[1], a[2], b[1], b[2], c[1], c[2], cx[1], cy[1]);
-      cross_point(a[2], a[3], b[2], b[3], c[2], c[3], cx[2], cy[2]);
-      cross_point(a[3], a[0], b[3], b[0], c[3], c[0], cx[3], cy[3]);
-      double center_x = (cx[0] + cx[2]) / 2.0;
-      double center_y = (cy[0] + cy[2]) / 2.0;
-      const double center_z = zmax / 2.0 - 1.5;
-      const double height = zmax;
-      const double e03x = cx[0] - cx[3], e03y = cy[0] - cy[3];
-      const double e01x = cx[0] - cx[1], e01y = cy[0] - cy[1];
-      const double l1 = sqrt(e03x * e03x + e03y * e03y);
-      const double l2 = sqrt(e01x * e01x + e01y * e01y);
-      bool skip = false;
-      if (inst_is_car[s] && (l1 / l2 > car_aspect_max || l2 / l1 > car_aspect_max)) skip = true;
-      double length = 0.0, width = 0.0, rotation = 0.0;
-      if (l1 >= l2) {
-        length = l1; width = l2;
-        rotation = atan((cy[3] - cy[0]) / (cx[3] - cx[0] + 1e-8));
-      } else if (l1 < l2) {
-        length = l2; width = l1;
-        rotation = atan((cy[1] - cy[0]) / (cx[1] - cx[0] + 1e-8));
-      } else {
-        skip = true;                               // NaN extents
-      }
-      if (!skip) {
-        const double kPi = 3.141592653589793;
-        rotation = -rotation - kPi / 2.0;
-        const double theta = atan(-center_x / (center_y + 1e-8));
-        const double alpha = rotation - theta;
-        const float *M = calib[v].M43;             // calibration_kitti.py:104-112 (fp64 in)
-        const double rx = ((center_x * (double)M[0] + center_y * (double)M[3]) + center_z * (double)M[6]) + (double)M[9];
-        const double ry = ((center_x * (double)M[1] + center_y * (double)M[4]) + center_z * (double)M[7]) + (double)M[10];
-        const double rz = ((center_x * (double)M[2] + center_y * (double)M[5]) + center_z * (double)M[8]) + (double)M[11];
-        const int slot = atomicAdd(n_rows, 1);
-        if (slot < cap_rows) {
-          double *o = rows + (size_t)slot * DFU3D_ROW_DOUBLES;
-          o[0] = (double)v; o[1] = (double)jinst; o[2] = (double)kc;
-          o[3] = (double)inst_class[s]; o[4] = alpha;
-          o[5] = (double)inst_box[s * 4 + 0]; o[6] = (double)inst_box[s * 4 + 1];
-          o[7] = (double)inst_box[s * 4 + 2]; o[8] = (double)inst_box[s * 4 + 3];
-          o[9] = height; o[10] = width; o[11] = length;
-          o[12] = rx; o[13] = ry; o[14] = rz; o[15] = rotation;
-          o[16] = (double)inst_score[s]; o[17] = (double)m;
-          o[18] = thb; o[19] = c1min; o[20] = c2min; o[21] = c1max; o[22] = c2max;
-          o[23] = (double)root;
-        } else {
-          atomicOr(status, DFU3D_ST_ROW_OVERFLOW);
-        }
-      }
+      emit_box(thb, sin_s, cos_s, c1min, c1max, c2min, c2max, zmax, s, v, jinst, kc, root, m, calib,
+               inst_class, inst_is_car, inst_box, inst_score, car_aspect_max, cap_rows, rows,
+               n_rows, status);
     }
     __syncthreads();
+  }
+}
+
+// ---- large clusters: (cluster, heading batch) workgroups over the whole chip ----
+__global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ gsx,
+                                                     const double *__restrict__ gsy, int n_theta,
+                                                     double dtheta, int nb, double *__restrict__ fit_ws,
+                                                     int cap_big) {
+  __shared__ double s_ct[TB], s_st[TB];
+  __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
+  const int nbig = min(*(const int *)fit_ws, cap_big);
+  const int c = blockIdx.x / nb;
+  const int tb = (blockIdx.x - c * nb) * TB;
+  if (c >= nbig || tb >= n_theta) return;
+  const double *dsc = fit_ws + 2 + (size_t)c * 8;
+  const int m = (int)dsc[3];
+  const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
+  double *s_cost = fit_ws + 2 + (size_t)cap_big * 8 + (size_t)c * MAXTH;        // heading costs of cluster c
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  if (threadIdx.x < TB) {
+    const double theta = (double)(tb + threadIdx.x) * dtheta;
+    s_ct[threadIdx.x] = cos(theta);
+    s_st[threadIdx.x] = sin(theta);
+  }
+  __syncthreads();
+  {
+      const int nt = min(TB, n_theta - tb);
+      double acc[4 * TB];
+#pragma unroll
+      for (int t = 0; t < TB; t++) { acc[4 * t] = INFINITY; acc[4 * t + 1] = -INFINITY; acc[4 * t + 2] = INFINITY; acc[4 * t + 3] = -INFINITY; }
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[t], st = s_st[t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          acc[4 * t] = fmin(acc[4 * t], c1); acc[4 * t + 1] = fmax(acc[4 * t + 1], c1);
+          acc[4 * t + 2] = fmin(acc[4 * t + 2], c2); acc[4 * t + 3] = fmax(acc[4 * t + 3], c2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) {
+        const double r = (k & 1) ? wave_red<OpMax>(acc[k]) : wave_red<OpMin>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4 * TB) {
+        const int k = threadIdx.x;
+        double r = s_part[0][k];
+        for (int w = 1; w < FW; w++) r = (k & 1) ? fmax(r, s_part[w][k]) : fmin(r, s_part[w][k]);
+        s_bext[k] = r;
+      }
+      __syncthreads();
+      // sums and counts of E1 / E2
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) acc[k] = 0.0;
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[t], st = s_st[t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
+          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
+          if (d1 < d2) { acc[4 * t] += d1; acc[4 * t + 1] += 1.0; }
+          else { acc[4 * t + 2] += d2; acc[4 * t + 3] += 1.0; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * TB; k++) {
+        const double r = wave_red<OpSum>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4 * TB) {
+        const int k = threadIdx.x;
+        double r = s_part[0][k];
+        for (int w = 1; w < FW; w++) r += s_part[w][k];
+        s_bsum[k] = r;
+      }
+      __syncthreads();
+      // squared deviations from the means
+#pragma unroll
+      for (int k = 0; k < 2 * TB; k++) acc[k] = 0.0;
+      for (int i = threadIdx.x; i < m; i += FT) {
+        const double x = mx[i], y = my[i];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const double ct = s_ct[t], st = s_st[t];
+          const double c1 = x * ct + y * st;
+          const double c2 = x * (-st) + y * ct;
+          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
+          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
+          const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
+          if (d1 < d2) { const double u = d1 - (n1 > 0.0 ? s_bsum[4 * t] / n1 : 0.0); acc[2 * t] += u * u; }
+          else { const double u = d2 - (n2 > 0.0 ? s_bsum[4 * t + 2] / n2 : 0.0); acc[2 * t + 1] += u * u; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2 * TB; k++) {
+        const double r = wave_red<OpSum>(acc[k]);
+        if (lane == 0) s_part[wave][k] = r;
+      }
+      __syncthreads();
+      if (threadIdx.x < nt) {
+        const int t = threadIdx.x;
+        double q1 = s_part[0][2 * t], q2 = s_part[0][2 * t + 1];
+        for (int w = 1; w < FW; w++) { q1 += s_part[w][2 * t]; q2 += s_part[w][2 * t + 1]; }
+        const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
+        double V1 = 0.0, V2 = 0.0;
+        if (n1 > 0.0) V1 = -(q1 / n1);
+        if (n2 > 0.0) V2 = -(q2 / n2);
+        s_cost[tb + t] = V1 + V2;
+      }
+      __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(FT) void k_fit_big_box(
+    const double *__restrict__ gsx, const double *__restrict__ gsy, int max_inst,
+    const ViewCalib *__restrict__ calib, const int *__restrict__ inst_class,
+    const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
+    const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
+    int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
+    uint32_t *__restrict__ status, const double *__restrict__ fit_ws, int cap_big) {
+  __shared__ double s_ext[FW][4];
+  const int nbig = min(*(const int *)fit_ws, cap_big);
+  const int c = blockIdx.x;
+  if (c >= nbig) return;
+  const double *dsc = fit_ws + 2 + (size_t)c * 8;
+  const int s = (int)dsc[0], kc = (int)dsc[1], root = (int)dsc[2], m = (int)dsc[3];
+  const double zmax = dsc[5];
+  const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
+  const double *cost = fit_ws + 2 + (size_t)cap_big * 8 + (size_t)c * MAXTH;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  int best = 0;
+  double bc = -INFINITY;
+  for (int th = 0; th < n_theta; th++) {          // first strict maximum (rectangle_fitting.py:135-136)
+    const double cc = cost[th];
+    if (bc < cc) { bc = cc; best = th; }
+  }
+  const double thb = (double)best * dtheta;
+  const double sin_s = sin(thb), cos_s = cos(thb);
+  double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+  for (int i = threadIdx.x; i < m; i += FT) {
+    const double x = mx[i], y = my[i];
+    const double c1 = x * cos_s + y * sin_s;
+    const double c2 = x * (-sin_s) + y * cos_s;
+    a0 = fmin(a0, c1); a1 = fmax(a1, c1);
+    b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+  }
+  a0 = wave_min_d(a0); a1 = wave_max_d(a1);
+  b0 = wave_min_d(b0); b1 = wave_max_d(b1);
+  if (lane == 0) { s_ext[wave][0] = a0; s_ext[wave][1] = a1; s_ext[wave][2] = b0; s_ext[wave][3] = b1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c1min = s_ext[0][0], c1max = s_ext[0][1], c2min = s_ext[0][2], c2max = s_ext[0][3];
+    for (int w = 1; w < FW; w++) {
+      c1min = fmin(c1min, s_ext[w][0]); c1max = fmax(c1max, s_ext[w][1]);
+      c2min = fmin(c2min, s_ext[w][2]); c2max = fmax(c2max, s_ext[w][3]);
+    }
+    const int v = s / max_inst, jinst = s - v * max_inst;
+    emit_box(thb, sin_s, cos_s, c1min, c1max, c2min, c2max, zmax, s, v, jinst, kc, root, m, calib,
+             inst_class, inst_is_car, inst_box, inst_score, car_aspect_max, cap_rows, rows, n_rows,
+             status);
   }
 }
 
@@ -754,6 +850,12 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   return DFU3D_OK;
 }
 
+extern "C" int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap) {
+  if (pool_cap <= 0) return DFU3D_EINVAL;
+  const int64_t cap_big = pool_cap / LDS_MEMBERS + 1;
+  return 2 + cap_big * (8 + MAXTH);
+}
+
 extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
                                 const int32_t *label, const int64_t *seg_base,
                                 const int32_t *seg_cnt, int32_t S, int32_t max_inst,
@@ -762,17 +864,30 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
                                 const float *inst_score, int32_t n_theta, double dtheta,
                                 double car_aspect_max, double *sx, double *sy, int32_t *sroot,
                                 int32_t cap_rows, double *rows, int32_t *n_rows,
-                                uint32_t *status, void *stream) {
+                                uint32_t *status, double *fit_ws, int64_t pool_cap,
+                                void *stream) {
   if (!px || !py || !pz || !label || !seg_base || !seg_cnt || !calib || !inst_class ||
       !inst_is_car || !inst_box || !inst_score || !sx || !sy || !sroot || !rows || !n_rows ||
-      !status)
+      !status || !fit_ws)
     return DFU3D_EINVAL;
-  if (S <= 0 || max_inst <= 0 || cap_rows <= 0 || n_theta <= 0) return DFU3D_EINVAL;
+  if (S <= 0 || max_inst <= 0 || cap_rows <= 0 || n_theta <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
   if (n_theta > MAXTH) return DFU3D_ERANGE;
-  hipLaunchKernelGGL(k_lshape_fit, dim3(S), dim3(FT), 0, (hipStream_t)stream, px, py, pz, label,
+  hipStream_t st = (hipStream_t)stream;
+  const int cap_big = (int)(pool_cap / LDS_MEMBERS + 1);
+  if (hipMemsetAsync(fit_ws, 0, 16, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_lshape_fit, dim3(S), dim3(FT), 0, st, px, py, pz, label,
                      (const long long *)seg_base, seg_cnt, max_inst, (const ViewCalib *)calib,
                      inst_class, inst_is_car, inst_box, inst_score, n_theta, dtheta,
-                     car_aspect_max, sx, sy, sroot, cap_rows, rows, n_rows, status);
+                     car_aspect_max, sx, sy, sroot, cap_rows, rows, n_rows, status, fit_ws, cap_big);
+  DFU3D_LAUNCH_CHECK();
+  const int nb = (n_theta + TB - 1) / TB;
+  hipLaunchKernelGGL(k_fit_big_cost, dim3(cap_big * nb), dim3(FT), 0, st, sx, sy, n_theta, dtheta,
+                     nb, fit_ws, cap_big);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_fit_big_box, dim3(cap_big), dim3(FT), 0, st, sx, sy, max_inst,
+                     (const ViewCalib *)calib, inst_class, inst_is_car, inst_box, inst_score,
+                     n_theta, dtheta, car_aspect_max, cap_rows, rows, n_rows, status, fit_ws,
+                     cap_big);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }

@@ -111,6 +111,7 @@ class PseudoBoxEngine:
             L.sx, L.sy = f64(pc), f64(pc)
             L.label, L.sroot = i32(pc), i32(pc)
             L.si3 = i32(3 * pc)
+            L.fit_ws = f64(int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(pc)))
             L.flags = torch.empty(pc, dtype=torch.uint8, device=d)
             L.mean_d = f64(pc) if self.p.stat_filter else None
             L.base_a = torch.empty(S, dtype=torch.int64, device=d)
@@ -235,7 +236,7 @@ class PseudoBoxEngine:
                       calib, b.inst_class[v0:v1].reshape(-1), b.inst_is_car[v0:v1].reshape(-1),
                       b.inst_box[v0:v1].reshape(-1), b.inst_score[v0:v1].reshape(-1),
                       self.n_theta, self.dtheta, p.car_aspect_max, self.sx, self.sy, self.sroot,
-                      self.cap_rows, rows, n_rows, status, self.pool_cap)
+                      self.cap_rows, rows, n_rows, status, self.pool_cap, self.fit_ws)
 
     # ------------------------------------------------------------------
     def run(self, b: ViewBatch, sync: bool = True):

@@ -263,7 +263,10 @@ def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap, sx=None
 
 def lshape_fit(px, py, pz, label, seg_base, seg_cnt, S, max_inst, calib, inst_class,
                inst_is_car, inst_box, inst_score, n_theta, dtheta, car_aspect_max, sx, sy,
-               sroot, cap_rows, rows, n_rows, status, pool_cap):
+               sroot, cap_rows, rows, n_rows, status, pool_cap, fit_ws=None):
+    nws = int(_lib.lib().dfu3d_lshape_fit_ws_doubles(pool_cap))
+    if fit_ws is None:
+        fit_ws = torch.empty(nws, dtype=torch.float64, device=px.device)
     if S % max_inst:
         raise Dfu3dError("S must be V*max_inst")
     V = S // max_inst
@@ -283,7 +286,8 @@ def lshape_fit(px, py, pz, label, seg_base, seg_cnt, S, max_inst, calib, inst_cl
         _chk(sroot, "sroot", torch.int32, numel=pool_cap), cap_rows,
         _chk(rows, "rows", torch.float64, numel=cap_rows * ROW_DOUBLES),
         _chk(n_rows, "n_rows", torch.int32, numel=1),
-        _chk(status, "status", torch.int32, min_numel=1), _stream())
+        _chk(status, "status", torch.int32, min_numel=1),
+        _chk(fit_ws, "fit_ws", torch.float64, min_numel=nws), pool_cap, _stream())
     _lib.check(rc, "dfu3d_lshape_fit")
 
 
