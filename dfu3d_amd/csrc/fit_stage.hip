@@ -22,6 +22,8 @@ constexpr int BLK = 32;            // groups per block (1024 points): second pru
 constexpr int SMALL_N = 4096;      // segments up to this size: 32-bit parents, 20 KB of LDS
 constexpr int LARGE_N = 61440;     // up to this size: 16-bit parents in LDS (120 KB)
 constexpr int LARGE_GRP = LARGE_N / GRP;
+constexpr int GRID_NC_SMALL = 2048;   // grid path: cells kept in LDS (24 KB) ...
+constexpr int GRID_NC_LARGE = 12288;  // ... or 144 KB for wide instances
 
 // ---- parent-array accessors: 32-bit (LDS or global) and 16-bit (LDS only) ----
 struct ParI {
@@ -76,10 +78,18 @@ struct ParH {
   }
 };
 
+// find with path halving: every visited node is re-pointed at its grandparent.
+// Any ancestor is a valid parent, so the plain store is benign next to the
+// atomic links of uf_unite (a lost link is re-established by its retry loop).
 template <class P>
 __device__ __forceinline__ int uf_find(const P &par, int a) {
   int p = par.load(a);
-  while (p != a) { a = p; p = par.load(a); }
+  while (p != a) {
+    const int gp = par.load(p);
+    if (gp != p) par.flatten(a, gp);
+    a = p;
+    p = gp;
+  }
   return a;
 }
 // returns the root of the merged set as seen by this thread
@@ -111,6 +121,12 @@ __device__ __forceinline__ int uf_unite(const P &par, int a, int b) {
 //      or s > S_HI (sqrt(s) > every R); only the thin band in between evaluates
 //      the reference's sqrt expression (rectangle_fitting.py:167-170).
 // None of the prunes changes a decision, so the labels equal the reference's.
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+#define CT_STAMP(k) do { const long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
+#else
+#define CT_STAMP(k) do {} while (0)
+#endif
+
 template <class P, int NGRP>
 __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s_box,
                                              int *s_summ2, float4 *s_box2,
@@ -118,6 +134,11 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
                                              int n, double R0, double Rd, const int *perm,
                                              int *tmp, int *glabel) {
   constexpr int NBLK = (NGRP + BLK - 1) / BLK;
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+  long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks, descended, boxtests(max lane), slow groups, slow iters, unites(lane0), early exits, -
+  long long dbg_t = clock64();
+#endif
   const int ngrp_all = min((n + GRP - 1) / GRP, NGRP);
   double r2max = 0.0;
   for (int i = threadIdx.x; i < n; i += CT) {
@@ -154,10 +175,12 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
   const double S_HI = Rmax * Rmax * (1.0 + 1e-9);      // s > S_HI  => sqrt(s) > every R_i
   const double S_LO = R0 * R0 * (1.0 - 1e-12);         // s <= S_LO => sqrt(s) <= R0 <= R_i
 
+  CT_STAMP(0);
   for (int c0 = 0; c0 < n; c0 += CT) {
     // flatten + summarise everything before this chunk
     for (int k = threadIdx.x; k < c0; k += CT) par.flatten(k, uf_find(par, k));
     __syncthreads();
+    CT_STAMP(1);
     const int ngrp = min(c0 / GRP, NGRP);
     for (int g = threadIdx.x; g < ngrp; g += CT) s_summ[g] = par.group_root(g);
     __syncthreads();
@@ -169,6 +192,7 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
       s_summ2[B] = (r >= 0 && !diff) ? r : -1;
     }
     __syncthreads();
+    CT_STAMP(2);
     const int nblk_sum = ngrp / BLK;
     const int i = c0 + threadIdx.x;
     const bool act = i < n;
@@ -201,6 +225,9 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         }
       }
       if (!__any(need)) return;                                 // wave-uniform
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+      dbg_cnt[3]++;
+#endif
       // the wave fetches the group's 32 points once (one coalesced load each)
       const int jl = jg + (lane & (GRP - 1));
       const bool in = jl < n;
@@ -208,10 +235,23 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
       // cheap exit: every query of the wave that still needs this group sits in
       // one set and all 32 points already belong to it (own-chunk groups mostly)
       const int r_first = __shfl(ri, __ffsll((unsigned long long)__ballot(need)) - 1, 64);
-      if (__all(!need || ri == r_first) && __all(!in || pg == r_first)) return;
+      if (__all(!need || ri == r_first) && __all(!in || pg == r_first)) {
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+        dbg_cnt[6]++;
+#endif
+        return;
+      }
       const double xg = in ? X[jl] : 0.0, yg = in ? Y[jl] : 0.0;
-#pragma unroll 4
       for (int k = GRP - 1; k >= 0; k--) {
+        if ((k & 7) == 7 && k != GRP - 1) {
+          // every 8 points: once all queries that need this group have merged into
+          // the set that owns all of its points, the rest of the group is moot
+          const int rf = __shfl(ri, __ffsll((unsigned long long)__ballot(need)) - 1, 64);
+          if (__all(!need || ri == rf) && __all(!in || pg == rf)) break;
+        }
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+        dbg_cnt[4]++;
+#endif
         const int pj = __shfl(pg, k, 64);
         const double xj = __shfl(xg, k, 64), yj = __shfl(yg, k, 64);
         if (need && (jg + k < i) && pj != ri) {                 // (3) not in my set (yet)
@@ -224,12 +264,18 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
             const double d = sqrt(sq);                          // rectangle_fitting.py:169
             adj = (d <= Ri) || (d <= R0 + Rd * sqrt(xj * xj + yj * yj));
           }
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+          if (adj) dbg_cnt[5]++;
+#endif
           if (adj) ri = uf_unite(par, ri, jg + k);
         }
       }
     };
     for (int B = (gc + BLK - 1) / BLK - 1; B >= 0; B--) {
       const int g_lo = B * BLK, g_hi = min(g_lo + BLK, gc);
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+      dbg_cnt[0]++;
+#endif
       bool need2 = act;
       if (need2 && B < NBLK) {
         if (B < nblk_sum && s_summ2[B] == ri) need2 = false;    // (1) whole block is mine
@@ -241,6 +287,9 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         }
       }
       if (!__any(need2)) continue;                              // wave-uniform
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+      dbg_cnt[1]++;
+#endif
       if (g_lo >= NGRP) {                                       // beyond the summarised range
         for (int g = g_hi - 1; g >= g_lo; g--) visit_group(g, need2);
         continue;
@@ -253,6 +302,9 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
 #pragma unroll 8
         for (int q = 0; q < BLK; q++)
           mm |= (q < ng && s_summ[g_lo + q] != ri) ? (1u << q) : 0u;
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+        dbg_cnt[2] += __popc(mm);
+#endif
         while (mm) {
           const int q = __ffs((int)mm) - 1;
           mm &= mm - 1u;
@@ -271,19 +323,47 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         visit_group(g_lo + q, need2 && ((cand >> q) & 1u));
       }
     }
+    CT_STAMP(3);
+    __syncthreads();     // every point of the chunk has met the earlier points: own-chunk groups mostly exit early
+    CT_STAMP(4);
     for (int g = gc; g < gend; g++) visit_group(g, act);
+    CT_STAMP(5);
     __syncthreads();
   }
+  CT_STAMP(6);
   // Back to the reference's labelling: smallest ORIGINAL index of each cluster.
   for (int i = threadIdx.x; i < n; i += CT) {
     par.flatten(i, uf_find(par, i));
     tmp[i] = 0x7FFFFFFF;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += CT) atomicMin(&tmp[par.load(i)], perm[i]);
+  for (int i0 = 0; i0 < n; i0 += CT) {       // wave-uniform trip count
+    const int i = i0 + threadIdx.x;
+    const int r = (i < n) ? par.load(i) : -1;
+    const int pm = (i < n) ? perm[i] : 0x7FFFFFFF;
+    // one atomic per wave when the whole wave sits in one cluster (the common case)
+    const int r0 = __shfl(r, __ffsll((unsigned long long)__ballot(r >= 0)) - 1, 64);
+    if (__all(r < 0 || r == r0)) {
+      int m = pm;
+#pragma unroll
+      for (int k = 32; k >= 1; k >>= 1) m = min(m, __shfl_xor(m, k, 64));
+      if (lane_id() == 0 && r0 >= 0) atomicMin(&tmp[r0], m);
+    } else if (r >= 0) {
+      atomicMin(&tmp[r], pm);
+    }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += CT)
     glabel[perm[i]] = __hip_atomic_load(&tmp[par.load(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DFU3D_DBG_CLUSTER_TIMING
+  CT_STAMP(7);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 8; k++) {
+      ((long long *)(tmp))[(threadIdx.x >> 6) * 8 + k] = dbg_acc[k];
+      ((long long *)(tmp))[64 + (threadIdx.x >> 6) * 8 + k] = dbg_cnt[k];
+    }
+#endif
 }
 
 // Counting sort of one instance's points by spatial cell (row-major cells of
@@ -347,6 +427,228 @@ __device__ __forceinline__ void cell_sort(const double *X, const double *Y, int 
   __syncthreads();
 }
 
+// ============================================================================
+// Grid formulation of a13 (the fast path).  With cell side g = R_max/2 (+ margin)
+//   * g*sqrt(2) < R0, so two points of one cell are ALWAYS adjacent (d <= R0 <= R_i):
+//     a cell is one set from the start and union-find runs over cells, not points;
+//   * cells more than 2 apart are farther than R_max: only the 5x5 neighbourhood
+//     matters, 12 offsets per cell counting every unordered pair once.
+// Two neighbouring cells are linked as soon as ONE adjacent point pair is found
+// (the reference's predicate, evaluated exactly); pairs of cells that already
+// share a root are never tested.  Touching cells go first so that dense
+// instances collapse into one set before the gap-1 offsets are looked at.
+// Labels = smallest original index of the cell-component.  Instances whose
+// bounding box needs more than NC cells fall through to the point-level kernels.
+template <int NC>
+struct GridGeom { double x0, y0, inv, g, Rmax; int nx, ny, ncell; bool ok; };
+
+template <int NC>
+__device__ __forceinline__ GridGeom<NC> grid_geometry(const double *X, const double *Y, int n,
+                                                      double R0, double Rd, double *s_red) {
+  double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, r2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += CT) {
+    const double x = X[i], y = Y[i];
+    x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+    r2 = fmax(r2, x * x + y * y);
+  }
+  x0 = wave_min_d(x0); x1 = wave_max_d(x1); y0 = wave_min_d(y0); y1 = wave_max_d(y1);
+  r2 = wave_max_d(r2);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) { s_red[5 * w] = x0; s_red[5 * w + 1] = x1; s_red[5 * w + 2] = y0; s_red[5 * w + 3] = y1; s_red[5 * w + 4] = r2; }
+  __syncthreads();
+  for (int k = 0; k < CT / 64; k++) {
+    x0 = fmin(x0, s_red[5 * k]); x1 = fmax(x1, s_red[5 * k + 1]);
+    y0 = fmin(y0, s_red[5 * k + 2]); y1 = fmax(y1, s_red[5 * k + 3]); r2 = fmax(r2, s_red[5 * k + 4]);
+  }
+  __syncthreads();
+  GridGeom<NC> G;
+  G.Rmax = (R0 + Rd * sqrt(r2)) * (1.0 + 1e-9) + 1e-12;
+  G.g = 0.5 * G.Rmax * (1.0 + 1e-6) + 1e-12;          // cells 3 apart: gap 2g > Rmax
+  G.x0 = x0; G.y0 = y0; G.inv = 1.0 / G.g;
+  const double ex = x1 - x0, ey = y1 - y0;
+  G.ok = (G.g * 1.4142135623730951 <= R0 * 0.999) && (ex >= 0.0) && (ey >= 0.0) &&
+         (ex < 1e9) && (ey < 1e9);
+  double fx = floor(ex * G.inv) + 1.0, fy = floor(ey * G.inv) + 1.0;
+  if (!(G.ok && fx * fy <= (double)NC)) { G.ok = false; fx = 1.0; fy = 1.0; }
+  G.nx = (int)fx; G.ny = (int)fy; G.ncell = G.nx * G.ny;
+  return G;
+}
+
+template <int NC>
+__device__ __forceinline__ int grid_cell(const GridGeom<NC> &G, double x, double y) {
+  const int cx = (int)fmin(fmax((x - G.x0) * G.inv, 0.0), (double)(G.nx - 1));
+  const int cy = (int)fmin(fmax((y - G.y0) * G.inv, 0.0), (double)(G.ny - 1));
+  return cy * G.nx + cx;
+}
+
+__device__ __forceinline__ int cell_find(int *par_, int a) {
+  volatile int *par = par_;            // other waves link cells concurrently
+  int p = par[a];
+  while (p != a) {
+    const int gp = par[p];
+    if (gp != p) par[a] = gp;
+    a = p;
+    p = gp;
+  }
+  return a;
+}
+__device__ __forceinline__ void cell_unite(int *par, int a, int b) {
+  while (true) {
+    a = cell_find(par, a);
+    b = cell_find(par, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(par + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+// -1: instance not eligible for this variant (NC_MIN < ncell <= NC handled here)
+template <int NC, int NC_MIN>
+__global__ __launch_bounds__(CT) void k_range_cluster_grid(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
+    double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
+    int *__restrict__ perm_all) {
+  __shared__ int s_end[NC];          // cell -> end of its run in sorted order
+  __shared__ int s_par[NC];          // union-find over cells (volatile use through pointers)
+  __shared__ int s_min[NC];          // smallest original index per root cell
+  __shared__ double s_red[5 * (CT / 64)];
+  __shared__ int s_w[CT / 64];
+  const int s = blockIdx.x;
+  const int n = seg_cnt[s];
+  if (n == 0) return;
+  const long long base = seg_base[s];
+  const double *X = px + base, *Y = py + base;
+  double *SX = sx + base, *SY = sy + base;
+  int *perm = perm_all + base;
+  const GridGeom<NC> G = grid_geometry<NC>(X, Y, n, R0, Rd, s_red);
+  if (!G.ok) return;                                   // too wide: point-level kernels
+  if (NC_MIN > 0) {                                    // the smaller variant owns it
+    const GridGeom<(NC_MIN > 0 ? NC_MIN : 1)> Gs = grid_geometry<(NC_MIN > 0 ? NC_MIN : 1)>(X, Y, n, R0, Rd, s_red);
+    if (Gs.ok) return;
+  }
+  const int ncell = G.ncell;
+  // ---- counting sort by cell ------------------------------------------------
+  for (int c = threadIdx.x; c < ncell; c += CT) { s_end[c] = 0; s_par[c] = c; s_min[c] = 0x7FFFFFFF; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += CT) atomicAdd(&s_end[grid_cell(G, X[i], Y[i])], 1);
+  __syncthreads();
+  {
+    const int per = (ncell + CT - 1) / CT;
+    const int c_lo = min((int)threadIdx.x * per, ncell), c_hi = min(c_lo + per, ncell);
+    int mine = 0;
+    for (int c = c_lo; c < c_hi; c++) mine += s_end[c];
+    int tot;
+    int run = block_excl_scan<CT / 64>(mine, s_w, tot);
+    for (int c = c_lo; c < c_hi; c++) { const int h = s_end[c]; s_end[c] = run; run += h; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += CT) {
+    const double x = X[i], y = Y[i];
+    const int pos = atomicAdd(&s_end[grid_cell(G, x, y)], 1);      // s_end[c] ends as the run's end
+    SX[pos] = x;
+    SY[pos] = y;
+    perm[pos] = i;
+  }
+  __syncthreads();
+  // ---- link neighbouring cells ----------------------------------------------
+  const double S_HI = G.Rmax * G.Rmax * (1.0 + 1e-9);
+  const double S_LO = R0 * R0 * (1.0 - 1e-12);
+  const int lane = lane_id();
+  // half neighbourhood: 4 touching offsets, then the 8 with a one-cell gap
+  const int ODX[12] = {1, -1, 0, 1, 2, -2, -1, 0, 1, 2, -2, 2};
+  const int ODY[12] = {0, 1, 1, 1, 0, 2, 2, 2, 2, 2, 1, 1};
+  for (int round = 0; round < 2; round++) {
+    const int o_lo = round ? 4 : 0, n_off = round ? 8 : 4;
+    const int items = ncell * n_off;
+    const int iters = (items + CT - 1) / CT;
+    for (int it = 0; it < iters; it++) {                 // uniform trip count per block
+      const int idx = it * CT + threadIdx.x;
+      int c = 0, nb = 0;
+      bool need = false;
+      if (idx < items) {
+        c = idx / n_off;
+        const int o = o_lo + (idx - c * n_off);
+        const int cx = c % G.nx, cy = c / G.nx;
+        const int qx = cx + ODX[o], qy = cy + ODY[o];
+        if (qx >= 0 && qx < G.nx && qy < G.ny) {
+          nb = qy * G.nx + qx;
+          const int a0 = c ? s_end[c - 1] : 0, b0 = s_end[nb - 1];     // nb > c >= 0
+          need = (s_end[c] > a0) && (s_end[nb] > b0) &&
+                 (cell_find(s_par, c) != cell_find(s_par, nb));
+        }
+      }
+      // the wave serves its lanes' open pairs one at a time, all 64 lanes on the point pairs
+      unsigned long long todo = __ballot(need);
+      while (todo) {
+        const int src = __ffsll(todo) - 1;
+        todo &= todo - 1ull;
+        const int cc = __shfl(c, src, 64), nn = __shfl(nb, src, 64);
+        if (cell_find(s_par, cc) == cell_find(s_par, nn)) continue;   // merged meanwhile (uniform)
+        const int a0 = cc ? s_end[cc - 1] : 0, a1 = s_end[cc];
+        const int b0 = s_end[nn - 1], b1 = s_end[nn];
+        // (i) tight boxes of the two runs: farther apart than R_max -> no pair can be adjacent
+        double ax0 = INFINITY, ax1 = -INFINITY, ay0 = INFINITY, ay1 = -INFINITY;
+        double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+        for (int i = a0 + lane; i < a1; i += 64) {
+          const double x = SX[i], y = SY[i];
+          ax0 = fmin(ax0, x); ax1 = fmax(ax1, x); ay0 = fmin(ay0, y); ay1 = fmax(ay1, y);
+        }
+        for (int i = b0 + lane; i < b1; i += 64) {
+          const double x = SX[i], y = SY[i];
+          bx0 = fmin(bx0, x); bx1 = fmax(bx1, x); by0 = fmin(by0, y); by1 = fmax(by1, y);
+        }
+        ax0 = wave_min_d(ax0); ax1 = wave_max_d(ax1); ay0 = wave_min_d(ay0); ay1 = wave_max_d(ay1);
+        bx0 = wave_min_d(bx0); bx1 = wave_max_d(bx1); by0 = wave_min_d(by0); by1 = wave_max_d(by1);
+        const double gx = fmax(fmax(bx0 - ax1, ax0 - bx1), 0.0), gy = fmax(fmax(by0 - ay1, ay0 - by1), 0.0);
+        if (gx * gx + gy * gy > S_HI) continue;
+        // (ii) 64 x 64 tiles of point pairs: each lane keeps one point of the second
+        // run, the first run's points are broadcast lane by lane -- no memory traffic
+        // inside a tile; leave at the first adjacent pair
+        bool found = false;
+        for (int b_lo = b0; b_lo < b1 && !found; b_lo += 64) {
+          const int ib = b_lo + lane;
+          const bool vb = ib < b1;
+          const double xb = vb ? SX[ib] : 0.0, yb = vb ? SY[ib] : 0.0;
+          for (int a_lo = a0; a_lo < a1 && !found; a_lo += 64) {
+            const int ia = a_lo + lane;
+            const double xal = (ia < a1) ? SX[ia] : 0.0, yal = (ia < a1) ? SY[ia] : 0.0;
+            const int cnt = min(64, a1 - a_lo);
+            bool adj = false;
+            for (int k = 0; k < cnt; k++) {
+              const double xa = __shfl(xal, k, 64), ya = __shfl(yal, k, 64);
+              const double dx = xa - xb, dy = ya - yb;
+              const double sq = dx * dx + dy * dy;
+              if (vb && sq <= S_HI) {
+                if (sq <= S_LO) adj = true;
+                else {
+                  const double d = sqrt(sq);                               // rectangle_fitting.py:169
+                  adj = adj || (d <= R0 + Rd * sqrt(xa * xa + ya * ya)) ||
+                        (d <= R0 + Rd * sqrt(xb * xb + yb * yb));
+                }
+              }
+              if ((k & 15) == 15 && __any(adj)) break;
+            }
+            found = __any(adj);
+          }
+        }
+        if (found && lane == 0) cell_unite(s_par, cc, nn);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- labels: smallest original index of the component ---------------------
+  for (int i = threadIdx.x; i < n; i += CT)
+    atomicMin(&s_min[cell_find(s_par, grid_cell(G, SX[i], SY[i]))], perm[i]);
+  __syncthreads();
+  int *glabel = label + base;
+  for (int i = threadIdx.x; i < n; i += CT)
+    glabel[perm[i]] = s_min[cell_find(s_par, grid_cell(G, SX[i], SY[i]))];
+}
+
 __global__ __launch_bounds__(CT) void k_range_cluster_small(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
@@ -358,11 +660,13 @@ __global__ __launch_bounds__(CT) void k_range_cluster_small(
   __shared__ int s_summ2[SMALL_N / GRP / BLK];
   __shared__ float4 s_box2[SMALL_N / GRP / BLK];
   __shared__ double s_red[4 * (CT / 64)];
+  __shared__ double s_red5[5 * (CT / 64)];
   __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0 || n > SMALL_N) return;
   const long long base = seg_base[s];
+  if (grid_geometry<GRID_NC_LARGE>(px + base, py + base, n, R0, Rd, s_red5).ok) return;   // grid path did it
   cell_sort<SMALL_N>(px + base, py + base, n, s_parent, s_red, s_w, sx + base, sy + base, si + base);
   ParI par{s_parent, false};
   cluster_body<ParI, SMALL_N / GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, sx + base, sy + base,
@@ -380,11 +684,13 @@ __global__ __launch_bounds__(CT) void k_range_cluster_large(
   __shared__ int s_summ2[LARGE_GRP / BLK];
   __shared__ float4 s_box2[LARGE_GRP / BLK];
   __shared__ double s_red[4 * (CT / 64)];
+  __shared__ double s_red5[5 * (CT / 64)];
   __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n <= SMALL_N) return;
   const long long base = seg_base[s];
+  if (grid_geometry<GRID_NC_LARGE>(px + base, py + base, n, R0, Rd, s_red5).ok) return;   // grid path did it
   cell_sort<LARGE_N / 2>(px + base, py + base, n, (int *)s_parent, s_red, s_w, sx + base, sy + base,
                          si + base);
   if (n <= LARGE_N) {
@@ -837,8 +1143,17 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
                                    int64_t pool_cap, void *stream) {
   if (!px || !py || !seg_base || !seg_cnt || !label || !sx || !sy || !si) return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
-  // two LDS footprints: small instances (<= SMALL_N points, several workgroups per
-  // CU) and large ones; each kernel returns at once for the other's segments
+  // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0>), dim3(S), dim3(CT), 0,
+                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
+                     label, sx, sy, si);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL>), dim3(S), dim3(CT), 0,
+                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
+                     label, sx, sy, si);
+  DFU3D_LAUNCH_CHECK();
+  // fallback for instances wider than the largest grid: point-level union-find
+  // (two LDS footprints; each kernel returns at once for segments it does not own)
   hipLaunchKernelGGL(k_range_cluster_small, dim3(S), dim3(CT), 0, (hipStream_t)stream, px, py,
                      (const long long *)seg_base, seg_cnt, R0, Rd, label, sx, sy, si,
                      (long long)pool_cap);
