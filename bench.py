@@ -100,9 +100,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dump", type=str, default="", help="write per-kernel timing JSON here")
+    ap.add_argument("--dist-backend", default=None, help="nccl (default on GPUs) | gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env()
+    if args.single_device:
+        os.environ["LOCAL_RANK_OVERRIDE"] = "0"
+    rank, world, local = D.init_from_env(args.dist_backend)
+    if args.single_device:
+        local = 0
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
@@ -157,7 +164,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     n_boxes = int(rows.shape[0])

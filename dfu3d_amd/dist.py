@@ -45,13 +45,20 @@ def allgather_rows(rows: torch.Tensor, frame_of_view=None) -> torch.Tensor:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    cdev = torch.device("cpu") if dist.get_backend() == "gloo" else rows.device
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=cdev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     mx = max(max(counts), 1)
     pad = torch.zeros((mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
     pad[:rows.shape[0]] = rows
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    if dist.get_backend() == "gloo" and pad.is_cuda:      # CPU rehearsal of the multi-GPU path
+        cpu = pad.cpu()
+        out = [torch.empty_like(cpu) for _ in range(world)]
+        dist.all_gather(out, cpu)
+        out = [o.to(rows.device) for o in out]
+    else:
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad)
     return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
