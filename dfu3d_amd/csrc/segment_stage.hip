@@ -220,13 +220,31 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
 }
 
 // ---------------------------------------------------------------- a12 ball query
+// exists-within-C with a spatial hash: the instance's LiDAR points (at most a
+// few thousand) are hashed by their cell of side c = C(1+1e-6) into an LDS
+// multimap (open addressing, one 64-bit word per point: 3 x 16-bit cell | 16-bit
+// index); a pseudo point looks at the 27 cells around its own and evaluates the
+// reference's predicate only on the points it finds there (d2 < T <=> sqrt(d2) < C).
+// Any point closer than C lies in one of those cells, so the answer is exact.
+// Instances with more LiDAR points than the table holds use the brute-force tile loop.
+constexpr int BH_SLOTS = 8192;                 // 64 KB of LDS
+constexpr int BH_MAX = 4096;                   // load factor <= 0.5
+constexpr unsigned long long BH_EMPTY = ~0ull;
+
+__device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
+  uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  return h & (BH_SLOTS - 1);
+}
+
 __global__ __launch_bounds__(QT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ base_a,
     const int *__restrict__ cnt_a, const long long *__restrict__ base_b,
-    const int *__restrict__ cnt_b, double T, int S, const int *__restrict__ tile_off,
+    const int *__restrict__ cnt_b, double T, double C, int S, const int *__restrict__ tile_off,
     uint8_t *__restrict__ flags) {
-  __shared__ double sx[PT], sy[PT], sz[PT];
+  __shared__ unsigned long long s_tab[BH_SLOTS];
+  __shared__ double s_red[3 * (QT / 64)];
   __shared__ int s_pending;
   const int t = blockIdx.x;
   if (t >= tile_off[S]) return;
@@ -243,6 +261,71 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
   double x = 0.0, y = 0.0, z = 0.0;
   if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
   bool found = false;
+  if (na <= BH_MAX) {
+    // origin of the cell grid: component-wise minimum of the LiDAR points
+    double mx = INFINITY, my = INFINITY, mz = INFINITY;
+    for (int i = threadIdx.x; i < na; i += QT) {
+      mx = fmin(mx, px[ba + i]); my = fmin(my, py[ba + i]); mz = fmin(mz, pz[ba + i]);
+    }
+    mx = wave_min_d(mx); my = wave_min_d(my); mz = wave_min_d(mz);
+    if (lane_id() == 0) { s_red[3 * (threadIdx.x >> 6)] = mx; s_red[3 * (threadIdx.x >> 6) + 1] = my; s_red[3 * (threadIdx.x >> 6) + 2] = mz; }
+    for (int i = threadIdx.x; i < BH_SLOTS; i += QT) s_tab[i] = BH_EMPTY;
+    __syncthreads();
+    for (int w = 0; w < QT / 64; w++) { mx = fmin(mx, s_red[3 * w]); my = fmin(my, s_red[3 * w + 1]); mz = fmin(mz, s_red[3 * w + 2]); }
+    const double inv = 1.0 / (C * (1.0 + 1e-6));
+    // cell coordinates are offset by 1 so that the 27-neighbourhood never underflows;
+    // anything beyond 65534 cells (6.5 km) from the origin cannot be near a LiDAR point
+    bool too_wide = false;
+    for (int i = threadIdx.x; i < na; i += QT) {
+      const double fx = floor((px[ba + i] - mx) * inv), fy = floor((py[ba + i] - my) * inv),
+                   fz = floor((pz[ba + i] - mz) * inv);
+      if (!(fx < 65000.0 && fy < 65000.0 && fz < 65000.0)) { too_wide = true; continue; }
+      const uint32_t ix = (uint32_t)fx + 1u, iy = (uint32_t)fy + 1u, iz = (uint32_t)fz + 1u;
+      const unsigned long long word = (unsigned long long)ix | ((unsigned long long)iy << 16) |
+                                      ((unsigned long long)iz << 32) | ((unsigned long long)i << 48);
+      uint32_t h = bh_hash(ix, iy, iz);
+      while (atomicCAS(&s_tab[h], BH_EMPTY, word) != BH_EMPTY) h = (h + 1) & (BH_SLOTS - 1);
+    }
+    if (threadIdx.x == 0) s_pending = 0;
+    __syncthreads();
+    if (too_wide) s_pending = 1;
+    __syncthreads();
+    if (!s_pending) {
+      if (valid) {
+        const double fx = floor((x - mx) * inv), fy = floor((y - my) * inv), fz = floor((z - mz) * inv);
+        if (fx >= -1.0 && fy >= -1.0 && fz >= -1.0 && fx < 65001.0 && fy < 65001.0 && fz < 65001.0) {
+          const int cx = (int)fx + 1, cy = (int)fy + 1, cz = (int)fz + 1;      // >= 0
+          for (int dz = -1; dz <= 1 && !found; dz++)
+            for (int dy = -1; dy <= 1 && !found; dy++)
+              for (int dx = -1; dx <= 1 && !found; dx++) {
+                const int ux = cx + dx, uy = cy + dy, uz = cz + dz;
+                if (ux < 1 || uy < 1 || uz < 1) continue;                        // no LiDAR cell there
+                const unsigned long long key = (unsigned long long)ux | ((unsigned long long)uy << 16) |
+                                               ((unsigned long long)uz << 32);
+                uint32_t h = bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz);
+                while (true) {
+                  const unsigned long long wv = s_tab[h];
+                  if (wv == BH_EMPTY) break;
+                  if ((wv & 0xFFFFFFFFFFFFull) == key) {
+                    const int j = (int)(wv >> 48);
+                    const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
+                    double d = ex * ex;
+                    d += ey * ey;
+                    d += ez * ez;
+                    if (d < T) { found = true; break; }      // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
+                  }
+                  h = (h + 1) & (BH_SLOTS - 1);
+                }
+              }
+        }
+        flags[bq + q] = found ? 1 : 0;
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  // brute force over LDS tiles (more LiDAR points than the hash holds, or a huge extent)
+  double *sx = (double *)s_tab, *sy = sx + PT, *sz = sy + PT;     // 24 KB of the table's LDS
   for (int j0 = 0; j0 < na; j0 += PT) {
     const int m = min(PT, na - j0);
     __syncthreads();
@@ -259,7 +342,7 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
         double d = dx * dx;
         d += dy * dy;
         d += dz * dz;
-        if (d < T) { found = true; break; }      // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
+        if (d < T) { found = true; break; }
       }
       if (!found) s_pending = 1;
     }
@@ -517,7 +600,7 @@ extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const in
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_ball_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
-                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, S,
+                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_off, flags);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz, (long long *)base_b,

@@ -100,7 +100,7 @@ def test_radius_filter_matches_oracle(st):
 # ------------------------------------------------------------------ a12
 def test_ballquery_fuse_matches_oracle(st):
     rng = np.random.default_rng(12)
-    cases = [(0, 10), (10, 0), (40, 300), (1, 50), (1500, 2600), (3, 3)]
+    cases = [(0, 10), (10, 0), (40, 300), (1, 50), (1500, 2600), (3, 3), (4500, 900), (4096, 5000)]
     segsA, segsB = [], []
     for na, nb in cases:
         a = rng.normal(0, 2.0, (na, 3))
