@@ -708,7 +708,7 @@ __global__ __launch_bounds__(CT) void k_range_cluster_large(
 constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
-constexpr int LDS_MEMBERS = 2048;   // clusters up to this size: members cached in LDS, one wave per heading
+constexpr int LDS_MEMBERS = 1024;   // clusters up to this size: members cached in LDS, one wave per heading
 constexpr int TB = 8;               // larger clusters: headings per point-parallel sweep
 
 // block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
@@ -976,9 +976,11 @@ __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ 
   __shared__ double s_ct[TB], s_st[TB];
   __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
   const int nbig = min(*(const int *)fit_ws, cap_big);
-  const int c = blockIdx.x / nb;
-  const int tb = (blockIdx.x - c * nb) * TB;
-  if (c >= nbig || tb >= n_theta) return;
+  for (int item = blockIdx.x; item < nbig * nb; item += gridDim.x) {     // uniform per block
+  const int c = item / nb;
+  const int tb = (item - c * nb) * TB;
+  if (tb >= n_theta) continue;
+  __syncthreads();
   const double *dsc = fit_ws + 2 + (size_t)c * 8;
   const int m = (int)dsc[3];
   const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
@@ -1083,6 +1085,7 @@ __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ 
       }
       __syncthreads();
   }
+  }
 }
 
 __global__ __launch_bounds__(FT) void k_fit_big_box(
@@ -1094,8 +1097,8 @@ __global__ __launch_bounds__(FT) void k_fit_big_box(
     uint32_t *__restrict__ status, const double *__restrict__ fit_ws, int cap_big) {
   __shared__ double s_ext[FW][4];
   const int nbig = min(*(const int *)fit_ws, cap_big);
-  const int c = blockIdx.x;
-  if (c >= nbig) return;
+  for (int c = blockIdx.x; c < nbig; c += gridDim.x) {
+  __syncthreads();
   const double *dsc = fit_ws + 2 + (size_t)c * 8;
   const int s = (int)dsc[0], kc = (int)dsc[1], root = (int)dsc[2], m = (int)dsc[3];
   const double zmax = dsc[5];
@@ -1132,6 +1135,7 @@ __global__ __launch_bounds__(FT) void k_fit_big_box(
     emit_box(thb, sin_s, cos_s, c1min, c1max, c2min, c2max, zmax, s, v, jinst, kc, root, m, calib,
              inst_class, inst_is_car, inst_box, inst_score, car_aspect_max, cap_rows, rows, n_rows,
              status);
+  }
   }
 }
 
@@ -1196,10 +1200,11 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
                      car_aspect_max, sx, sy, sroot, cap_rows, rows, n_rows, status, fit_ws, cap_big);
   DFU3D_LAUNCH_CHECK();
   const int nb = (n_theta + TB - 1) / TB;
-  hipLaunchKernelGGL(k_fit_big_cost, dim3(cap_big * nb), dim3(FT), 0, st, sx, sy, n_theta, dtheta,
+  const int g2 = cap_big * nb < 4096 ? cap_big * nb : 4096;           // persistent: items are looped over
+  hipLaunchKernelGGL(k_fit_big_cost, dim3(g2), dim3(FT), 0, st, sx, sy, n_theta, dtheta,
                      nb, fit_ws, cap_big);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fit_big_box, dim3(cap_big), dim3(FT), 0, st, sx, sy, max_inst,
+  hipLaunchKernelGGL(k_fit_big_box, dim3(cap_big < 2048 ? cap_big : 2048), dim3(FT), 0, st, sx, sy, max_inst,
                      (const ViewCalib *)calib, inst_class, inst_is_car, inst_box, inst_score,
                      n_theta, dtheta, car_aspect_max, cap_rows, rows, n_rows, status, fit_ws,
                      cap_big);
