@@ -290,6 +290,11 @@ class PseudoBoxEngine:
         rows, n_rows, status = self._last
         counts = n_rows.cpu().numpy()                   # the one host sync
         stw = int(np.bitwise_or.reduce(status.cpu().numpy().astype(np.int64)))
+        if self.dense and (stw & st.ST_VOX_OVERFLOW):   # a pass that overflowed left its bin table dirty
+            for L in self.lanes:
+                with torch.cuda.stream(L.stream):
+                    st.bin_table_init(L.table, self.Vc * L.E)
+            torch.cuda.synchronize()
         parts = []
         for c, n in enumerate(counts):
             n = int(min(n, self.cap_rows))
