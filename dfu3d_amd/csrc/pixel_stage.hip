@@ -134,10 +134,10 @@ constexpr uint32_t AMBIG = 0xFFFFFFFEu;
 // the fp64 path of pixel_bin() would decide identically.  Everything else
 // returns AMBIG and is classified by pixel_bin() in k_bp_bin_amb.
 __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const dfu3d_bin_geom &g,
-                                                   double inv_t, double inv_p, int W, int pix,
-                                                   float d, int key_axis, double &key) {
+                                                   double inv_t, double inv_p, int row, int col,
+                                                   float d, int key_axis, double &key, int &it_out,
+                                                   int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
-  const int row = pix / W, col = pix - row * W;
   double x, y, z;
   pixel_to_lidar(c, col, row, d, x, y, z);
   if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
@@ -166,6 +166,8 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const dfu
   if (!(ft > mt && ft < 1.0 - mt && fp > mp && fp < 1.0 - mp)) return AMBIG;
   const int it = (int)floor(qt) - g.t_lo, ip = (int)floor(qp) - g.p_lo;
   if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) return AMBIG;
+  it_out = it;
+  ip_out = ip;
   return (uint32_t)(it * g.p_n + ip);
 }
 
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   __syncthreads();
   uint32_t bins[PPT];
   double keys[PPT];
+  int its[PPT], ips[PPT];
   const bool inside = (row < H) && (col < W);
   const int base = row * W + col;
   if (inside) {
@@ -212,12 +215,14 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       bins[k] = NOBIN;
       keys[k] = 0.0;
       if (col + k < W) {
-        const uint32_t b = pixel_bin_fast(c, g, inv_t, inv_p, W, base + k, d[k], key_axis, keys[k]);
+        its[k] = 0; ips[k] = 0;
+        const uint32_t b = pixel_bin_fast(c, g, inv_t, inv_p, row, col + k, d[k], key_axis, keys[k],
+                                          its[k], ips[k]);
         if (b == AMBIG) {
           s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
         } else {
           bins[k] = b;
-          if (b != NOBIN) { tmin = min(tmin, (int)(b / (uint32_t)g.p_n)); pmin = min(pmin, (int)(b % (uint32_t)g.p_n)); }
+          if (b != NOBIN) { tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]); }
         }
       }
     }
@@ -231,12 +236,15 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
+#ifdef DFU3D_DBG_BP_NOAGG
+  if (t0 == -12345)
+#endif
   if (inside) {
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = bins[k];
       if (b == NOBIN) continue;
-      const int lt = (int)(b / (uint32_t)g.p_n) - t0, lp = (int)(b % (uint32_t)g.p_n) - p0;
+      const int lt = its[k] - t0, lp = ips[k] - p0;
       if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
         const int w = lt * WIN_P + lp;
         atomicAdd(&s_cnt[w], 1u);
@@ -256,6 +264,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   }
   __syncthreads();
   // flush the window: one set of global atomics per touched bin
+#ifdef DFU3D_DBG_BP_NOFLUSH
+  if (t0 == -12345)
+#endif
   for (int w = threadIdx.x; w < WIN_T * WIN_P; w += PB) {
     const uint32_t cw = s_cnt[w];
     if (cw == 0u) continue;
