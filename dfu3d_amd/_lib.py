@@ -85,6 +85,10 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own HIP runtime; it must be in the process before this
+    # library is dlopen'ed so that both resolve the SAME libamdhip64 (otherwise torch's
+    # streams and device pointers are foreign to our launches: hipErrorInvalid*).
+    import torch  # noqa: F401
     path = _build.OUT
     if not os.path.exists(path):
         try:

@@ -167,6 +167,10 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   return z ^ (z >> 31);
 }
 
+// a sticky error left behind by an earlier, unrelated HIP call of the process must
+// not be mistaken for a failure of our launch
+#define DFU3D_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
 #define DFU3D_LAUNCH_CHECK()                                      \
   do {                                                            \
     if (hipGetLastError() != hipSuccess) return DFU3D_ELAUNCH;    \

@@ -1145,6 +1145,7 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
                                    const int32_t *seg_cnt, int32_t S, double R0, double Rd,
                                    int32_t *label, double *sx, double *sy, int32_t *si,
                                    int64_t pool_cap, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!px || !py || !seg_base || !seg_cnt || !label || !sx || !sy || !si) return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
@@ -1185,6 +1186,7 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
                                 int32_t cap_rows, double *rows, int32_t *n_rows,
                                 uint32_t *status, double *fit_ws, int64_t pool_cap,
                                 void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!px || !py || !pz || !label || !seg_base || !seg_cnt || !calib || !inst_class ||
       !inst_is_car || !inst_box || !inst_score || !sx || !sy || !sroot || !rows || !n_rows ||
       !status || !fit_ws)

@@ -345,6 +345,7 @@ extern "C" int dfu3d_fov_filter(const float *points, const int32_t *pt_off,
                                 int32_t V, int32_t fov_h, int32_t fov_w,
                                 int32_t cap_n, int32_t *fov_idx, int32_t *n_fov,
                                 void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!points || !pt_off || !view_frame || !calib || !fov_idx || !n_fov) return DFU3D_EINVAL;
   if (V <= 0 || cap_n <= 0 || fov_h <= 0 || fov_w <= 0) return DFU3D_EINVAL;
   hipLaunchKernelGGL(k_fov_filter, dim3(V), dim3(NT), 0, (hipStream_t)stream,
@@ -361,6 +362,7 @@ extern "C" int dfu3d_plane_ransac(const float *points, const int32_t *pt_off,
                                   double max_hs, double xy_range, int32_t trials,
                                   uint64_t seed, const int64_t *key,
                                   int32_t *cand_idx, double *plane, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!points || !pt_off || !view_frame || !fov_idx || !n_fov || !key || !cand_idx || !plane)
     return DFU3D_EINVAL;
   if (V <= 0 || cap_n <= 0 || trials < 0) return DFU3D_EINVAL;
@@ -379,6 +381,7 @@ extern "C" int dfu3d_project_label(
     int32_t max_inst, int32_t H, int32_t W, int32_t cap_n, double plane_offset,
     double xy_range, int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag, int32_t *K,
     uint32_t *it_bits, double *it_x, double *it_y, double *it_z, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!points || !pt_off || !view_frame || !calib || !plane || !fov_idx || !n_fov ||
       !masks || !n_inst || !ag_pt || !ib_pix || !n_ag || !K || !it_bits || !it_x ||
       !it_y || !it_z)

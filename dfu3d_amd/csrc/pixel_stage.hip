@@ -599,6 +599,7 @@ extern "C" int64_t dfu3d_bin_table_geometry(dfu3d_bin_geom *g) {
 }
 
 extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!table || E <= 0) return DFU3D_EINVAL;
   const Table T = table_view(table, E);
   hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(256), 0, (hipStream_t)stream, T.kmin,
@@ -630,6 +631,7 @@ extern "C" int dfu3d_backproject_bin(
     int32_t key_axis, void *table, uint32_t *pix_bin, int32_t *blk_cnt, int32_t cap_vox,
     int32_t *n_vox, uint32_t *vox_pix, uint32_t *it_bits, double *it_x, double *it_y,
     double *it_z, uint32_t *status, int32_t phases, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!depth || !calib || !geom || !table || !pix_bin || !blk_cnt || !n_vox || !vox_pix ||
       !it_bits || !it_x || !it_y || !it_z || !status)
     return DFU3D_EINVAL;

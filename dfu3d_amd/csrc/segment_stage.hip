@@ -497,6 +497,7 @@ extern "C" int dfu3d_segments_build(
     int32_t max_inst, int64_t pool_cap, int64_t *pool_cursor, double *px, double *py,
     double *pz, int64_t *base_a, int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
     uint32_t *status, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!a_bits || !a_x || !a_y || !a_z || !a_n || !b_bits || !b_x || !b_y || !b_z || !b_n ||
       !pool_cursor || !px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !status)
     return DFU3D_EINVAL;
@@ -526,6 +527,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
                                    int32_t S, int64_t pool_cap, int32_t *tile_off,
                                    uint8_t *flags, int32_t *queue, int32_t phases,
                                    void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags || !queue)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || nb_points < 0) return DFU3D_EINVAL;
@@ -560,6 +562,7 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
                                  double std_ratio, int32_t S, int64_t pool_cap,
                                  int32_t *tile_off, uint8_t *flags, double *mean_d,
                                  double *stats, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   (void)stats;
   if (!px || !py || !pz || !seg_base || !seg_cnt || !enable || !tile_off || !flags || !mean_d)
     return DFU3D_EINVAL;
@@ -586,6 +589,7 @@ extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const in
                                     const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
                                     double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
                                     uint8_t *flags, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
   if (!px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !tile_off || !flags)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
