@@ -37,6 +37,11 @@ def build_parser():
     ap.add_argument('--start', type=int, default=0)
     ap.add_argument('--end', type=int, default=None)
     ap.add_argument('--skip-existing', action='store_true')
+    ap.add_argument('--batch-frames', type=int, default=16,
+                    help='frames per engine call (0: one view at a time through save_depth_as_points)')
+    ap.add_argument('--no-virtual-points', action='store_true',
+                    help='labels only: skip the velodyne_depth/*.npy files of vis_utils.py:164-166')
+    ap.add_argument('--streams', type=int, default=2)
     return ap
 
 
@@ -56,6 +61,20 @@ def main(argv=None):
     depth_dir = args.depth_dir or os.path.join(args.detpath, 'depth_2')
     label_out = args.label_out or os.path.join(args.detpath, 'label_2')
     t0 = time.time()
+    if args.skip_existing:
+        mine = [s for s in mine if not os.path.exists(os.path.join(label_out, s + '.txt'))]
+    if args.batch_frames > 0:
+        from ..pipeline import BatchedLabeler
+        lab = BatchedLabeler(batch_frames=max(1, min(args.batch_frames, len(mine))), lanes=args.streams,
+                             workers=max(1, args.workers),
+                             device="cuda:%d" % (local if world > 1 else 0),
+                             want_points=not args.no_virtual_points)
+        stats = lab.run(args.detpath, mine, label_out, depth_dir)
+        if rank == 0:
+            dt = time.time() - t0
+            print("%d frames, %d boxes, %.2f frames/s (files in, files out)" % (stats["frames"], stats["boxes"],
+                                                                              stats["frames"] / max(dt, 1e-9)))
+        mine = []
     for k, idx in enumerate(mine):
         if args.skip_existing and os.path.exists(os.path.join(label_out, idx + '.txt')):
             continue

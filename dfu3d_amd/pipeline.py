@@ -1,0 +1,231 @@
+"""Batched labelling of a KITTI-format directory (the L0
+readers either side of the hot path).
+
+The reference walks the directory one frame at a time
+(tools/PENet/main.py:238-349, vis_utils.py:136-166).  Here frames are read by a
+pool of host threads (velodyne/*.bin, calib/*.txt, image_2/*.png, seg_2/*.npz,
+depth_2/*.npy; tools/nuscenes2kitti.py:246-285 for the formats), packed into
+PINNED staging tensors, copied to the GPU on a side stream while the previous
+batch is still being processed, run through PseudoBoxEngine in one multi-view
+launch chain, and the label files (and, optionally, the float16 virtual-point
+files of vis_utils.py:164-166) are written by background threads.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .calibration import Calibration
+from .engine import PseudoBoxEngine, ViewBatch
+from .labels import write_label_file
+from .params import NUSC_CLASSES, Params
+
+
+@dataclass
+class Frame:
+    stem: str
+    points: np.ndarray          # (n,4) f32
+    calib: Calibration
+    depth: np.ndarray           # (H,W) f32
+    masks: np.ndarray           # (M,H,W) u8
+    classes: np.ndarray         # (M,) int
+    scores: np.ndarray          # (M,) f32
+    boxes: np.ndarray           # (M,4) f32
+    thing_classes: List[str]
+    image: Optional[np.ndarray] = None   # (H,W,3) u8, only for the virtual-point file
+
+
+def read_frame(root, stem, depth_dir=None, want_image=False, score_min=0.7) -> Frame:
+    """One frame of the directory layout written by dfu3d_amd.kitti_io.write_frame."""
+    pts = np.fromfile(os.path.join(root, 'velodyne', stem + '.bin'), dtype=np.float32).reshape(-1, 4)
+    calib = Calibration(os.path.join(root, 'calib', stem + '.txt'))
+    depth = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), stem + '.npy')).astype(np.float32, copy=False)
+    z = np.load(os.path.join(root, 'seg_2', stem + '.npz'), allow_pickle=False)
+    keep = z['scores'] > score_min                                  # vis_utils.py:218
+    image = None
+    if want_image:
+        from PIL import Image
+        image = np.asarray(Image.open(os.path.join(root, 'image_2', stem + '.png')).convert('RGB'), np.uint8)
+    return Frame(stem, pts, calib, depth.reshape(depth.shape[0], depth.shape[1]),
+                 np.ascontiguousarray(z['masks'][keep], np.uint8), z['classes'][keep].astype(np.int64),
+                 z['scores'][keep].astype(np.float32), z['boxes'][keep].astype(np.float32),
+                 [str(s) for s in z['thing_classes']], image)
+
+
+class BatchedLabeler:
+    """Directory -> label files, `batch_frames` single-camera frames per engine call."""
+
+    def __init__(self, params: Params = None, batch_frames=16, lanes=2, workers=8, device="cuda:0",
+                 cap_n=1 << 17, want_points=False):
+        self.p = params or Params()
+        self.B = int(batch_frames)
+        self.lanes = int(lanes)
+        self.workers = int(workers)
+        self.dev = torch.device(device)
+        self.cap_n = int(cap_n)
+        self.want_points = bool(want_points)
+        self._engines = {}
+        self._copy_stream = torch.cuda.Stream(self.dev)
+        self.stats = {"frames": 0, "boxes": 0}
+
+    # ------------------------------------------------------------------
+    def _engine(self, H, W, M):
+        key = (H, W, M)
+        e = self._engines.get(key)
+        if e is None:
+            p = self.p
+            if tuple(p.bounds_hw) != (H, W) or tuple(p.fov_hw) != (H, W):
+                p = Params(**{**p.__dict__, "bounds_hw": (H, W), "fov_hw": (H, W)})
+            per_lane = max(1, self.B // max(1, self.lanes))
+            while self.B % per_lane:
+                per_lane -= 1
+            e = PseudoBoxEngine(p, H, W, M, self.cap_n, views_per_chunk=per_lane, dense=True,
+                                cap_vox=1 << 19, pool_per_view=1 << 19, rows_per_view=256,
+                                device=self.dev, lanes=self.B // per_lane)
+            self._engines[key] = e
+        return e
+
+    def _pack(self, frames: List[Frame]):
+        """Frames -> pinned host tensors -> device ViewBatch (async on the copy stream)."""
+        B = self.B
+        H, W = frames[0].depth.shape
+        M = max([f.masks.shape[0] for f in frames] + [1])
+        M = min(32, (M + 7) // 8 * 8)
+        for f in frames:
+            if f.points.shape[0] > self.cap_n:
+                raise ValueError("%s: %d LiDAR points exceed cap_n=%d" % (f.stem, f.points.shape[0], self.cap_n))
+        n_pts = [f.points.shape[0] for f in frames] + [0] * (B - len(frames))
+        off = np.zeros(B + 1, np.int64)
+        off[1:] = np.cumsum(n_pts)
+        pin = lambda *s, dt: torch.empty(s, dtype=dt).pin_memory()
+        pts = pin(max(int(off[-1]), 1), 4, dt=torch.float32)
+        depth = pin(B, H, W, dt=torch.float32)
+        masks = torch.zeros((B, M, H, W), dtype=torch.uint8).pin_memory()
+        calib = torch.zeros((B, 48), dtype=torch.float32)
+        n_inst = torch.zeros(B, dtype=torch.int32)
+        cls = torch.zeros((B, M), dtype=torch.int32)
+        car = torch.zeros((B, M), dtype=torch.int32)
+        rl = torch.zeros((B, M), dtype=torch.float64)
+        rp = torch.zeros((B, M), dtype=torch.float64)
+        box = torch.zeros((B, M, 4), dtype=torch.float32)
+        score = torch.zeros((B, M), dtype=torch.float32)
+        key = torch.zeros(B, dtype=torch.int64)
+        depth.zero_()
+        for i, f in enumerate(frames):
+            if f.depth.shape != (H, W):
+                raise ValueError("%s: depth %s differs from the batch's %s" % (f.stem, f.depth.shape, (H, W)))
+            m = min(f.masks.shape[0], M)
+            pts[off[i]:off[i + 1]] = torch.from_numpy(f.points[:n_pts[i]])
+            depth[i] = torch.from_numpy(f.depth)
+            if m:
+                masks[i, :m] = torch.from_numpy(f.masks[:m])
+            calib[i] = torch.from_numpy(f.calib.record())
+            n_inst[i] = m
+            names = [f.thing_classes[int(c)] for c in f.classes[:m]]
+            for j, nm in enumerate(names):
+                cls[i, j] = int(f.classes[j])
+                car[i, j] = 1 if nm == "Car" else 0
+                rl[i, j], rp[i, j] = self.p.instance_radii(nm)
+            if m:
+                box[i, :m] = torch.from_numpy(f.boxes[:m])
+                score[i, :m] = torch.from_numpy(f.scores[:m])
+            key[i] = int(f.stem) if f.stem.isdigit() else i
+        d = self.dev
+        with torch.cuda.stream(self._copy_stream):
+            g = lambda t: t.to(d, non_blocking=True)
+            vb = ViewBatch(points=g(pts), pt_off=g(torch.from_numpy(off).to(torch.int32)),
+                           view_frame=torch.arange(B, dtype=torch.int32, device=d), calib=g(calib),
+                           masks=g(masks), n_inst=g(n_inst), inst_class=g(cls), inst_is_car=g(car),
+                           inst_r_lidar=g(rl), inst_r_pseudo=g(rp), inst_box=g(box), inst_score=g(score),
+                           view_key=g(key), host_pt_off=off, host_view_frame=np.arange(B), depth=g(depth))
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        return vb, ready, (H, W, M), (pts, depth, masks)      # keep the pinned buffers alive
+
+    def _write(self, frames, rows_h, label_out, npy_out, vp):
+        for i, f in enumerate(frames):
+            r = rows_h[rows_h[:, 0] == i]
+            write_label_file(os.path.join(label_out, f.stem + '.txt'), r, NUSC_CLASSES)
+            if vp is not None:
+                np.save(os.path.join(npy_out, f.stem + '.npy'), vp[i])
+
+    def _virtual_points(self, eng, vb, frames):
+        """my_loader.py:611-617 for every frame of the batch -> list of float16 arrays.
+        Every chunk of the batch ran on its own lane, so lane c still holds chunk c's
+        FOV list (the LiDAR rows of the file, vis_utils.py:152-154)."""
+        out = [None] * len(frames)
+        Vc = eng.Vc
+        for c in range(self.B // Vc):
+            L = eng.lanes[c]
+            eng._bind(L)
+            fov_n = L.n_fov.cpu().numpy()
+            fov_i = L.fov_idx.view(Vc, eng.cap_n).cpu().numpy()
+            n_vox, vox_pix, xyz, _ = eng.virtual_points(vb, c * Vc)
+            nv = n_vox.cpu().numpy()
+            for k in range(Vc):
+                i = c * Vc + k
+                if i >= len(frames):
+                    continue
+                f = frames[i]
+                n = int(nv[k])
+                newp = np.zeros((n, 8))
+                newp[:, 0:3] = xyz[k, :n].cpu().numpy()
+                if f.image is not None and n:
+                    pix = vox_pix[k, :n].cpu().numpy().astype(np.int64)
+                    newp[:, 4:7] = f.image.reshape(-1, 3)[pix].astype(np.int32) / 3
+                newp[:, -1] = 1
+                lid = f.points[fov_i[k][:fov_n[k]]]
+                newl = np.zeros((lid.shape[0], 8))
+                newl[:, 0:4] = lid
+                newl[:, 3] *= 10
+                newl[:, -1] = 2
+                out[i] = np.concatenate([newl, newp], 0).astype(np.float16)
+        return out
+
+    # ------------------------------------------------------------------
+    def _prepare(self, root, batch, depth_dir, pool):
+        torch.cuda.set_device(self.dev)
+        frames = list(pool.map(lambda s: read_frame(root, s, depth_dir, self.want_points), batch))
+        return frames, self._pack(frames)
+
+    def run(self, root, stems: List[str], label_out, depth_dir=None, npy_out=None):
+        os.makedirs(label_out, exist_ok=True)
+        if self.want_points:
+            npy_out = npy_out or os.path.join(root, 'velodyne_depth')
+            os.makedirs(npy_out, exist_ok=True)
+        batches = [stems[i:i + self.B] for i in range(0, len(stems), self.B)]
+        if not batches:
+            return self.stats
+        pool = ThreadPoolExecutor(self.workers)       # file readers
+        prep = ThreadPoolExecutor(1)                  # reads + packs + uploads the NEXT batch
+        writers = ThreadPoolExecutor(2)
+        pending = []
+        fut = prep.submit(self._prepare, root, batches[0], depth_dir, pool)
+        for bi in range(len(batches)):
+            frames, (vb, ready, (H, W, M), keep) = fut.result()
+            if bi + 1 < len(batches):
+                fut = prep.submit(self._prepare, root, batches[bi + 1], depth_dir, pool)
+            eng = self._engine(H, W, M)
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(ready)
+            for t in vb.__dict__.values():             # uploaded on the copy stream, used on this one
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
+            rows, status = eng.run(vb)
+            if status:
+                from .stages import status_message
+                raise RuntimeError("device status: " + status_message(status))
+            rows_h = rows.cpu().numpy()
+            vp = self._virtual_points(eng, vb, frames) if self.want_points else None
+            pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp))
+            self.stats["frames"] += len(frames)
+            self.stats["boxes"] += int(rows_h.shape[0])
+            del keep
+        for p_ in pending:
+            p_.result()
+        for ex in (pool, prep, writers):
+            ex.shutdown()
+        return self.stats

@@ -118,6 +118,52 @@ def test_cli_on_kitti_directory_matches_oracle(tmp_path):
         assert np.array_equal(vp, exp[f].all_points.astype(np.float16))
     # a second run with --skip-existing leaves the files alone
     assert cli.main(["--detpath", root, "--skip-existing", "--conf_files", "x.yaml"]) == 0
+    # the one-view-at-a-time path (save_depth_as_points) writes the same files as the batched one
+    import shutil
+    keep = {}
+    for f in range(2):
+        keep[f] = (open(os.path.join(root, "label_2", "%06d.txt" % f)).read(),
+                   np.load(os.path.join(root, "velodyne_depth", "%06d.npy" % f)))
+    shutil.rmtree(os.path.join(root, "label_2")); shutil.rmtree(os.path.join(root, "velodyne_depth"))
+    assert cli.main(["--detpath", root, "--batch-frames", "0", "--conf_files", "x.yaml"]) == 0
+    for f in range(2):
+        assert open(os.path.join(root, "label_2", "%06d.txt" % f)).read() == keep[f][0]
+        assert np.array_equal(np.load(os.path.join(root, "velodyne_depth", "%06d.npy" % f)), keep[f][1])
+
+
+def test_batched_labeler_many_frames_partial_batch(tmp_path):
+    """5 frames in batches of 4 (one padded batch), 2 streams, labels only."""
+    _need_gpu()
+    from dfu3d_amd import synth, kitti_io
+    from dfu3d_amd.labels import read_label_file
+    from dfu3d_amd.params import NUSC_CLASSES
+    from dfu3d_amd.pipeline import BatchedLabeler
+    H, W, M = 180, 320, 5
+    root = str(tmp_path / "kitti")
+    exp = {}
+    for f in range(5):
+        s = synth.make_scene(160 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=14, k_max=18,
+                             rings=(32, 24, 32, 16, 32)[f])
+        n = int(s.n_inst[0])
+        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], pattern_image(H, W), s.masks[0][:n].numpy(),
+                             s.inst_class[0][:n].numpy(), s.inst_score[0][:n].numpy(),
+                             s.inst_box[0][:n].numpy(), NUSC_CLASSES, s.depth[0].numpy())
+        oc = O.Calibration(os.path.join(root, "calib", "%06d.txt" % f))
+        lid, _ = O.fov_filter(s.points.numpy(), oc, (H, W))
+        op = O.Params(bounds_hw=(H, W), fov_hw=(H, W))
+        exp[f] = O.depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], None, oc, lid, O.NUSC_CLASSES,
+                                     s.masks[0][:n].numpy().astype(np.float32), s.inst_class[0][:n].numpy(),
+                                     s.inst_box[0][:n].numpy(), op, plane_key=f, want_points=False).rows
+    lab = BatchedLabeler(batch_frames=4, lanes=2, workers=4)
+    stats = lab.run(root, ["%06d" % f for f in range(5)], os.path.join(root, "label_2"))
+    assert stats["frames"] == 5 and stats["boxes"] == sum(len(v) for v in exp.values())
+    for f in range(5):
+        objs = read_label_file(os.path.join(root, "label_2", "%06d.txt" % f))
+        assert len(objs) == len(exp[f])
+        for o, r in zip(objs, exp[f]):
+            assert o.cls_type == r.name
+            got = np.array([o.alpha, *o.box2d, o.h, o.w, o.l, *[float(v) for v in o.src.split(" ")[11:14]], o.ry])
+            np.testing.assert_allclose(got, r.as_vector(), rtol=1e-6, atol=1e-6)
 
 
 def test_integration_md_ctypes_example_runs_and_matches_oracle(monkeypatch):
