@@ -11,6 +11,7 @@ launch chain, and the label files (and, optionally, the float16 virtual-point
 files of vis_utils.py:164-166) are written by background threads.
 """
 import os
+import time
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import List, Optional
@@ -38,13 +39,46 @@ class Frame:
     image: Optional[np.ndarray] = None   # (H,W,3) u8, only for the virtual-point file
 
 
+def _npz_arrays(path):
+    """np.load(path) for a .npz without pickles, but each member is inflated by ONE zlib call
+    (zipfile's chunked reader holds the GIL most of the time, which serialises the reader threads)."""
+    import io
+    import struct
+    import zipfile
+    import zlib
+    out = {}
+    with open(path, 'rb') as fh, zipfile.ZipFile(fh) as zf:
+        for info in zf.infolist():
+            fh.seek(info.header_offset)
+            hdr = fh.read(30)
+            n_name, n_extra = struct.unpack('<HH', hdr[26:30])
+            fh.seek(info.header_offset + 30 + n_name + n_extra)
+            raw = fh.read(info.compress_size)
+            if info.compress_type == zipfile.ZIP_DEFLATED:
+                raw = zlib.decompress(raw, -15, info.file_size)
+            elif info.compress_type != zipfile.ZIP_STORED:
+                raise ValueError("%s: unsupported zip compression %d" % (path, info.compress_type))
+            bio = io.BytesIO(raw)
+            major, _ = np.lib.format.read_magic(bio)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(bio) if major == 1
+                                     else np.lib.format.read_array_header_2_0(bio))
+            if dtype.hasobject:
+                raise ValueError("%s: object arrays are not accepted" % path)
+            a = np.frombuffer(raw, dtype=dtype, offset=bio.tell(), count=int(np.prod(shape, dtype=np.int64)))
+            out[info.filename[:-4] if info.filename.endswith('.npy') else info.filename] = \
+                a.reshape(shape, order='F' if fortran else 'C')
+    return out
+
+
 def read_frame(root, stem, depth_dir=None, want_image=False, score_min=0.7) -> Frame:
     """One frame of the directory layout written by dfu3d_amd.kitti_io.write_frame."""
     pts = np.fromfile(os.path.join(root, 'velodyne', stem + '.bin'), dtype=np.float32).reshape(-1, 4)
     calib = Calibration(os.path.join(root, 'calib', stem + '.txt'))
     depth = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), stem + '.npy')).astype(np.float32, copy=False)
-    z = np.load(os.path.join(root, 'seg_2', stem + '.npz'), allow_pickle=False)
+    z = _npz_arrays(os.path.join(root, 'seg_2', stem + '.npz'))
     keep = z['scores'] > score_min                                  # vis_utils.py:218
+    if keep.all():
+        keep = slice(None)
     image = None
     if want_image:
         from PIL import Image
@@ -69,7 +103,8 @@ class BatchedLabeler:
         self.want_points = bool(want_points)
         self._engines = {}
         self._copy_stream = torch.cuda.Stream(self.dev)
-        self.stats = {"frames": 0, "boxes": 0}
+        self._stage = {}
+        self.stats = {"frames": 0, "boxes": 0, "t_read": 0.0, "t_pack": 0.0, "t_wait": 0.0, "t_gpu": 0.0}
 
     # ------------------------------------------------------------------
     def _engine(self, H, W, M):
@@ -88,7 +123,22 @@ class BatchedLabeler:
             self._engines[key] = e
         return e
 
-    def _pack(self, frames: List[Frame]):
+    def _staging(self, slot, B, H, W, M):
+        """Pinned host buffers, two sets used alternately and kept for the whole run
+        (page-locking hundreds of MB per batch costs more than the batch itself)."""
+        st = self._stage.get(slot)
+        if st is None or st["shape"][:3] != (B, H, W) or st["shape"][3] < M:
+            st = {"shape": (B, H, W, M),
+                  "pts": torch.empty((B * self.cap_n, 4), dtype=torch.float32).pin_memory(),
+                  "depth": torch.zeros((B, H, W), dtype=torch.float32).pin_memory(),
+                  "masks": torch.zeros(B * M * H * W, dtype=torch.uint8).pin_memory(),
+                  "done": None}
+            self._stage[slot] = st
+        if st["done"] is not None:
+            st["done"].synchronize()                   # the upload that last read these buffers
+        return st
+
+    def _pack(self, frames: List[Frame], slot, pool):
         """Frames -> pinned host tensors -> device ViewBatch (async on the copy stream)."""
         B = self.B
         H, W = frames[0].depth.shape
@@ -97,13 +147,27 @@ class BatchedLabeler:
         for f in frames:
             if f.points.shape[0] > self.cap_n:
                 raise ValueError("%s: %d LiDAR points exceed cap_n=%d" % (f.stem, f.points.shape[0], self.cap_n))
+            if f.depth.shape != (H, W):
+                raise ValueError("%s: depth %s differs from the batch's %s" % (f.stem, f.depth.shape, (H, W)))
         n_pts = [f.points.shape[0] for f in frames] + [0] * (B - len(frames))
         off = np.zeros(B + 1, np.int64)
         off[1:] = np.cumsum(n_pts)
-        pin = lambda *s, dt: torch.empty(s, dtype=dt).pin_memory()
-        pts = pin(max(int(off[-1]), 1), 4, dt=torch.float32)
-        depth = pin(B, H, W, dt=torch.float32)
-        masks = torch.zeros((B, M, H, W), dtype=torch.uint8).pin_memory()
+        st = self._staging(slot, B, H, W, M)
+        pts = st["pts"][:max(int(off[-1]), 1)]
+        depth = st["depth"]
+        masks = st["masks"][:B * M * H * W].view(B, M, H, W)
+        pts_np, depth_np, masks_np = pts.numpy(), depth.numpy(), masks.numpy()
+
+        def fill(i):                                   # big memcpys, in parallel on the reader pool
+            f = frames[i]
+            m = min(f.masks.shape[0], M)
+            np.copyto(pts_np[off[i]:off[i + 1]], f.points)
+            np.copyto(depth_np[i], f.depth)
+            if m:
+                np.copyto(masks_np[i, :m], f.masks[:m])
+        list(pool.map(fill, range(len(frames))))
+        if len(frames) < B:
+            depth[len(frames):].zero_()                # padded views: no pixels, no points, no instances
         calib = torch.zeros((B, 48), dtype=torch.float32)
         n_inst = torch.zeros(B, dtype=torch.int32)
         cls = torch.zeros((B, M), dtype=torch.int32)
@@ -113,19 +177,12 @@ class BatchedLabeler:
         box = torch.zeros((B, M, 4), dtype=torch.float32)
         score = torch.zeros((B, M), dtype=torch.float32)
         key = torch.zeros(B, dtype=torch.int64)
-        depth.zero_()
         for i, f in enumerate(frames):
-            if f.depth.shape != (H, W):
-                raise ValueError("%s: depth %s differs from the batch's %s" % (f.stem, f.depth.shape, (H, W)))
             m = min(f.masks.shape[0], M)
-            pts[off[i]:off[i + 1]] = torch.from_numpy(f.points[:n_pts[i]])
-            depth[i] = torch.from_numpy(f.depth)
-            if m:
-                masks[i, :m] = torch.from_numpy(f.masks[:m])
             calib[i] = torch.from_numpy(f.calib.record())
             n_inst[i] = m
-            names = [f.thing_classes[int(c)] for c in f.classes[:m]]
-            for j, nm in enumerate(names):
+            for j in range(m):
+                nm = f.thing_classes[int(f.classes[j])]
                 cls[i, j] = int(f.classes[j])
                 car[i, j] = 1 if nm == "Car" else 0
                 rl[i, j], rp[i, j] = self.p.instance_radii(nm)
@@ -137,13 +194,16 @@ class BatchedLabeler:
         with torch.cuda.stream(self._copy_stream):
             g = lambda t: t.to(d, non_blocking=True)
             vb = ViewBatch(points=g(pts), pt_off=g(torch.from_numpy(off).to(torch.int32)),
-                           view_frame=torch.arange(B, dtype=torch.int32, device=d), calib=g(calib),
-                           masks=g(masks), n_inst=g(n_inst), inst_class=g(cls), inst_is_car=g(car),
-                           inst_r_lidar=g(rl), inst_r_pseudo=g(rp), inst_box=g(box), inst_score=g(score),
-                           view_key=g(key), host_pt_off=off, host_view_frame=np.arange(B), depth=g(depth))
+                           view_frame=torch.arange(B, dtype=torch.int32, device=d), calib=g(calib.pin_memory()),
+                           masks=g(masks), n_inst=g(n_inst.pin_memory()), inst_class=g(cls.pin_memory()),
+                           inst_is_car=g(car.pin_memory()), inst_r_lidar=g(rl.pin_memory()),
+                           inst_r_pseudo=g(rp.pin_memory()), inst_box=g(box.pin_memory()),
+                           inst_score=g(score.pin_memory()), view_key=g(key.pin_memory()),
+                           host_pt_off=off, host_view_frame=np.arange(B), depth=g(depth))
             ready = torch.cuda.Event()
             ready.record(self._copy_stream)
-        return vb, ready, (H, W, M), (pts, depth, masks)      # keep the pinned buffers alive
+        st["done"] = ready
+        return vb, ready, (H, W, M)
 
     def _write(self, frames, rows_h, label_out, npy_out, vp):
         for i, f in enumerate(frames):
@@ -186,10 +246,15 @@ class BatchedLabeler:
         return out
 
     # ------------------------------------------------------------------
-    def _prepare(self, root, batch, depth_dir, pool):
+    def _prepare(self, root, batch, depth_dir, pool, slot):
         torch.cuda.set_device(self.dev)
+        t0 = time.perf_counter()
         frames = list(pool.map(lambda s: read_frame(root, s, depth_dir, self.want_points), batch))
-        return frames, self._pack(frames)
+        t1 = time.perf_counter()
+        packed = self._pack(frames, slot, pool)
+        self.stats["t_read"] += t1 - t0
+        self.stats["t_pack"] += time.perf_counter() - t1
+        return frames, packed
 
     def run(self, root, stems: List[str], label_out, depth_dir=None, npy_out=None):
         os.makedirs(label_out, exist_ok=True)
@@ -203,11 +268,14 @@ class BatchedLabeler:
         prep = ThreadPoolExecutor(1)                  # reads + packs + uploads the NEXT batch
         writers = ThreadPoolExecutor(2)
         pending = []
-        fut = prep.submit(self._prepare, root, batches[0], depth_dir, pool)
+        fut = prep.submit(self._prepare, root, batches[0], depth_dir, pool, 0)
         for bi in range(len(batches)):
-            frames, (vb, ready, (H, W, M), keep) = fut.result()
+            t0 = time.perf_counter()
+            frames, (vb, ready, (H, W, M)) = fut.result()
+            t1 = time.perf_counter()
+            self.stats["t_wait"] += t1 - t0
             if bi + 1 < len(batches):
-                fut = prep.submit(self._prepare, root, batches[bi + 1], depth_dir, pool)
+                fut = prep.submit(self._prepare, root, batches[bi + 1], depth_dir, pool, (bi + 1) & 1)
             eng = self._engine(H, W, M)
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_event(ready)
@@ -219,11 +287,11 @@ class BatchedLabeler:
                 from .stages import status_message
                 raise RuntimeError("device status: " + status_message(status))
             rows_h = rows.cpu().numpy()
+            self.stats["t_gpu"] += time.perf_counter() - t1
             vp = self._virtual_points(eng, vb, frames) if self.want_points else None
             pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp))
             self.stats["frames"] += len(frames)
             self.stats["boxes"] += int(rows_h.shape[0])
-            del keep
         for p_ in pending:
             p_.result()
         for ex in (pool, prep, writers):
