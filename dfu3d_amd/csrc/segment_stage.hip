@@ -133,56 +133,111 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 }
 
 // ---------------------------------------------------------------- a10 radius
-// Phase A: every query sweeps only the 1024-point tile it lives in (its
-// neighbours in input order).  With nb_points = 1 that settles all but the
-// isolated points; those (and only those) are appended to a queue.
+// Phase A (streaming, no LDS): a query is first tested against itself and its
+// two nearest list neighbours (lane^1, lane^2) -- the lists are in pixel / sweep
+// order, so list neighbours are spatial neighbours and nb_points = 1 is settled
+// right there for ~98 % of the points.  If a lane of the wave is still
+// undecided, eight of the wave's points are broadcast one by one (v_readlane,
+// scalar operands) until every lane has its nb_points+1 distinct hits.
+// Whatever is still undecided is collected in a workgroup-local LDS list and
+// appended with one global atomic to the queue of phase B, which sees the whole
+// segment.
+// Each workgroup walks RF_TPB consecutive query tiles: one binary search, then a
+// linear step from segment to segment.
+constexpr int RF_TPB = 8;
+constexpr int RF_LONG = 2048;      // phase B hands segments longer than this to a whole workgroup
+constexpr int RF_STRIDE = 8;       // phase A tries lanes 0, 8, 16, ... of the wave
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(QT) void k_radius_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ seg_base,
     const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S,
     const int *__restrict__ tile_off, uint8_t *__restrict__ flags, int *__restrict__ queue) {
-  __shared__ double sx[PT], sy[PT], sz[PT];
-  const int t = blockIdx.x;
-  if (t >= tile_off[S]) return;
-  const int s = find_segment(tile_off, S, t);
-  const int q0 = (t - tile_off[s]) * QT;
-  const int n = seg_cnt[s];
-  const long long base = seg_base[s];
-  const double r = radius[s];
-  const int q = q0 + threadIdx.x;
-  const bool valid = q < n;
-  if (!(r > 0.0)) {                 // r == 0: no filter; r < 0 (or NaN): drop all
-    if (valid) flags[base + q] = (r == 0.0) ? 1 : 0;
-    return;
-  }
-  const double r2 = r * r;
-  const int j0 = (q0 / PT) * PT;
-  const int m = min(PT, n - j0);
-  for (int i = threadIdx.x; i < m; i += QT) {
-    sx[i] = px[base + j0 + i];
-    sy[i] = py[base + j0 + i];
-    sz[i] = pz[base + j0 + i];
-  }
+  __shared__ int2 s_list[RF_TPB * QT];
+  __shared__ int s_n, s_base;
+  const int ntile = tile_off[S];
+  int t = blockIdx.x * RF_TPB;
+  if (t >= ntile) return;
+  if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  if (!valid) return;
-  const double x = sx[q - j0], y = sy[q - j0], z = sz[q - j0];
-  int cnt = 0;
-  for (int j = 0; j < m; j++) {
-    const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
-    double d = dx * dx;
-    d += dy * dy;
-    d += dz * dz;
-    if (d < r2) {
-      if (++cnt > nb) break;
+  const int t_end = min(t + RF_TPB, ntile);
+  int s = find_segment(tile_off, S, t);
+  const int lane = lane_id();
+  const int w_in_tile = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  for (; t < t_end; t++) {
+    while (tile_off[s + 1] <= t) s++;
+    const int n = seg_cnt[s];
+    const long long base = seg_base[s];
+    const double r = radius[s];
+    const int w0 = (t - tile_off[s]) * QT + w_in_tile;     // first point of this wave (uniform)
+    if (w0 >= n) continue;
+    const int q = w0 + lane;
+    const bool valid = q < n;
+    if (!(r > 0.0)) {               // r == 0: no filter; r < 0 (or NaN): drop all
+      if (valid) flags[base + q] = (r == 0.0) ? 1 : 0;
+      continue;
+    }
+    const double r2 = r * r;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
+    const int wn = min(64, n - w0);
+    // self + the two nearest list neighbours (quad permutes, no LDS traffic)
+    int cnt = 0;
+    {
+      const int l1 = lane ^ 1, l2 = lane ^ 2;
+      const double x1 = shfl_xor_d(x, 1), y1 = shfl_xor_d(y, 1), z1 = shfl_xor_d(z, 1);
+      const double x2 = shfl_xor_d(x, 2), y2 = shfl_xor_d(y, 2), z2 = shfl_xor_d(z, 2);
+      double dx = x - x1, dy = y - y1, dz = z - z1;
+      double d = dx * dx;
+      d += dy * dy;
+      d += dz * dz;
+      cnt = 1 + ((l1 < wn && d < r2) ? 1 : 0);                 // self: d == 0 < r2
+      dx = x - x2; dy = y - y2; dz = z - z2;
+      d = dx * dx;
+      d += dy * dy;
+      d += dz * dz;
+      cnt += (l2 < wn && d < r2) ? 1 : 0;
+    }
+    // undecided lanes: a few of the wave's points, broadcast as scalar operands
+    // (v_readlane), are tried by all of them at once; what is left after that is
+    // almost surely isolated and goes to phase B
+    if (__ballot(valid && cnt <= nb)) {
+      const int l1 = lane ^ 1, l2 = lane ^ 2;
+      for (int j = 0; j < wn; j += RF_STRIDE) {
+        const double dx = x - readlane_d(x, j), dy = y - readlane_d(y, j), dz = z - readlane_d(z, j);
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (d < r2 && j != lane && j != l1 && j != l2) cnt++;   // never count a point twice
+        if (__ballot(valid && cnt <= nb) == 0ull) break;
+      }
+    }
+    const bool pending = valid && cnt <= nb;       // a lower bound that did not reach nb_points + 1
+    if (valid && !pending) flags[base + q] = 1;
+    const unsigned long long pm = __ballot(pending);
+    if (pm) {                       // block-local list (LDS), one LDS atomic per wave
+      int slot0 = 0;
+      if (lane == 0) slot0 = atomicAdd(&s_n, __popcll(pm));
+      slot0 = __builtin_amdgcn_readfirstlane(slot0);
+      if (pending) {
+        const int slot = slot0 + __popcll(pm & ((1ull << lane) - 1ull));
+        s_list[slot] = make_int2(s, q);
+      }
     }
   }
-  if (cnt > nb || n <= PT) {
-    flags[base + q] = (cnt > nb) ? 1 : 0;
-  } else {                          // undecided: the rest of the segment must be seen
-    const int slot = atomicAdd(&queue[0], 1);
-    queue[2 + 2 * slot] = s;
-    queue[3 + 2 * slot] = q;
-  }
+  __syncthreads();
+  const int np = s_n;
+  if (np == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&queue[0], np);        // one global atomic per workgroup
+  __syncthreads();
+  int2 *out = (int2 *)(queue + 2) + s_base;
+  for (int i = threadIdx.x; i < np; i += QT) out[i] = s_list[i];
 }
 
 // Phase B: one wave per undecided query; the 64 lanes stride the whole segment
@@ -191,7 +246,7 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ seg_base,
     const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb,
-    uint8_t *__restrict__ flags, const int *__restrict__ queue) {
+    uint8_t *__restrict__ flags, int *__restrict__ queue, long long pool_cap) {
   const int nq = queue[0];
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
@@ -202,9 +257,12 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
     const long long base = seg_base[s];
     const double r = radius[s], r2 = r * r;
     const double x = px[base + q], y = py[base + q], z = pz[base + q];
+    // own 64-point chunk first (list neighbours are near), then the rest of the
+    // segment RU chunks at a time so that the loads of one step overlap
     int cnt = 0;
-    for (int j0 = 0; j0 < n && cnt <= nb; j0 += 64) {
-      const int j = j0 + lane;
+    const int c0 = q >> 6;
+    {
+      const int j = (c0 << 6) + lane;
       bool hit = false;
       if (j < n) {
         const double dx = x - px[base + j], dy = y - py[base + j], dz = z - pz[base + j];
@@ -213,9 +271,105 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
         d += dz * dz;
         hit = d < r2;
       }
-      cnt += __popcll(__ballot(hit));
+      cnt = __popcll(__ballot(hit));
     }
-    if (lane == 0) flags[base + q] = (cnt > nb) ? 1 : 0;
+    constexpr int RU = 4;
+    // then outwards from the own chunk, RU chunks per step (their loads overlap).  A long
+    // segment that did not settle in the first step is swept by a whole workgroup
+    // (k_radius_resolve_long); its entry moves to the top end of the queue
+    bool handed = false;
+    const int nch = (n + 63) >> 6;
+    int lo = c0 - 1, hi = c0 + 1;
+    for (int step = 0; (lo >= 0 || hi < nch) && cnt <= nb; step++) {
+      if (step == 1 && n > RF_LONG) {
+        int h = 0;
+        if (lane == 0) h = atomicAdd(&queue[1], 1);
+        h = __builtin_amdgcn_readfirstlane(h);
+        if ((long long)nq + h + 1 <= pool_cap) {           // room left (always, in practice)
+          if (lane == 0) {
+            queue[2 + 2 * (pool_cap - 1 - h)] = s;
+            queue[3 + 2 * (pool_cap - 1 - h)] = q;
+          }
+          handed = true;
+          break;
+        }
+      }
+      double cx[RU], cy[RU], cz[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        int c;                                            // uniform: next chunk above / below in turn
+        if (u & 1) c = (lo >= 0) ? lo-- : ((hi < nch) ? hi++ : -1);
+        else c = (hi < nch) ? hi++ : ((lo >= 0) ? lo-- : -1);
+        const int j = (c << 6) + lane;
+        const bool ok = (c >= 0) && (j < n);
+        cx[u] = ok ? px[base + j] : __builtin_nan("");
+        cy[u] = ok ? py[base + j] : 0.0;
+        cz[u] = ok ? pz[base + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const double dx = x - cx[u], dy = y - cy[u], dz = z - cz[u];
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        cnt += __popcll(__ballot(d < r2));                 // NaN never compares below r2
+      }
+    }
+    if (lane == 0 && !handed) flags[base + q] = (cnt > nb) ? 1 : 0;
+  }
+}
+
+// Phase B': one workgroup per query that is (almost surely) isolated in a long
+// segment: 1024 candidates per step, leaves (all waves together) as soon as the
+// count is reached.
+__global__ __launch_bounds__(256) void k_radius_resolve_long(
+    const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, const long long *__restrict__ seg_base,
+    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb,
+    uint8_t *__restrict__ flags, const int *__restrict__ queue, long long pool_cap) {
+  __shared__ int s_cnt;
+  const int nq = queue[0];
+  long long nh = queue[1];
+  if (nh > pool_cap - nq) nh = pool_cap - nq;             // entries beyond that were resolved inline
+  const int lane = lane_id();
+  for (long long e = blockIdx.x; e < nh; e += gridDim.x) {
+    const int s = queue[2 + 2 * (pool_cap - 1 - e)], q = queue[3 + 2 * (pool_cap - 1 - e)];
+    const int n = seg_cnt[s];
+    const long long base = seg_base[s];
+    const double r = radius[s], r2 = r * r;
+    const double x = px[base + q], y = py[base + q], z = pz[base + q];
+    if (threadIdx.x == 0) s_cnt = 1;                      // the query itself (d = 0 < r2)
+    __syncthreads();
+    // outwards from the query: per step 512 list positions above and 512 below it
+    constexpr int RU = 4;
+    int c = 1;
+    const int reach = max(q, n - 1 - q);
+    for (int k0 = 0; k0 < reach && c <= nb; k0 += 512) {
+      double cx[RU], cy[RU], cz[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int off = k0 + 1 + (u >> 1) * 256 + (int)threadIdx.x;     // 1 .. 512 beyond k0
+        const int j = (u & 1) ? q - off : q + off;
+        const bool ok = (j >= 0) && (j < n);
+        cx[u] = ok ? px[base + j] : __builtin_nan("");
+        cy[u] = ok ? py[base + j] : 0.0;
+        cz[u] = ok ? pz[base + j] : 0.0;
+      }
+      int h = 0;
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const double dx = x - cx[u], dy = y - cy[u], dz = z - cz[u];
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        h += __popcll(__ballot(d < r2));
+      }
+      if (lane == 0 && h) atomicAdd(&s_cnt, h);
+      __syncthreads();
+      c = s_cnt;                                         // the same value for every thread ...
+      __syncthreads();                                   // ... because nobody adds before all have read
+    }
+    if (threadIdx.x == 0) flags[base + q] = (c > nb) ? 1 : 0;
   }
 }
 
@@ -538,14 +692,19 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_FLAGS) {
-    hipLaunchKernelGGL(k_radius_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+    hipLaunchKernelGGL(k_radius_flags, dim3((tile_grid(pool_cap, S) + RF_TPB - 1) / RF_TPB), dim3(QT), 0, st, px, py, pz,
                        (const long long *)seg_base, seg_cnt, radius, nb_points, S, tile_off, flags,
                        queue);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
     hipLaunchKernelGGL(k_radius_resolve, dim3(2048), dim3(256), 0, st, px, py, pz,
-                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue);
+                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue,
+                       (long long)pool_cap);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_radius_resolve_long, dim3(2048), dim3(256), 0, st, px, py, pz,
+                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue,
+                       (long long)pool_cap);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {

@@ -29,6 +29,22 @@ def fit(c):
                   b.inst_is_car.reshape(-1), b.inst_box.reshape(-1), b.inst_score.reshape(-1), eng.n_theta, eng.dtheta,
                   p.car_aspect_max, eng.sx, eng.sy, eng.sroot, eng.cap_rows, rows_b, nr, stt, eng.pool_cap)
 print("lshape_fit all: %.3f ms" % timeit(lambda: fit(cnt)))
+# cluster-size histogram over the whole batch
+sizes_all = []
+cn = cnt.cpu().numpy(); ba = eng.base_a.cpu().numpy(); lab_all = eng.label.cpu().numpy()
+nclus = []
+for s_ in range(S):
+    if cn[s_] == 0: continue
+    l = lab_all[ba[s_]:ba[s_] + cn[s_]]
+    u, c = np.unique(l, return_counts=True)
+    sizes_all += c.tolist(); nclus.append(len(u))
+sizes_all = np.array(sizes_all)
+print("segments %d (nonempty %d), points %d, clusters %d, clusters/segment mean %.2f max %d" % (S, (cn > 0).sum(), cn.sum(), len(sizes_all), np.mean(nclus), max(nclus)))
+print("segment size pct 10/50/90/99/max:", np.percentile(cn[cn > 0], [10, 50, 90, 99, 100]).astype(int))
+print("cluster size pct 10/50/90/99/max:", np.percentile(sizes_all, [10, 50, 90, 99, 100]).astype(int))
+for lo, hi in ((1, 1), (2, 8), (9, 64), (65, 256), (257, 1024), (1025, 4096), (4097, 1 << 30)):
+    k = (sizes_all >= lo) & (sizes_all <= hi)
+    print("  clusters with %5d..%-10d members: %6d  (points %8d)" % (lo, hi, k.sum(), sizes_all[k].sum()))
 order = torch.argsort(cnt, descending=True).tolist()
 for s_ in order[:10]:
     one = torch.zeros_like(cnt); one[s_] = cnt[s_]
