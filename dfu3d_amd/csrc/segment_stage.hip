@@ -396,7 +396,7 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
     const double *__restrict__ pz, const long long *__restrict__ base_a,
     const int *__restrict__ cnt_a, const long long *__restrict__ base_b,
     const int *__restrict__ cnt_b, double T, double C, int S, const int *__restrict__ tile_off,
-    uint8_t *__restrict__ flags) {
+    uint8_t *__restrict__ flags, int masked) {
   __shared__ unsigned long long s_tab[BH_SLOTS];
   __shared__ double s_red[3 * (QT / 64)];
   __shared__ int s_pending;
@@ -407,7 +407,9 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
   const int nq = cnt_b[s], na = cnt_a[s];
   const long long bq = base_b[s], ba = base_a[s];
   const int q = q0 + threadIdx.x;
-  const bool valid = q < nq;
+  // masked: flags hold the keep mask of a preceding filter that was not compacted;
+  // a dropped point is not a query and stays dropped
+  const bool valid = (q < nq) && (!masked || flags[bq + q]);
   if (na == 0) {                       // my_loader.py:602: fuse skipped
     if (valid) flags[bq + q] = 1;
     return;
@@ -510,12 +512,14 @@ __global__ __launch_bounds__(QT) void k_ball_flags(
 // In-order compaction of segment s by flags.  dst = src (in place) or, when
 // dst_after_base != nullptr, directly behind another segment
 // (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
-__global__ __launch_bounds__(256) void k_seg_compact(
+constexpr int CPT = 1024;   // threads per compaction workgroup
+constexpr int CPE = 4;      // consecutive elements per thread
+__global__ __launch_bounds__(CPT) void k_seg_compact(
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
     const uint8_t *__restrict__ flags, const long long *__restrict__ dst_after_base,
     const int *__restrict__ dst_after_cnt) {
-  __shared__ int s_w[4];
+  __shared__ int s_w[CPT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   const long long src = seg_base[s];
@@ -525,16 +529,28 @@ __global__ __launch_bounds__(256) void k_seg_compact(
     return;
   }
   int running = 0;
-  for (int t0 = 0; t0 < n; t0 += 256) {
-    const int i = t0 + threadIdx.x;
-    const bool f = (i < n) && flags[src + i];
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (f) { x = px[src + i]; y = py[src + i]; z = pz[src + i]; }
+  for (int t0 = 0; t0 < n; t0 += CPT * CPE) {
+    const int i0 = t0 + threadIdx.x * CPE;
+    bool f[CPE];
+    double x[CPE], y[CPE], z[CPE];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < CPE; k++) {
+      const int i = i0 + k;
+      f[k] = (i < n) && flags[src + i];
+      x[k] = y[k] = z[k] = 0.0;
+      if (f[k]) { x[k] = px[src + i]; y[k] = py[src + i]; z[k] = pz[src + i]; }
+      mine += f[k] ? 1 : 0;
+    }
     int tot;
-    const int r = block_rank<4>(f, s_w, tot);   // barriers: loads above complete first
-    if (f) {
-      const long long d = dst + running + r;
-      px[d] = x; py[d] = y; pz[d] = z;
+    int r = block_excl_scan<CPT / 64>(mine, s_w, tot);   // barriers: loads above complete first
+#pragma unroll
+    for (int k = 0; k < CPE; k++) {
+      if (f[k]) {
+        const long long d = dst + running + r;            // d <= src + i: never ahead of the reads
+        px[d] = x[k]; py[d] = y[k]; pz[d] = z[k];
+        r++;
+      }
     }
     running += tot;
   }
@@ -708,7 +724,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {
-    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
+    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
                        (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
                        (const int *)nullptr);
     DFU3D_LAUNCH_CHECK();
@@ -737,17 +753,17 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   hipLaunchKernelGGL(k_stat_flags, dim3(S), dim3(256), 0, st, (const long long *)seg_base,
                      seg_cnt, enable, std_ratio, mean_d, flags);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz,
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
                      (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
                      (const int *)nullptr);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
 
-extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const int64_t *base_a,
+static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t *base_a,
                                     const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
                                     double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
-                                    uint8_t *flags, void *stream) {
+                                    uint8_t *flags, int masked, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !tile_off || !flags)
     return DFU3D_EINVAL;
@@ -764,10 +780,27 @@ extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const in
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_ball_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
-                     tile_off, flags);
+                     tile_off, flags, masked);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(256), 0, st, px, py, pz, (long long *)base_b,
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz, (long long *)base_b,
                      cnt_b, flags, (const long long *)base_a, cnt_a);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
+}
+
+extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const int64_t *base_a,
+                                    const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
+                                    double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
+                                    uint8_t *flags, void *stream) {
+  return ballquery_fuse_impl(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
+                             flags, 0, stream);
+}
+
+extern "C" int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
+                                           const int64_t *base_a, const int32_t *cnt_a,
+                                           int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
+                                           int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
+                                           void *stream) {
+  return ballquery_fuse_impl(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
+                             flags, 1, stream);
 }

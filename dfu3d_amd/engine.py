@@ -220,15 +220,23 @@ class PseudoBoxEngine:
         self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
                      self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
                      self.queue)
-        self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_b,
-                     self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
-                     self.queue)
+        # pseudo lists: flags only -- the fuse below compacts once for both filters, unless the
+        # (dormant) statistical filter sits in between and needs the filtered lists
+        fused = not p.stat_filter
+        if fused and not self.timing:
+            st.radius_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, rp, p.nb_points, S,
+                             self.pool_cap, self.tile_off, self.flags, self.queue,
+                             phases=st.RF_ALL & ~st.RF_COMPACT)
+        else:
+            self._phased("rf_", st.radius_filter, rf_ph[:3] if fused else rf_ph, self.px, self.py, self.pz,
+                         self.base_b, self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off,
+                         self.flags, self.queue)
         if p.stat_filter:
             R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
                            self.tile_off, self.flags, self.mean_d)
         R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
-                          self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags)
+                          self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags, masked=fused)
         torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
         R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0,
           p.Rd, self.label, self.pool_cap, self.sx, self.sy, self.si3)

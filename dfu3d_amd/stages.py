@@ -235,8 +235,10 @@ def stat_filter(px, py, pz, seg_base, seg_cnt, enable, nb_neighbors, std_ratio, 
     _lib.check(rc, "dfu3d_stat_filter")
 
 
-def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off, flags):
-    rc = _lib.lib().dfu3d_ballquery_fuse(
+def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off, flags, masked=False):
+    """masked=True: `flags` holds the keep mask of a radius_filter call made without RF_COMPACT."""
+    fn = _lib.lib().dfu3d_ballquery_fuse_masked if masked else _lib.lib().dfu3d_ballquery_fuse
+    rc = fn(
         _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
         _chk(pz, "pz", torch.float64, numel=pool_cap),
         _chk(base_a, "base_a", torch.int64, numel=S), _chk(cnt_a, "cnt_a", torch.int32, numel=S),

@@ -182,9 +182,9 @@ int dfu3d_radius_filter(double *px, double *py, double *pz,
                         int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
                         int32_t *queue, int32_t phases, void *stream);
 #define DFU3D_RF_TILES 1    /* k_tile_scan: query-tile list, queue reset        */
-#define DFU3D_RF_FLAGS 2    /* k_radius_flags: neighbour count in the own tile  */
+#define DFU3D_RF_FLAGS 2    /* k_radius_flags: list neighbours / own wave       */
 #define DFU3D_RF_COMPACT 4  /* k_seg_compact: ordered in-place compaction       */
-#define DFU3D_RF_RESOLVE 8  /* k_radius_resolve: isolated points, whole segment */
+#define DFU3D_RF_RESOLVE 8  /* k_radius_resolve(_long): undecided, whole segment */
 #define DFU3D_RF_ALL 15
 
 /* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
@@ -208,6 +208,16 @@ int dfu3d_ballquery_fuse(double *px, double *py, double *pz,
                          int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
                          int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
                          void *stream);
+/* Same, but flags[base_b[s] + i] holds on entry the keep mask of a filter that
+ * was run without its compaction phase (dfu3d_radius_filter with
+ * phases = DFU3D_RF_ALL & ~DFU3D_RF_COMPACT): masked-out points are neither
+ * queries nor survivors, so my_loader.py:587-605 (filter, then fuse) costs one
+ * compaction of the pseudo points instead of two. */
+int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
+                                const int64_t *base_a, const int32_t *cnt_a,
+                                int64_t *base_b, int32_t *cnt_b, double C,
+                                int32_t S, int64_t pool_cap, int32_t *tile_off,
+                                uint8_t *flags, void *stream);
 
 /* ---- a13: _adoptive_range_segmentation (rectangle_fitting.py:161-191) ------
  * label[seg_base[s] + i] = smallest in-segment index of the cluster that

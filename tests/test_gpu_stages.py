@@ -139,6 +139,54 @@ def test_ballquery_fuse_matches_oracle(st):
         assert np.array_equal(X[base_a[s]:base_a[s] + len(exp)], exp), s
 
 
+def test_masked_ballquery_equals_filter_then_fuse(st):
+    """radius filter without its compaction + dfu3d_ballquery_fuse_masked == the two stages one after the
+    other (my_loader.py:587-605), checked against the oracle's filter and fuse."""
+    rng = np.random.default_rng(121)
+    cases = [(0, 40), (30, 0), (60, 700), (900, 4000), (5, 5), (4200, 3000)]
+    segsA, segsB = [], []
+    for na, nb in cases:
+        a = rng.normal(0, 2.0, (na, 3))
+        b = rng.normal(0, 2.0, (nb, 3))
+        if na and nb:
+            h = nb // 2
+            b[:h] = a[rng.integers(0, na, h)] + rng.normal(0, 0.06, (h, 3))
+            far = rng.random(nb) < 0.2                              # isolated pseudo points: the filter drops them
+            b[far] = rng.uniform(-300, 300, (int(far.sum()), 3))
+        segsA.append(a)
+        segsB.append(b)
+    chunks, base_a, base_b, cur = [], [], [], 0
+    for a, b in zip(segsA, segsB):
+        base_a.append(cur); cur += len(a)
+        base_b.append(cur); cur += len(b)
+        chunks += [a, b]
+    P = np.concatenate(chunks)
+    cap = len(P) + 16
+    Pp = np.full((cap, 3), 9.0); Pp[:len(P)] = P
+    px, py, pz = _t(Pp[:, 0]), _t(Pp[:, 1]), _t(Pp[:, 2])
+    S = len(cases)
+    cnt_a = _t(np.array([len(a) for a in segsA], np.int32))
+    cnt_b = _t(np.array([len(b) for b in segsB], np.int32))
+    ta, tb = _t(np.array(base_a, np.int64)), _t(np.array(base_b, np.int64))
+    radius = _t(np.array([0.6, 3.0, 0.6, 3.0, 0.6, 3.0]))
+    tile_off = torch.zeros(S + 1, dtype=torch.int32, device=DEV)
+    flags = torch.zeros(cap, dtype=torch.uint8, device=DEV)
+    queue = torch.zeros(2 + 2 * cap, dtype=torch.int32, device=DEV)
+    st.radius_filter(px, py, pz, tb, cnt_b, radius, 1, S, cap, tile_off, flags, queue,
+                     phases=st.RF_ALL & ~st.RF_COMPACT)
+    st.ballquery_fuse(px, py, pz, ta, cnt_a, tb, cnt_b, 0.1, S, cap, tile_off, flags, masked=True)
+    torch.cuda.synchronize()
+    X = torch.stack([px, py, pz], 1).cpu().numpy()
+    ncb = cnt_b.cpu().numpy()
+    r = radius.cpu().numpy()
+    for s, (a, b) in enumerate(zip(segsA, segsB)):
+        b1 = b[O.radius_outlier(b, 1, r[s])] if len(b) else b
+        keep = O.ball_query(b1, a, 0.1) if len(a) and len(b1) else np.ones(len(b1), bool)
+        exp = np.concatenate([a, b1[keep]])
+        assert ncb[s] == keep.sum(), s
+        assert np.array_equal(X[base_a[s]:base_a[s] + len(exp)], exp), s
+
+
 # ------------------------------------------------------------------ a11
 def test_stat_filter_matches_oracle(st):
     rng = np.random.default_rng(11)
