@@ -108,12 +108,12 @@ __global__ __launch_bounds__(256) void k_seg_write(
 
 // ---------------------------------------------------------------- tiles
 __global__ __launch_bounds__(1024) void k_tile_scan(int S, const int *__restrict__ cnt,
-                                                    int *__restrict__ tile_off) {
+                                                    int *__restrict__ tile_off, int qt) {
   __shared__ int s_w[16];
   int running = 0;
   for (int b0 = 0; b0 < S; b0 += 1024) {
     const int s = b0 + threadIdx.x;
-    const int nt = (s < S) ? (cnt[s] + QT - 1) / QT : 0;
+    const int nt = (s < S) ? (cnt[s] + qt - 1) / qt : 0;
     int tot;
     const int ex = block_excl_scan<16>(nt, s_w, tot);
     if (s < S) tile_off[s] = running + ex;
@@ -374,138 +374,169 @@ __global__ __launch_bounds__(256) void k_radius_resolve_long(
 }
 
 // ---------------------------------------------------------------- a12 ball query
-// exists-within-C with a spatial hash: the instance's LiDAR points (at most a
-// few thousand) are hashed by their cell of side c = C(1+1e-6) into an LDS
-// multimap (open addressing, one 64-bit word per point: 3 x 16-bit cell | 16-bit
-// index); a pseudo point looks at the 27 cells around its own and evaluates the
-// reference's predicate only on the points it finds there (d2 < T <=> sqrt(d2) < C).
-// Any point closer than C lies in one of those cells, so the answer is exact.
-// Instances with more LiDAR points than the table holds use the brute-force tile loop.
-constexpr int BH_SLOTS = 8192;                 // 64 KB of LDS
-constexpr int BH_MAX = 4096;                   // load factor <= 0.5
-constexpr unsigned long long BH_EMPTY = ~0ull;
+// exists-within-C with a spatial hash.  Coordinates are quantised to units of
+// u = C(1+1e-5)/16 (17 bits per axis, +-409 m for C = 0.1); a cell is 32 units
+// = 2C(1+1e-5) wide.  The instance's LiDAR points (at most 4096) are chained
+// per cell in LDS: head[hash(cell)] -> node -> node ..., a node being ONE 64-bit
+// word (3 x 17-bit quantised coordinate | 13-bit next link), so that a dense
+// cell costs one LDS read per point and no probing.  A pseudo point q can only
+// be within C of points whose cells meet [q-C', q+C'] (C' = C(1+1e-6)): at most
+// two cells per axis, and because fp rounding of the quantisation is monotone no
+// candidate is missed.  For every node on those chains the quantised
+// coordinates give a lower bound of the distance that discards almost every
+// non-neighbour without touching memory; the rest is decided by the
+// reference's predicate on the fp64 coordinates (d2 < T <=> sqrt(d2) < C).
+// A workgroup of 1024 threads walks BQ_TPB consecutive 1024-query tiles and
+// rebuilds the table only when the instance changes.  Instances with more
+// LiDAR points than the table holds, or beyond the quantised range, use the
+// brute-force tile loop.
+constexpr int BT = 1024;                       // queries per tile = threads per workgroup
+constexpr int BH_HEADS = 8192;                 // 32 KB of LDS
+constexpr int BH_MAX = 4096;                   // nodes: 32 KB of LDS; 12-bit index
+constexpr int BQ_TPB = 4;
 
 __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
   uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
   h ^= h >> 15;
-  return h & (BH_SLOTS - 1);
+  return h;
 }
 
-__global__ __launch_bounds__(QT) void k_ball_flags(
+__global__ __launch_bounds__(BT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ base_a,
     const int *__restrict__ cnt_a, const long long *__restrict__ base_b,
     const int *__restrict__ cnt_b, double T, double C, int S, const int *__restrict__ tile_off,
     uint8_t *__restrict__ flags, int masked) {
-  __shared__ unsigned long long s_tab[BH_SLOTS];
-  __shared__ double s_red[3 * (QT / 64)];
+  __shared__ unsigned long long s_node[BH_MAX];
+  __shared__ uint32_t s_head[BH_HEADS];
   __shared__ int s_pending;
-  const int t = blockIdx.x;
-  if (t >= tile_off[S]) return;
-  const int s = find_segment(tile_off, S, t);
-  const int q0 = (t - tile_off[s]) * QT;
-  const int nq = cnt_b[s], na = cnt_a[s];
-  const long long bq = base_b[s], ba = base_a[s];
-  const int q = q0 + threadIdx.x;
-  // masked: flags hold the keep mask of a preceding filter that was not compacted;
-  // a dropped point is not a query and stays dropped
-  const bool valid = (q < nq) && (!masked || flags[bq + q]);
-  if (na == 0) {                       // my_loader.py:602: fuse skipped
-    if (valid) flags[bq + q] = 1;
-    return;
-  }
-  double x = 0.0, y = 0.0, z = 0.0;
-  if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
-  bool found = false;
-  if (na <= BH_MAX) {
-    // origin of the cell grid: component-wise minimum of the LiDAR points
-    double mx = INFINITY, my = INFINITY, mz = INFINITY;
-    for (int i = threadIdx.x; i < na; i += QT) {
-      mx = fmin(mx, px[ba + i]); my = fmin(my, py[ba + i]); mz = fmin(mz, pz[ba + i]);
+  const int ntile = tile_off[S];
+  int t = blockIdx.x * BQ_TPB;
+  if (t >= ntile) return;
+  const int t_end = min(t + BQ_TPB, ntile);
+  int s = find_segment(tile_off, S, t);
+  const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
+  const double Cq = C * (1.0 + 1e-6);
+  const double OFF = 65536.0;                    // quantised coordinates are stored with this offset
+  int hashed_s = -1;                             // segment whose LiDAR points are in the table
+  bool hash_ok = false;
+  uint32_t mask = 0;
+  for (; t < t_end; t++) {
+    while (tile_off[s + 1] <= t) s++;
+    const int q0 = (t - tile_off[s]) * BT;
+    const int nq = cnt_b[s], na = cnt_a[s];
+    const long long bq = base_b[s], ba = base_a[s];
+    const int q = q0 + threadIdx.x;
+    // masked: flags hold the keep mask of a preceding filter that was not compacted;
+    // a dropped point is not a query and stays dropped
+    const bool valid = (q < nq) && (!masked || flags[bq + q]);
+    if (na == 0) {                       // my_loader.py:602: fuse skipped
+      if (valid) flags[bq + q] = 1;
+      continue;
     }
-    mx = wave_min_d(mx); my = wave_min_d(my); mz = wave_min_d(mz);
-    if (lane_id() == 0) { s_red[3 * (threadIdx.x >> 6)] = mx; s_red[3 * (threadIdx.x >> 6) + 1] = my; s_red[3 * (threadIdx.x >> 6) + 2] = mz; }
-    for (int i = threadIdx.x; i < BH_SLOTS; i += QT) s_tab[i] = BH_EMPTY;
-    __syncthreads();
-    for (int w = 0; w < QT / 64; w++) { mx = fmin(mx, s_red[3 * w]); my = fmin(my, s_red[3 * w + 1]); mz = fmin(mz, s_red[3 * w + 2]); }
-    const double inv = 1.0 / (C * (1.0 + 1e-6));
-    // cell coordinates are offset by 1 so that the 27-neighbourhood never underflows;
-    // anything beyond 65534 cells (6.5 km) from the origin cannot be near a LiDAR point
-    bool too_wide = false;
-    for (int i = threadIdx.x; i < na; i += QT) {
-      const double fx = floor((px[ba + i] - mx) * inv), fy = floor((py[ba + i] - my) * inv),
-                   fz = floor((pz[ba + i] - mz) * inv);
-      if (!(fx < 65000.0 && fy < 65000.0 && fz < 65000.0)) { too_wide = true; continue; }
-      const uint32_t ix = (uint32_t)fx + 1u, iy = (uint32_t)fy + 1u, iz = (uint32_t)fz + 1u;
-      const unsigned long long word = (unsigned long long)ix | ((unsigned long long)iy << 16) |
-                                      ((unsigned long long)iz << 32) | ((unsigned long long)i << 48);
-      uint32_t h = bh_hash(ix, iy, iz);
-      while (atomicCAS(&s_tab[h], BH_EMPTY, word) != BH_EMPTY) h = (h + 1) & (BH_SLOTS - 1);
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
+    if (na <= BH_MAX && hashed_s != s) {         // (re)build the table -- uniform per workgroup
+      int slots = 256;
+      while (slots < 2 * na) slots <<= 1;
+      mask = (uint32_t)slots - 1u;
+      __syncthreads();                           // queries of the previous tile are done
+      for (int i = threadIdx.x; i < slots; i += BT) s_head[i] = 0u;
+      if (threadIdx.x == 0) s_pending = 0;
+      __syncthreads();
+      bool too_wide = false;
+      for (int i = threadIdx.x; i < na; i += BT) {
+        const double fx = floor(px[ba + i] * inv) + OFF, fy = floor(py[ba + i] * inv) + OFF,
+                     fz = floor(pz[ba + i] * inv) + OFF;
+        if (!(fx >= 64.0 && fy >= 64.0 && fz >= 64.0 && fx < 131000.0 && fy < 131000.0 && fz < 131000.0)) {
+          too_wide = true;
+          continue;
+        }
+        const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
+        const uint32_t prev = atomicExch(&s_head[bh_hash(ix >> 5, iy >> 5, iz >> 5) & mask], (uint32_t)i + 1u);
+        s_node[i] = (unsigned long long)ix | ((unsigned long long)iy << 17) |
+                    ((unsigned long long)iz << 34) | ((unsigned long long)prev << 51);
+      }
+      if (too_wide) s_pending = 1;
+      __syncthreads();
+      hash_ok = (s_pending == 0);
+      hashed_s = s;
     }
-    if (threadIdx.x == 0) s_pending = 0;
-    __syncthreads();
-    if (too_wide) s_pending = 1;
-    __syncthreads();
-    if (!s_pending) {
+    bool found = false;
+    if (na <= BH_MAX && hash_ok) {
       if (valid) {
-        const double fx = floor((x - mx) * inv), fy = floor((y - my) * inv), fz = floor((z - mz) * inv);
-        if (fx >= -1.0 && fy >= -1.0 && fz >= -1.0 && fx < 65001.0 && fy < 65001.0 && fz < 65001.0) {
-          const int cx = (int)fx + 1, cy = (int)fy + 1, cz = (int)fz + 1;      // >= 0
-          for (int dz = -1; dz <= 1 && !found; dz++)
-            for (int dy = -1; dy <= 1 && !found; dy++)
-              for (int dx = -1; dx <= 1 && !found; dx++) {
-                const int ux = cx + dx, uy = cy + dy, uz = cz + dz;
-                if (ux < 1 || uy < 1 || uz < 1) continue;                        // no LiDAR cell there
-                const unsigned long long key = (unsigned long long)ux | ((unsigned long long)uy << 16) |
-                                               ((unsigned long long)uz << 32);
-                uint32_t h = bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz);
-                while (true) {
-                  const unsigned long long wv = s_tab[h];
-                  if (wv == BH_EMPTY) break;
-                  if ((wv & 0xFFFFFFFFFFFFull) == key) {
-                    const int j = (int)(wv >> 48);
+        // quantised range [q - C', q + C'] on each axis (NaN / far-away queries fail the range test)
+        const double lx = floor((x - Cq) * inv) + OFF, hx = floor((x + Cq) * inv) + OFF;
+        const double ly = floor((y - Cq) * inv) + OFF, hy = floor((y + Cq) * inv) + OFF;
+        const double lz = floor((z - Cq) * inv) + OFF, hz = floor((z + Cq) * inv) + OFF;
+        // stored coordinates lie in [64, 131000); a range that misses [0, 131071] entirely
+        // (or is NaN / infinite) cannot contain one
+        if (hx >= 0.0 && hy >= 0.0 && hz >= 0.0 && lx <= 131071.0 && ly <= 131071.0 && lz <= 131071.0) {
+          const int x0 = (int)fmax(lx, 0.0) >> 5, x1 = (int)fmin(hx, 131071.0) >> 5;
+          const int y0 = (int)fmax(ly, 0.0) >> 5, y1 = (int)fmin(hy, 131071.0) >> 5;
+          const int z0 = (int)fmax(lz, 0.0) >> 5, z1 = (int)fmin(hz, 131071.0) >> 5;
+          // the query's own quantised position; a query outside the quantised range skips the
+          // lower bound and tests every node of its chains exactly
+          const double fqx = floor(x * inv) + OFF, fqy = floor(y * inv) + OFF, fqz = floor(z * inv) + OFF;
+          const bool qin = fqx >= 0.0 && fqy >= 0.0 && fqz >= 0.0 && fqx <= 131071.0 && fqy <= 131071.0 && fqz <= 131071.0;
+          const int qx = qin ? (int)fqx : 0, qy = qin ? (int)fqy : 0, qz = qin ? (int)fqz : 0;
+          for (int uz = z0; uz <= z1 && !found; uz++)
+            for (int uy = y0; uy <= y1 && !found; uy++)
+              for (int ux = x0; ux <= x1 && !found; ux++) {
+                uint32_t node = s_head[bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz) & mask];
+                while (node) {
+                  const unsigned long long wv = s_node[node - 1u];
+                  const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
+                            az = (int)((wv >> 34) & 0x1FFFFull);
+                  // each quantised difference is within 1 (+3e-11) unit of the true one, so the
+                  // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
+                  // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
+                  const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
+                            ez_ = max(abs(az - qz) - 1, 0);
+                  if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
+                    const int j = (int)node - 1;
                     const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
                     double d = ex * ex;
                     d += ey * ey;
                     d += ez * ez;
                     if (d < T) { found = true; break; }      // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
                   }
-                  h = (h + 1) & (BH_SLOTS - 1);
+                  node = (uint32_t)(wv >> 51);
                 }
               }
         }
         flags[bq + q] = found ? 1 : 0;
       }
-      return;
+      continue;
     }
-    __syncthreads();
-  }
-  // brute force over LDS tiles (more LiDAR points than the hash holds, or a huge extent)
-  double *sx = (double *)s_tab, *sy = sx + PT, *sz = sy + PT;     // 24 KB of the table's LDS
-  for (int j0 = 0; j0 < na; j0 += PT) {
-    const int m = min(PT, na - j0);
-    __syncthreads();
-    if (threadIdx.x == 0) s_pending = 0;
-    for (int i = threadIdx.x; i < m; i += QT) {
-      sx[i] = px[ba + j0 + i];
-      sy[i] = py[ba + j0 + i];
-      sz[i] = pz[ba + j0 + i];
-    }
-    __syncthreads();
-    if (valid && !found) {
-      for (int j = 0; j < m; j++) {
-        const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        if (d < T) { found = true; break; }
+    // brute force over LDS tiles (more LiDAR points than the table holds, or a huge extent)
+    hashed_s = -1;                               // the tiles below overwrite the table
+    double *sx = (double *)s_node, *sy = sx + PT, *sz = sy + PT;    // 24 KB of the nodes' LDS
+    for (int j0 = 0; j0 < na; j0 += PT) {
+      const int m = min(PT, na - j0);
+      __syncthreads();
+      if (threadIdx.x == 0) s_pending = 0;
+      for (int i = threadIdx.x; i < m; i += BT) {
+        sx[i] = px[ba + j0 + i];
+        sy[i] = py[ba + j0 + i];
+        sz[i] = pz[ba + j0 + i];
       }
-      if (!found) s_pending = 1;
+      __syncthreads();
+      if (valid && !found) {
+        for (int j = 0; j < m; j++) {
+          const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+          double d = dx * dx;
+          d += dy * dy;
+          d += dz * dz;
+          if (d < T) { found = true; break; }
+        }
+        if (!found) s_pending = 1;
+      }
+      __syncthreads();
+      if (!s_pending) break;
     }
-    __syncthreads();
-    if (!s_pending) break;
+    if (valid) flags[bq + q] = found ? 1 : 0;
   }
-  if (valid) flags[bq + q] = found ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- compaction
@@ -704,7 +735,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   hipStream_t st = (hipStream_t)stream;
   if (phases & DFU3D_RF_TILES) {
     if (hipMemsetAsync(queue, 0, 2 * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, QT);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_FLAGS) {
@@ -744,7 +775,7 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   if (S <= 0 || pool_cap <= 0 || nb_neighbors < 1) return DFU3D_EINVAL;
   if (nb_neighbors > KMAX) return DFU3D_ERANGE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, QT);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_knn_mean, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
                      (const long long *)seg_base, seg_cnt, enable, nb_neighbors, S, tile_off,
@@ -776,9 +807,10 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   double T = C * C;
   while (__builtin_sqrt(T) >= C) T = __builtin_nextafter(T, 0.0);
   while (__builtin_sqrt(T) < C) T = __builtin_nextafter(T, __builtin_inf());
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off, BT);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ball_flags, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
+  const int ball_tiles = (int)((pool_cap + BT - 1) / BT + S);
+  hipLaunchKernelGGL(k_ball_flags, dim3((ball_tiles + BQ_TPB - 1) / BQ_TPB), dim3(BT), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_off, flags, masked);
   DFU3D_LAUNCH_CHECK();
