@@ -724,6 +724,12 @@ __device__ __forceinline__ double wave_red(double v) {
 
 struct Ext { double c1min, c1max, c2min, c2max; };
 
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // l uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void cross_point(double a0, double a1, double b0, double b1,
                                             double c0, double c1, double &x, double &y) {
   // my_loader.py:699-702
@@ -793,32 +799,69 @@ __device__ void emit_box(double thb, double sin_s, double cos_s, double c1min, d
   }
 }
 
-__global__ __launch_bounds__(FT) void k_lshape_fit(
+// ---- workspace layout (doubles) ----------------------------------------------
+//   [0]            int q_count | int big_count
+//   [1]            spare
+//   [2 ...)        cluster descriptors, 8 doubles each (cap_q of them):
+//                  0 segment s, 1 cluster ordinal kc, 2 root (smallest point index), 3 members m,
+//                  4 position of the members in gsx/gsy, 5 max z of the instance, 6 ordinal among
+//                  the big clusters (m > LDS_MEMBERS), 7 spare
+//   then           big_list: int32 descriptor index per big cluster (cap_big)
+//   then           heading costs of the big clusters, MAXTH doubles each
+struct FitWs {
+  int *counters;
+  double *dsc;
+  int *big_list;
+  double *big_cost;
+  int cap_q, cap_big;
+};
+__host__ __device__ inline int fit_cap_q(int cap_rows) { return 2 * cap_rows + 64; }
+__host__ __device__ inline FitWs fit_ws_view(double *ws, int cap_rows, int cap_big) {
+  FitWs w;
+  w.cap_q = fit_cap_q(cap_rows);
+  w.cap_big = cap_big;
+  w.counters = (int *)ws;
+  w.dsc = ws + 2;
+  w.big_list = (int *)(w.dsc + (size_t)8 * w.cap_q);
+  w.big_cost = w.dsc + (size_t)8 * w.cap_q + (cap_big / 2 + 1);
+  return w;
+}
+
+// ---- F1: per instance, members of every cluster made contiguous -----------------
+// Clusters in ascending-root order (rectangle_fitting.py:188-191), members in index
+// order.  One stable counting sort per GK clusters: every wave owns a contiguous
+// range of the instance's points, counts its members per cluster, and after one
+// scan writes them behind the members of the waves before it -- no barrier inside
+// the sweeps, O(n) per GK clusters instead of O(n) per cluster.
+constexpr int GK = 64;
+
+__device__ __forceinline__ int rank_in(const int *roots, int nk, int L) {   // roots ascending, L present
+  int lo = 0, hi = nk - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (roots[mid] < L) lo = mid + 1; else hi = mid;
+  }
+  return (roots[lo] == L) ? lo : -1;
+}
+
+__global__ __launch_bounds__(FT) void k_fit_gather(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const int *__restrict__ label,
-    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, int max_inst,
-    const ViewCalib *__restrict__ calib, const int *__restrict__ inst_class,
-    const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
-    const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
-    double *__restrict__ gsx, double *__restrict__ gsy, int *__restrict__ sroot, int cap_rows,
-    double *__restrict__ rows, int *__restrict__ n_rows, uint32_t *__restrict__ status,
-    double *__restrict__ fit_ws, int cap_big) {
-  __shared__ double lx[LDS_MEMBERS], ly[LDS_MEMBERS];
-  __shared__ double s_cost[MAXTH], s_ct[MAXTH + TB], s_st[MAXTH + TB];
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt,
+    double *__restrict__ gsx, double *__restrict__ gsy, int *__restrict__ sroot,
+    uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_rows, int cap_big) {
+  __shared__ int s_roots[GK];
+  __shared__ int s_cnt[FW][GK];
+  __shared__ int s_tot[GK], s_off[GK];
   __shared__ double s_red[FW];
-  __shared__ double s_ext[FW][4];
   __shared__ int s_w[FW];
+  __shared__ int s_q0, s_total;
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0) return;
   const long long base = seg_base[s];
-  const int v = s / max_inst, jinst = s - v * max_inst;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  if (threadIdx.x < MAXTH + TB) {              // heading table (rectangle_fitting.py:119-122)
-    const double theta = (double)threadIdx.x * dtheta;
-    s_ct[threadIdx.x] = cos(theta);
-    s_st[threadIdx.x] = sin(theta);
-  }
+  const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
 
   // max z over ALL instance points (my_loader.py:647-648)
   double zm = -INFINITY;
@@ -841,46 +884,218 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
     if (f) sroot[base + nroots + r] = i;
     nroots += tot;
   }
+  if (threadIdx.x == 0) s_q0 = atomicAdd(&W.counters[0], nroots);
   __syncthreads();
+  const int q0 = s_q0;
 
-  long long goff = 0;                     // members of cluster kc live at gsx/gsy[base + goff ...]
-  for (int kc = 0; kc < nroots; kc++) {
-    const int root = sroot[base + kc];
-    // gather the cluster's members in index order
-    int m = 0;
-    for (int t0 = 0; t0 < n; t0 += FT) {
-      const int i = t0 + threadIdx.x;
-      const bool f = (i < n) && (label[base + i] == root);
-      int tot;
-      const int r = block_rank<FW>(f, s_w, tot);
-      if (f) {
-        const int d = m + r;
-        const double x = px[base + i], y = py[base + i];
-        gsx[base + goff + d] = x;
-        gsy[base + goff + d] = y;
-        if (d < LDS_MEMBERS) { lx[d] = x; ly[d] = y; }
+  const int R = (((n + FW - 1) / FW) + 63) & ~63;          // points per wave, a multiple of 64
+  const int r0 = min(n, wave * R), r1 = min(n, r0 + R);
+  long long goff = 0;
+  for (int k0 = 0; k0 < nroots; k0 += GK) {
+    const int nk = min(GK, nroots - k0);
+    __syncthreads();
+    if (threadIdx.x < nk) s_roots[threadIdx.x] = sroot[base + k0 + threadIdx.x];
+    for (int i = threadIdx.x; i < FW * GK; i += FT) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int lo_root = s_roots[0], hi_root = s_roots[nk - 1];
+    // counts per (wave, cluster)
+    for (int c = r0; c < r1; c += 64) {
+      const int i = c + lane;
+      int key = -1;
+      if (i < r1) {
+        const int L = label[base + i];
+        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
       }
-      m += tot;
+      unsigned long long rem = __ballot(key >= 0);
+      while (rem) {
+        const int src = __ffsll((long long)rem) - 1;
+        const int k = __shfl(key, src, 64);
+        const unsigned long long m = __ballot(key == k);
+        if (lane == src) s_cnt[wave][k] += __popcll(m);
+        rem &= ~m;
+      }
     }
     __syncthreads();
-    if (m > LDS_MEMBERS) {
-      // large cluster: hand it to the chip-wide kernels (k_fit_big_cost / k_fit_big_box)
-      if (threadIdx.x == 0) {
-        const int c = atomicAdd((int *)fit_ws, 1);
-        if (c < cap_big) {
-          double *dsc = fit_ws + 2 + (size_t)c * 8;
-          dsc[0] = (double)s; dsc[1] = (double)kc; dsc[2] = (double)root; dsc[3] = (double)m;
-          dsc[4] = (double)(base + goff); dsc[5] = zmax;
-        }
-      }
-      goff += m;
-      __syncthreads();
-      continue;
+    if (threadIdx.x < nk) {                                  // exclusive over the waves, per cluster
+      int t = 0;
+#pragma unroll
+      for (int w = 0; w < FW; w++) { const int c = s_cnt[w][threadIdx.x]; s_cnt[w][threadIdx.x] = t; t += c; }
+      s_tot[threadIdx.x] = t;
     }
-    goff += m;
+    __syncthreads();
+    if (wave == 0) {                                         // exclusive over the clusters
+      const int v = (lane < nk) ? s_tot[lane] : 0;
+      const int inc = wave_incl_scan(v);
+      if (lane < nk) s_off[lane] = inc - v;
+      if (lane == 63) s_total = inc;
+    }
+    __syncthreads();
+    // stable scatter
+    for (int c = r0; c < r1; c += 64) {
+      const int i = c + lane;
+      int key = -1;
+      double x = 0.0, y = 0.0;
+      if (i < r1) {
+        const int L = label[base + i];
+        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
+        if (key >= 0) { x = px[base + i]; y = py[base + i]; }
+      }
+      unsigned long long rem = __ballot(key >= 0);
+      while (rem) {
+        const int src = __ffsll((long long)rem) - 1;
+        const int k = __shfl(key, src, 64);
+        const unsigned long long m = __ballot(key == k);
+        const int cur = s_cnt[wave][k];
+        if (key == k) {
+          const long long d = base + goff + s_off[k] + cur + __popcll(m & ((1ull << lane) - 1ull));
+          gsx[d] = x;
+          gsy[d] = y;
+        }
+        if (lane == src) s_cnt[wave][k] = cur + __popcll(m);
+        rem &= ~m;
+      }
+    }
+    // descriptors
+    if (threadIdx.x < nk) {
+      const int k = threadIdx.x, e = q0 + k0 + k;
+      if (e < W.cap_q) {
+        double *d = W.dsc + (size_t)8 * e;
+        const int m = s_tot[k];
+        d[0] = (double)s; d[1] = (double)(k0 + k); d[2] = (double)s_roots[k]; d[3] = (double)m;
+        d[4] = (double)(base + goff + s_off[k]); d[5] = zmax; d[6] = -1.0; d[7] = 0.0;
+        if (m > LDS_MEMBERS) {
+          const int bi = atomicAdd(&W.counters[1], 1);
+          if (bi < cap_big) { W.big_list[bi] = e; d[6] = (double)bi; }
+        }
+      } else {
+        atomicOr(status, DFU3D_ST_ROW_OVERFLOW);             // more clusters than 2 x cap_rows
+      }
+    }
+    __syncthreads();
+    goff += s_total;
+  }
+}
+
+// ---- F2a: clusters of at most 64 points, one wave each, one lane per heading -----
+// Members live in registers (lane i = member i) and are broadcast as scalar operands;
+// no reductions at all.  rectangle_fitting.py:83-136.
+__global__ __launch_bounds__(256) void k_fit_tiny(
+    const double *__restrict__ gsx, const double *__restrict__ gsy, int max_inst,
+    const ViewCalib *__restrict__ calib, const int *__restrict__ inst_class,
+    const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
+    const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
+    int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
+    uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_big) {
+  const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
+  const int nq = min(W.counters[0], W.cap_q);
+  const int lane = lane_id();
+  const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+  for (int e = gw; e < nq; e += nw) {
+    const double *d = W.dsc + (size_t)8 * e;
+    const int m = (int)d[3];
+    if (m > 64) continue;
+    const long long P = (long long)d[4];
+    const double x = (lane < m) ? gsx[P + lane] : 0.0, y = (lane < m) ? gsy[P + lane] : 0.0;
+    double bestc = -INFINITY;
+    int bestth = 0x7FFFFFFF;
+    for (int th = lane; th < ((n_theta + 63) & ~63); th += 64) {
+      const double theta = (double)th * dtheta;
+      const double ct = cos(theta), st = sin(theta);
+      double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+      for (int j = 0; j < m; j++) {
+        const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+        const double c1 = xj * ct + yj * st;
+        const double c2 = xj * (-st) + yj * ct;
+        a0 = fmin(a0, c1); a1 = fmax(a1, c1);
+        b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+      }
+      double s1 = 0.0, s2 = 0.0;
+      int n1 = 0, n2 = 0;
+      for (int j = 0; j < m; j++) {
+        const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+        const double c1 = xj * ct + yj * st;
+        const double c2 = xj * (-st) + yj * ct;
+        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+        if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+      }
+      const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
+      double q1 = 0.0, q2 = 0.0;
+      for (int j = 0; j < m; j++) {
+        const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+        const double c1 = xj * ct + yj * st;
+        const double c2 = xj * (-st) + yj * ct;
+        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+        if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
+        else { const double u = d2 - m2; q2 += u * u; }
+      }
+      double V1 = 0.0, V2 = 0.0;
+      if (n1) V1 = -(q1 / (double)n1);
+      if (n2) V2 = -(q2 / (double)n2);
+      const double c = V1 + V2;
+      // this lane's headings come in ascending order: keep the first strict maximum
+      if (th < n_theta && bestc < c) { bestc = c; bestth = th; }
+    }
+    // first strict maximum over all headings (rectangle_fitting.py:135-136): the largest
+    // cost, the smallest heading among equals; a lane without any (NaN costs only) has
+    // bestc = -inf / bestth = INT_MAX and loses against everything, and if nobody has one
+    // the loop of the reference never updates its initial choice, heading 0
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const double oc = shfl_xor_d(bestc, msk);
+      const int ot = __shfl_xor(bestth, msk, 64);
+      if (oc > bestc || (oc == bestc && ot < bestth)) { bestc = oc; bestth = ot; }
+    }
+    const int best = (bestth == 0x7FFFFFFF) ? 0 : bestth;
+    const double thb = (double)best * dtheta;
+    const double sin_s = sin(thb), cos_s = cos(thb);
+    double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+    if (lane < m) {
+      const double c1 = x * cos_s + y * sin_s;
+      const double c2 = x * (-sin_s) + y * cos_s;
+      a0 = c1; a1 = c1; b0 = c2; b1 = c2;
+    }
+    a0 = wave_min_d(a0); a1 = wave_max_d(a1);
+    b0 = wave_min_d(b0); b1 = wave_max_d(b1);
+    if (lane == 0) {
+      const int s = (int)d[0], kc = (int)d[1], root = (int)d[2];
+      const int v = s / max_inst, jinst = s - v * max_inst;
+      emit_box(thb, sin_s, cos_s, a0, a1, b0, b1, d[5], s, v, jinst, kc, root, m, calib, inst_class,
+               inst_is_car, inst_box, inst_score, car_aspect_max, cap_rows, rows, n_rows, status);
+    }
+  }
+}
+
+// ---- F2b: clusters of 65 .. LDS_MEMBERS points, one workgroup each ---------------
+__global__ __launch_bounds__(FT) void k_fit_medium(
+    const double *__restrict__ gsx, const double *__restrict__ gsy, int max_inst,
+    const ViewCalib *__restrict__ calib, const int *__restrict__ inst_class,
+    const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
+    const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
+    int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
+    uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_big) {
+  __shared__ double lx[LDS_MEMBERS], ly[LDS_MEMBERS];
+  __shared__ double s_cost[MAXTH], s_ct[MAXTH], s_st[MAXTH];
+  __shared__ double s_ext[FW][4];
+  const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
+  const int nq = min(W.counters[0], W.cap_q);
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  if (threadIdx.x < MAXTH) {                   // heading table (rectangle_fitting.py:119-122)
+    const double theta = (double)threadIdx.x * dtheta;
+    s_ct[threadIdx.x] = cos(theta);
+    s_st[threadIdx.x] = sin(theta);
+  }
+  for (int e = blockIdx.x; e < nq; e += gridDim.x) {
+    const double *d = W.dsc + (size_t)8 * e;
+    const int m = (int)d[3];
+    if (m <= 64 || m > LDS_MEMBERS) continue;
+    __syncthreads();
+    const long long P = (long long)d[4];
+    for (int i = threadIdx.x; i < m; i += FT) { lx[i] = gsx[P + i]; ly[i] = gsy[P + i]; }
+    __syncthreads();
     const double *mx = lx;
     const double *my = ly;
-    {
     // 89 headings, one wave each (rectangle_fitting.py:119-136)
     for (int th = wave; th < n_theta; th += FW) {
       const double ct = s_ct[th], st = s_st[th];
@@ -924,18 +1139,15 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
       if (n2) V2 = -(q2 / (double)n2);
       if (lane == 0) s_cost[th] = V1 + V2;
     }
-    }
     __syncthreads();
     // first strict maximum (rectangle_fitting.py:135-136)
     int best = 0;
     {
       double bc = -INFINITY;
-      bool have = false;
       for (int th = 0; th < n_theta; th++) {
         const double c = s_cost[th];
-        if (bc < c) { bc = c; best = th; have = true; }
+        if (bc < c) { bc = c; best = th; }
       }
-      (void)have;
     }
     // extents at the best heading (rectangle_fitting.py:139-157)
     const double thb = (double)best * dtheta;
@@ -960,11 +1172,12 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
         c1min = fmin(c1min, s_ext[w][0]); c1max = fmax(c1max, s_ext[w][1]);
         c2min = fmin(c2min, s_ext[w][2]); c2max = fmax(c2max, s_ext[w][3]);
       }
-      emit_box(thb, sin_s, cos_s, c1min, c1max, c2min, c2max, zmax, s, v, jinst, kc, root, m, calib,
+      const int s = (int)d[0], kc = (int)d[1], root = (int)d[2];
+      const int v = s / max_inst, jinst = s - v * max_inst;
+      emit_box(thb, sin_s, cos_s, c1min, c1max, c2min, c2max, d[5], s, v, jinst, kc, root, m, calib,
                inst_class, inst_is_car, inst_box, inst_score, car_aspect_max, cap_rows, rows,
                n_rows, status);
     }
-    __syncthreads();
   }
 }
 
@@ -972,19 +1185,20 @@ __global__ __launch_bounds__(FT) void k_lshape_fit(
 __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ gsx,
                                                      const double *__restrict__ gsy, int n_theta,
                                                      double dtheta, int nb, double *__restrict__ fit_ws,
-                                                     int cap_big) {
+                                                     int cap_rows, int cap_big) {
   __shared__ double s_ct[TB], s_st[TB];
   __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
-  const int nbig = min(*(const int *)fit_ws, cap_big);
+  const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
+  const int nbig = min(W.counters[1], cap_big);
   for (int item = blockIdx.x; item < nbig * nb; item += gridDim.x) {     // uniform per block
   const int c = item / nb;
   const int tb = (item - c * nb) * TB;
   if (tb >= n_theta) continue;
   __syncthreads();
-  const double *dsc = fit_ws + 2 + (size_t)c * 8;
+  const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
   const int m = (int)dsc[3];
   const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
-  double *s_cost = fit_ws + 2 + (size_t)cap_big * 8 + (size_t)c * MAXTH;        // heading costs of cluster c
+  double *s_cost = W.big_cost + (size_t)c * MAXTH;                              // heading costs of cluster c
   const int wave = threadIdx.x >> 6, lane = lane_id();
   if (threadIdx.x < TB) {
     const double theta = (double)(tb + threadIdx.x) * dtheta;
@@ -1094,16 +1308,17 @@ __global__ __launch_bounds__(FT) void k_fit_big_box(
     const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
     const float *__restrict__ inst_score, int n_theta, double dtheta, double car_aspect_max,
     int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
-    uint32_t *__restrict__ status, const double *__restrict__ fit_ws, int cap_big) {
+    uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_big) {
   __shared__ double s_ext[FW][4];
-  const int nbig = min(*(const int *)fit_ws, cap_big);
+  const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
+  const int nbig = min(W.counters[1], cap_big);
   for (int c = blockIdx.x; c < nbig; c += gridDim.x) {
   __syncthreads();
-  const double *dsc = fit_ws + 2 + (size_t)c * 8;
+  const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
   const int s = (int)dsc[0], kc = (int)dsc[1], root = (int)dsc[2], m = (int)dsc[3];
   const double zmax = dsc[5];
   const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
-  const double *cost = fit_ws + 2 + (size_t)cap_big * 8 + (size_t)c * MAXTH;
+  const double *cost = W.big_cost + (size_t)c * MAXTH;
   const int wave = threadIdx.x >> 6, lane = lane_id();
   int best = 0;
   double bc = -INFINITY;
@@ -1170,10 +1385,10 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   return DFU3D_OK;
 }
 
-extern "C" int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap) {
-  if (pool_cap <= 0) return DFU3D_EINVAL;
+extern "C" int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap, int32_t cap_rows) {
+  if (pool_cap <= 0 || cap_rows <= 0) return DFU3D_EINVAL;
   const int64_t cap_big = pool_cap / LDS_MEMBERS + 1;
-  return 2 + cap_big * (8 + MAXTH);
+  return 2 + (int64_t)8 * fit_cap_q(cap_rows) + (cap_big / 2 + 1) + cap_big * MAXTH;
 }
 
 extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
@@ -1195,19 +1410,31 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
   if (n_theta > MAXTH) return DFU3D_ERANGE;
   hipStream_t st = (hipStream_t)stream;
   const int cap_big = (int)(pool_cap / LDS_MEMBERS + 1);
+  const ViewCalib *vc = (const ViewCalib *)calib;
   if (hipMemsetAsync(fit_ws, 0, 16, st) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_lshape_fit, dim3(S), dim3(FT), 0, st, px, py, pz, label,
-                     (const long long *)seg_base, seg_cnt, max_inst, (const ViewCalib *)calib,
-                     inst_class, inst_is_car, inst_box, inst_score, n_theta, dtheta,
-                     car_aspect_max, sx, sy, sroot, cap_rows, rows, n_rows, status, fit_ws, cap_big);
+  // F1: members of every cluster contiguous, one descriptor per cluster
+  hipLaunchKernelGGL(k_fit_gather, dim3(S), dim3(FT), 0, st, px, py, pz, label,
+                     (const long long *)seg_base, seg_cnt, sx, sy, sroot, status, fit_ws,
+                     cap_rows, cap_big);
+  DFU3D_LAUNCH_CHECK();
+  // F2: heading search + box, by cluster size (each kernel loops over the descriptors it owns)
+  const int cap_q = fit_cap_q(cap_rows);
+  const int g_tiny = cap_q / 4 + 1 < 2048 ? cap_q / 4 + 1 : 2048;
+  hipLaunchKernelGGL(k_fit_tiny, dim3(g_tiny), dim3(256), 0, st, sx, sy, max_inst, vc, inst_class,
+                     inst_is_car, inst_box, inst_score, n_theta, dtheta, car_aspect_max, cap_rows,
+                     rows, n_rows, status, fit_ws, cap_big);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_fit_medium, dim3(cap_q < 2048 ? cap_q : 2048), dim3(FT), 0, st, sx, sy, max_inst,
+                     vc, inst_class, inst_is_car, inst_box, inst_score, n_theta, dtheta,
+                     car_aspect_max, cap_rows, rows, n_rows, status, fit_ws, cap_big);
   DFU3D_LAUNCH_CHECK();
   const int nb = (n_theta + TB - 1) / TB;
   const int g2 = cap_big * nb < 4096 ? cap_big * nb : 4096;           // persistent: items are looped over
   hipLaunchKernelGGL(k_fit_big_cost, dim3(g2), dim3(FT), 0, st, sx, sy, n_theta, dtheta,
-                     nb, fit_ws, cap_big);
+                     nb, fit_ws, cap_rows, cap_big);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_fit_big_box, dim3(cap_big < 2048 ? cap_big : 2048), dim3(FT), 0, st, sx, sy, max_inst,
-                     (const ViewCalib *)calib, inst_class, inst_is_car, inst_box, inst_score,
+                     vc, inst_class, inst_is_car, inst_box, inst_score,
                      n_theta, dtheta, car_aspect_max, cap_rows, rows, n_rows, status, fit_ws,
                      cap_big);
   DFU3D_LAUNCH_CHECK();

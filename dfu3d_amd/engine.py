@@ -111,7 +111,7 @@ class PseudoBoxEngine:
             L.sx, L.sy = f64(pc), f64(pc)
             L.label, L.sroot = i32(pc), i32(pc)
             L.si3 = i32(3 * pc)
-            L.fit_ws = f64(int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(pc)))
+            L.fit_ws = f64(int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(pc, self.cap_rows)))
             L.flags = torch.empty(pc, dtype=torch.uint8, device=d)
             L.mean_d = f64(pc) if self.p.stat_filter else None
             L.base_a = torch.empty(S, dtype=torch.int64, device=d)

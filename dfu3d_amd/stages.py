@@ -266,7 +266,7 @@ def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap, sx=None
 def lshape_fit(px, py, pz, label, seg_base, seg_cnt, S, max_inst, calib, inst_class,
                inst_is_car, inst_box, inst_score, n_theta, dtheta, car_aspect_max, sx, sy,
                sroot, cap_rows, rows, n_rows, status, pool_cap, fit_ws=None):
-    nws = int(_lib.lib().dfu3d_lshape_fit_ws_doubles(pool_cap))
+    nws = int(_lib.lib().dfu3d_lshape_fit_ws_doubles(pool_cap, cap_rows))
     if fit_ws is None:
         fit_ws = torch.empty(nws, dtype=torch.float64, device=px.device)
     if S % max_inst:

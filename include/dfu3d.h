@@ -242,10 +242,12 @@ int dfu3d_range_cluster(const double *px, const double *py,
  * Rows are appended in arbitrary order (sort by cols 0..2); n_rows is a device
  * counter.  inst_class/inst_is_car: int32 (S); inst_box: float32 (S,4);
  * inst_score float32 (S).  Scratch: sx, sy fp64 (pool_cap), sroot int32
- * (pool_cap), fit_ws fp64 (dfu3d_lshape_fit_ws_doubles(pool_cap): descriptors
- * and heading costs of the clusters that are too large for one workgroup and
- * are spread over the chip as (cluster, 8-heading batch) workgroups). */
-int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap);
+ * (pool_cap), fit_ws fp64 (dfu3d_lshape_fit_ws_doubles(pool_cap, cap_rows): one
+ * descriptor per cluster -- at most 2*cap_rows+64 clusters per call, more raise
+ * DFU3D_ST_ROW_OVERFLOW -- and the heading costs of the clusters that are too
+ * large for one workgroup and are spread over the chip as (cluster, 8-heading
+ * batch) workgroups). */
+int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap, int32_t cap_rows);
 int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
                      const int32_t *label, const int64_t *seg_base,
                      const int32_t *seg_cnt, int32_t S, int32_t max_inst,

@@ -20,7 +20,7 @@ px[:n] = torch.from_numpy(xy[:, 0]); py[:n] = torch.from_numpy(xy[:, 1])
 base = torch.zeros(1, dtype=torch.int64, device=dev); cnt = torch.full((1,), n, dtype=torch.int32, device=dev)
 label = torch.zeros(cap, dtype=torch.int32, device=dev)
 st.range_cluster(px, py, base, cnt, 1, p.R0, p.Rd, label, cap)
-nws = int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(cap))
+nws = int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(cap, 4096))
 ws = torch.full((nws,), -777.0, dtype=torch.float64, device=dev)
 rows = torch.zeros(8 * st.ROW_DOUBLES, dtype=torch.float64, device=dev); nr = torch.zeros(1, dtype=torch.int32, device=dev); stt = torch.zeros(1, dtype=torch.int32, device=dev)
 z32 = lambda k: torch.zeros(k, dtype=torch.int32, device=dev)
