@@ -62,6 +62,7 @@ SIGNATURES = {
                                      _P]),
     "dfu3d_range_cluster": (c_i32, [_P, _P, _P, _P, c_i32, c_f64, c_f64, _P, _P, _P, _P, c_i64,
                                     _P]),
+    "dfu3d_selftest_angles": (c_i32, [c_i64, ctypes.c_uint64, c_f64, c_f64, c_f64, _P, _P]),
     "dfu3d_lshape_fit_ws_doubles": (c_i64, [c_i64, c_i32]),
     "dfu3d_lshape_fit": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, _P, _P, _P, _P, _P,
                                  c_i32, c_f64, c_f64, _P, _P, _P, c_i32, _P, _P, _P, _P, c_i64,

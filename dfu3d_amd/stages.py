@@ -248,6 +248,16 @@ def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, til
     _lib.check(rc, "dfu3d_ballquery_fuse")
 
 
+def selftest_angles(n, seed=1, range_xy=100.0, z_lo=-6.0, z_hi=1.0, device="cuda:0"):
+    """-> (max error/bound for theta, for phi) of the fp32 angle estimates on this device."""
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    rc = _lib.lib().dfu3d_selftest_angles(int(n), int(seed), float(range_xy), float(z_lo), float(z_hi),
+                                          _chk(out, "out", torch.float64, numel=2), _stream())
+    _lib.check(rc, "dfu3d_selftest_angles")
+    t, p = out.cpu().tolist()
+    return t, p
+
+
 def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap, sx=None, sy=None, si=None):
     dev = px.device
     sx = sx if sx is not None else torch.empty(pool_cap, dtype=torch.float64, device=dev)

@@ -219,6 +219,16 @@ int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
                                 int32_t S, int64_t pool_cap, int32_t *tile_off,
                                 uint8_t *flags, void *stream);
 
+/* ---- self test of the two-tier bin classification ---------------------------
+ * dfu3d_backproject_bin decides a pixel's spherical bin from fp32 angle
+ * estimates when they are farther from every bin edge than a bound on their
+ * error, and in fp64 otherwise.  This entry point measures, over n pseudo-random
+ * points (|x|,|y| <= range_xy, z in [z_lo, z_hi]; every third one 50x closer),
+ * out2[0] = max |theta_fp32 - theta_fp64| / bound_theta, out2[1] likewise for phi
+ * (device doubles).  Values below 1 mean the bounds hold on this device. */
+int dfu3d_selftest_angles(int64_t n, uint64_t seed, double range_xy, double z_lo,
+                          double z_hi, double *out2, void *stream);
+
 /* ---- a13: _adoptive_range_segmentation (rectangle_fitting.py:161-191) ------
  * label[seg_base[s] + i] = smallest in-segment index of the cluster that
  * contains point i (clusters = connected components of d_ij <= R_i or

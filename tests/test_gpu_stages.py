@@ -64,6 +64,14 @@ def _clustered_points(rng, n, spread=1.0, outliers=0.05):
     return p
 
 
+def test_fp32_angle_bounds_hold_on_this_device(st):
+    """The two-tier bin classification trusts fp32 acosf/atanf only outside an error bound; measure the real
+    error against fp64 on 2e8 points (LiDAR-like ranges and close-in points) -- it must stay under half the bound."""
+    for seed, rxy, zlo, zhi in ((1, 100.0, -6.0, 1.0), (2, 5.0, -3.0, 1.0), (3, 60.0, -0.2, 0.2)):
+        t, p = st.selftest_angles(70_000_000, seed, rxy, zlo, zhi)
+        assert 0.0 < t < 0.5 and 0.0 < p < 0.5, (seed, t, p)
+
+
 # ------------------------------------------------------------------ a10
 def test_radius_filter_matches_oracle(st):
     rng = np.random.default_rng(10)
