@@ -43,7 +43,7 @@ def build_batch(frames, seed0, device, dense, k_boxes):
     return scenes
 
 
-PMC_NAMES = {"bp_bin": "k_bp_bin", "bp_rep": "k_bp_rep", "bp_emit": "k_bp_emit", "rf_flags": "k_radius_flags",
+PMC_NAMES = {"bp_bin": "k_bp_bin", "bp_emit": "k_bp_emit", "rf_flags": "k_radius_flags",
              "fov_filter": "k_fov_filter", "project_label": "k_project_rows"}
 
 
@@ -194,7 +194,6 @@ def main():
             n_rf_launch = kern.get("rf_flags", (0, 1))[1]
             alg = {
                 "bp_bin": views_per_launch * H * W * 4,                  # depth read
-                "bp_rep": views_per_launch * H * W * 4,                  # bin-id read
                 "bp_emit": views_per_launch * H * W * 4,                 # bin-id read
                 "rf_flags": 21.0 * rf_pts / max(n_rf_launch, 1),          # 16n + 4n + 1n
                 "fov_filter": views_per_launch * N_PTS * 16,

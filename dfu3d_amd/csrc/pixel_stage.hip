@@ -10,18 +10,25 @@
 // GPU formulation (order-free, deterministic): because input order == pixel
 // index, "first seen" is the minimum pixel index of a bin and "the first 100"
 // are the 100 smallest pixel indices.  Per view a direct-addressed table over
-// the reachable (theta,phi) bins holds {min key, count, first pixel, rep pixel}:
+// the reachable (theta,phi) bins holds {min key, min (key',pixel), count, first
+// pixel, rep pixel}:
 //   P1  per pixel: back-project, bin, store bin id; atomics: count++,
-//       first=min(pix), kmin=min(key)             (100-cap assumed not to bind)
+//       first=min(pix), kmin=min(key), combo=min(key' | pix) where key' is the
+//       order-preserving key cut to its top 64-b bits and b = bits of a pixel
+//       index                                    (100-cap assumed not to bind)
 //   O*  bins whose count exceeded the cap are listed by the 101st arrival and
 //       repaired exactly: their pixel lists are gathered, the 100th smallest
-//       pixel index T is radix-selected and kmin recomputed over pix <= T
-//   P2  per pixel: if key == kmin (and pix <= T): rep=min(pix); count pixels
-//       that are the first of their bin per 1024-pixel block
-//   SC  per view: exclusive scan of the block counts
-//   P3  per pixel block: ordered ranks of first-pixels -> voxel list
-//   P4  per voxel: representative's xyz + instance bits; table entry reset
-// Each pass streams the (V,H,W) float32 depth with float4 loads.
+//       pixel index T is radix-selected, kmin and the representative recomputed
+//       over pix <= T
+//   P3  ONE pass over the bin ids: per 1024-pixel block the pixels that are the
+//       first of their bin, chained over the blocks of a view by a decoupled
+//       look-back scan -> ordered voxel list
+//   P4  per voxel: the representative is the pixel p* of combo if its exact key
+//       equals kmin (p* is the smallest pixel among those whose cut key is
+//       minimal, a superset of the exact arg-mins); otherwise two keys of the
+//       bin differ only below the cut -- the bin's pixels are then scanned
+//       (practically never).  Then xyz + instance bits; table entry reset.
+// P1 streams the (V,H,W) float32 depth with float4 loads, P3 the bin ids.
 #include "common.hpp"
 
 namespace {
@@ -33,23 +40,35 @@ constexpr uint32_t NOBIN = 0xFFFFFFFFu;
 constexpr uint32_t OVF_FLAG = 0x80000000u;
 
 struct Table {
-  unsigned long long *kmin;
+  unsigned long long *kmin, *combo;
   uint32_t *cnt, *first, *rep;
 };
 __host__ __device__ inline Table table_view(void *base, int64_t E) {
   Table t;
   t.kmin = (unsigned long long *)base;
-  t.cnt = (uint32_t *)(t.kmin + E);
+  t.combo = t.kmin + E;
+  t.cnt = (uint32_t *)(t.combo + E);
   t.first = t.cnt + E;
   t.rep = t.first + E;
   return t;
 }
+static_assert(DFU3D_TABLE_ENTRY_BYTES == 28, "table entry");
 
-__global__ void k_table_init(unsigned long long *kmin, uint32_t *cnt, uint32_t *first,
-                             uint32_t *rep, int64_t E) {
+// order-preserving key cut to its top (64 - pix_bits) bits | pixel index
+__device__ __forceinline__ unsigned long long combo_word(unsigned long long okey, uint32_t pix,
+                                                         int pix_bits) {
+#ifdef DFU3D_DBG_COMBO_KEYBITS      /* test builds: provoke the scan of k_bp_vox */
+  okey &= ~0ull << (64 - DFU3D_DBG_COMBO_KEYBITS);
+#endif
+  return ((okey >> pix_bits) << pix_bits) | (unsigned long long)pix;
+}
+
+__global__ void k_table_init(unsigned long long *kmin, unsigned long long *combo, uint32_t *cnt,
+                             uint32_t *first, uint32_t *rep, int64_t E) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E;
        i += (int64_t)gridDim.x * blockDim.x) {
     kmin[i] = ~0ull;
+    combo[i] = ~0ull;
     cnt[i] = 0u;
     first[i] = NOBIN;
     rep[i] = NOBIN;
@@ -112,7 +131,7 @@ __device__ __forceinline__ void load4(const float *p, int base, int n, float d[P
 // table update shared by the two classification kernels
 __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key,
                                              uint32_t b, int v, int max_points, int cap_ovf,
-                                             uint32_t *ovf_bins, int *n_ovf) {
+                                             uint32_t *ovf_bins, int *n_ovf, int pix_bits) {
 #ifdef DFU3D_DBG_NOATOMIC
   if (pix == -12345) T.cnt[e] = 1;   // experiment: classification cost without table atomics
   return;
@@ -120,6 +139,7 @@ __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix,
   const uint32_t old = atomicAdd(&T.cnt[e], 1u);
   atomicMin(&T.first[e], (uint32_t)pix);
   atomicMin(&T.kmin[e], ordered_key(key));
+  atomicMin(&T.combo[e], combo_word(ordered_key(key), (uint32_t)pix, pix_bits));
   if (old == (uint32_t)max_points) {               // the (cap+1)-th arrival
     const int slot = atomicAdd(&n_ovf[v], 1);
     if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
@@ -202,9 +222,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     dfu3d_bin_geom g, double inv_t, double inv_p, int W, int H, int tiles_x, int key_axis,
     int64_t E_view, void *table, int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
     uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf, uint32_t *__restrict__ amb_list,
-    int *__restrict__ n_amb) {
+    int *__restrict__ n_amb, int pix_bits) {
   __shared__ uint32_t s_amb[PBLK];
-  __shared__ unsigned long long s_kmin[WIN_T * WIN_P];
+  __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
   __shared__ int s_namb, s_base, s_t0, s_p0;
   const int v = blockIdx.y;
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int row = ty * TILE_H + (threadIdx.x >> 4);
   const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
   if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
-  for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
+  for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
   uint32_t bins[PPT];
   double keys[PPT];
@@ -268,12 +288,15 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         const int w = lt * WIN_P + lp;
         atomicAdd(&s_cnt[w], 1u);
         atomicMin(&s_first[w], (uint32_t)(base + k));
-        atomicMin(&s_kmin[w], ordered_key(keys[k]));
+        const unsigned long long ok = ordered_key(keys[k]);
+        atomicMin(&s_kmin[w], ok);
+        atomicMin(&s_combo[w], combo_word(ok, (uint32_t)(base + k), pix_bits));
       } else {                                                    // outside the window: direct
         const int64_t e = tb0 + b;
         const uint32_t old = atomicAdd(&T.cnt[e], 1u);
         atomicMin(&T.first[e], (uint32_t)(base + k));
         atomicMin(&T.kmin[e], ordered_key(keys[k]));
+        atomicMin(&T.combo[e], combo_word(ordered_key(keys[k]), (uint32_t)(base + k), pix_bits));
         if (old == (uint32_t)g.max_points_per_voxel) {
           const int slot = atomicAdd(&n_ovf[v], 1);
           if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
@@ -294,6 +317,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     const uint32_t old = atomicAdd(&T.cnt[e], cw);
     atomicMin(&T.first[e], s_first[w]);
     atomicMin(&T.kmin[e], s_kmin[w]);
+    atomicMin(&T.combo[e], s_combo[w]);
     const uint32_t mx = (uint32_t)g.max_points_per_voxel;
     if (old <= mx && old + cw > mx) {                             // this add crossed the cap
       const int slot = atomicAdd(&n_ovf[v], 1);
@@ -313,7 +337,7 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     int HW, int key_axis, int64_t E_view, void *table, int64_t E_total,
     uint32_t *__restrict__ pix_bin, int cap_ovf, uint32_t *__restrict__ ovf_bins,
     int *__restrict__ n_ovf, const uint32_t *__restrict__ amb_list, const int *__restrict__ n_amb,
-    uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ status, int pix_bits) {
   const int v = blockIdx.y;
   const int na = n_amb[v];
   const ViewCalib c = calib[v];
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
     pix_bin[(size_t)v * HW + pix] = b;
     if (b != NOBIN)
-      commit_pixel(T, tb0 + b, pix, key, b, v, g.max_points_per_voxel, cap_ovf, ovf_bins, n_ovf);
+      commit_pixel(T, tb0 + b, pix, key, b, v, g.max_points_per_voxel, cap_ovf, ovf_bins, n_ovf, pix_bits);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -438,107 +462,114 @@ __global__ __launch_bounds__(256) void k_ovf_select(
   }
   if (lane_id() == 0) s_min[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
-    T.kmin[e] = m;
-    T.cnt[e] = OVF_FLAG | thr;       // P2 reads the threshold from here
-    T.rep[e] = NOBIN;
-  }
-  }
-}
-
-// ---- P2 ---------------------------------------------------------------------
-__global__ __launch_bounds__(PB) void k_bp_rep(
-    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, int W, int HW,
-    int key_axis, int64_t E_view, void *table, int64_t E_total,
-    const uint32_t *__restrict__ pix_bin, int nblk, int *__restrict__ blk_cnt) {
-  __shared__ int s_w[PB / 64];
-  const int v = blockIdx.y;
-  const ViewCalib c = calib[v];
-  const Recip rc = make_recip(c);
-  const Table T = table_view(table, E_total);
-  const int64_t tb0 = (int64_t)v * E_view;
-  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
-  int nfirst = 0;
-  if (base < HW) {
-    uint32_t bins[PPT];
-    if (base + PPT <= HW) {
-      const uint4 q = *(const uint4 *)(pix_bin + (size_t)v * HW + base);
-      bins[0] = q.x; bins[1] = q.y; bins[2] = q.z; bins[3] = q.w;
-    } else {
-      for (int k = 0; k < PPT; k++)
-        bins[k] = (base + k < HW) ? pix_bin[(size_t)v * HW + base + k] : NOBIN;
+  for (int w = 0; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;     // the same value in every thread
+  // representative: the smallest pixel <= T whose key is that minimum
+  uint32_t rp = NOBIN;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t pix = lst[i];
+    if (pix <= thr && pix < rp) {
+      const unsigned long long k = ordered_key(
+          pixel_key(c, rc, W, (int)pix, depth[(size_t)v * HW + pix], key_axis));
+      if (k == m) rp = pix;
     }
+  }
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {
-      if (bins[k] == NOBIN) continue;
-      const int pix = base + k;
-      const int64_t e = tb0 + bins[k];
-      const uint32_t cw = T.cnt[e];
-      const uint32_t thr = (cw & OVF_FLAG) ? (cw & ~OVF_FLAG) : 0x7FFFFFFFu;
-      if ((uint32_t)pix <= thr) {
-        const double key = pixel_key(c, rc, W, pix, depth[(size_t)v * HW + pix], key_axis);
-        if (ordered_key(key) == T.kmin[e]) atomicMin(&T.rep[e], (uint32_t)pix);
-      }
-      nfirst += (T.first[e] == (uint32_t)pix) ? 1 : 0;
-    }
-  }
-  nfirst = wave_sum_i(nfirst);
-  if (lane_id() == 0) s_w[threadIdx.x >> 6] = nfirst;
+  for (int x = 32; x >= 1; x >>= 1) rp = min(rp, (uint32_t)__shfl_xor((int)rp, x, 64));
   __syncthreads();
-  if (threadIdx.x == 0)
-    blk_cnt[(size_t)v * (nblk + 1) + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-// ---- SC: per-view exclusive scan of the block counts -------------------------
-__global__ __launch_bounds__(1024) void k_bp_scan(int nblk, int *__restrict__ blk_cnt,
-                                                  int *__restrict__ n_vox, int cap_vox,
-                                                  uint32_t *__restrict__ status) {
-  __shared__ int s_w[16];
-  const int v = blockIdx.x;
-  int *bc = blk_cnt + (size_t)v * (nblk + 1);
-  int running = 0;
-  for (int base = 0; base < nblk; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int val = (i < nblk) ? bc[i] : 0;
-    int tot;
-    const int ex = block_excl_scan<16>(val, s_w, tot);
-    if (i < nblk) bc[i] = running + ex;
-    running += tot;
-  }
+  if (lane_id() == 0) s_min[threadIdx.x >> 6] = (unsigned long long)rp;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    bc[nblk] = running;
-    n_vox[v] = running;                  // all touched bins (clamped in P4)
-    if (running > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+    for (int w = 0; w < 4; w++) rp = min(rp, (uint32_t)s_min[w]);
+    T.kmin[e] = m;
+    T.cnt[e] = OVF_FLAG | thr;       // P4 takes the representative from T.rep for these bins
+    T.rep[e] = rp;
+  }
   }
 }
 
-// ---- P3: ordered voxel list --------------------------------------------------
+// ---- P3: ordered voxel list in one pass ----------------------------------------
+// lb[v*nblk + b] = flag << 62 | value: flag 1 = the block's own count, 2 = inclusive
+// prefix (decoupled look-back; blocks of a view are dispatched in order of b).
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
+
+constexpr int EPT = 32;                       // pixels per thread in P3 (eight uint4 loads)
+constexpr int EBLK = PB * EPT;                 // 8192 pixels per block: few look-backs per view
+
 __global__ __launch_bounds__(PB) void k_bp_emit(
     int HW, int64_t E_view, void *table, int64_t E_total,
-    const uint32_t *__restrict__ pix_bin, int nblk, const int *__restrict__ blk_cnt,
-    int cap_vox, uint32_t *__restrict__ vox_bin) {
+    const uint32_t *__restrict__ pix_bin, int nblk, unsigned long long *__restrict__ lb,
+    int cap_vox, uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
+    uint32_t *__restrict__ status) {
   __shared__ int s_w[PB / 64];
-  const int v = blockIdx.y;
+  __shared__ int s_excl;
+  const int v = blockIdx.y, bk = blockIdx.x;
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
-  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
-  uint32_t bins[PPT];
-  bool isf[PPT];
-  int mine = 0;
+  const int base = bk * EBLK + threadIdx.x * EPT;
+  uint32_t bins[EPT];
+  if (base + EPT <= HW) {
 #pragma unroll
-  for (int k = 0; k < PPT; k++) {
-    const int pix = base + k;
-    bins[k] = (pix < HW) ? pix_bin[(size_t)v * HW + pix] : NOBIN;
-    isf[k] = (bins[k] != NOBIN) && (T.first[tb0 + bins[k]] == (uint32_t)pix);
-    mine += isf[k] ? 1 : 0;
+    for (int g = 0; g < EPT / 4; g++) {
+      const uint4 q = *(const uint4 *)(pix_bin + (size_t)v * HW + base + 4 * g);
+      bins[4 * g] = q.x; bins[4 * g + 1] = q.y; bins[4 * g + 2] = q.z; bins[4 * g + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EPT; k++) bins[k] = (base + k < HW) ? pix_bin[(size_t)v * HW + base + k] : NOBIN;
   }
-  int tot;
-  int r = block_excl_scan<PB / 64>(mine, s_w, tot) +
-          blk_cnt[(size_t)v * (nblk + 1) + blockIdx.x];
+  uint32_t isf = 0u;                            // bit k: pixel base+k is the first of its bin
 #pragma unroll
-  for (int k = 0; k < PPT; k++)
-    if (isf[k]) {
+  for (int k = 0; k < EPT; k++)
+    if ((bins[k] != NOBIN) && (T.first[tb0 + bins[k]] == (uint32_t)(base + k))) isf |= 1u << k;
+  const int mine = __popc(isf);
+  int tot;
+  const int r_in = block_excl_scan<PB / 64>(mine, s_w, tot);
+  unsigned long long *my = lb + (size_t)v * nblk;
+  if (threadIdx.x < 64) {                       // first wave: publish, look back, publish
+    const int lane = threadIdx.x;
+    if (lane == 0)
+      __hip_atomic_store(&my[bk], (bk == 0 ? LB_INC : LB_AGG) | (unsigned long long)tot,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long excl = 0;
+    int hi = bk - 1;                            // nearest predecessor not yet accounted for
+    while (hi >= 0) {
+      const int j = hi - lane;
+      unsigned long long w = LB_INC;            // lanes before block 0: neutral "inclusive 0"
+      if (j >= 0) {
+        do {
+          w = __hip_atomic_load(&my[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w >> 62) == 0ull);
+      }
+      const unsigned long long inc = __ballot((w >> 62) == 2ull);
+      const int stop = inc ? (__ffsll((long long)inc) - 1) : 64;      // nearest inclusive prefix
+      long long part = (lane <= stop) ? (long long)(w & LB_VAL) : 0ll;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const int lo = __shfl_xor((int)(part & 0xFFFFFFFFll), m, 64);
+        const int hi32 = __shfl_xor((int)(part >> 32), m, 64);
+        part += ((long long)hi32 << 32) | (unsigned int)lo;
+      }
+      excl += part;
+      if (inc) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      if (bk > 0)
+        __hip_atomic_store(&my[bk], LB_INC | (unsigned long long)(excl + tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = (int)excl;
+      if (bk == nblk - 1) {
+        const long long total = excl + tot;
+        n_vox[v] = (int)total;               // all touched bins (clamped in P4)
+        if (total > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+      }
+    }
+  }
+  __syncthreads();
+  int r = s_excl + r_in;
+#pragma unroll
+  for (int k = 0; k < EPT; k++)
+    if (isf & (1u << k)) {
       if (r < cap_vox) vox_bin[(size_t)v * cap_vox + r] = bins[k];
       r++;
     }
@@ -551,7 +582,8 @@ __global__ __launch_bounds__(256) void k_bp_vox(
     int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox,
     const uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
     uint32_t *__restrict__ vox_pix, uint32_t *__restrict__ it_bits,
-    double *__restrict__ it_x, double *__restrict__ it_y, double *__restrict__ it_z) {
+    double *__restrict__ it_x, double *__restrict__ it_y, double *__restrict__ it_z,
+    const uint32_t *__restrict__ pix_bin, int key_axis, int pix_bits) {
   const int v = blockIdx.y;
   const int ntouched = min(n_vox[v], cap_vox);
   const int nout = min(ntouched, max_voxels);
@@ -561,12 +593,34 @@ __global__ __launch_bounds__(256) void k_bp_vox(
     const size_t o = (size_t)v * cap_vox + k;
     const int64_t e = (int64_t)v * E_view + vox_bin[o];
     if (k < nout) {
-      const uint32_t pix = T.rep[e];
       const ViewCalib c = calib[v];
-  const Recip rc = make_recip(c);
-      const int row = (int)pix / W, col = (int)pix - row * W;
+      const Recip rc = make_recip(c);
+      const uint32_t cw = T.cnt[e];
+      uint32_t pix = (cw & OVF_FLAG) ? T.rep[e]
+                                     : (uint32_t)(T.combo[e] & ((1ull << pix_bits) - 1ull));
+      int row = (int)pix / W, col = (int)pix - row * W;
       double x, y, z;
       pixel_to_lidar(c, rc, col, row, depth[(size_t)v * HW + pix], x, y, z);
+      if (!(cw & OVF_FLAG)) {
+        double key = (key_axis == 2) ? z : y;
+        if (key == 0.0) key = 0.0;
+        if (ordered_key(key) != T.kmin[e]) {
+          // two keys of this bin agree in their top bits but not exactly: find the first
+          // arg-min among the bin's pixels the long way (one thread, practically never)
+          const uint32_t b = vox_bin[o];
+          const unsigned long long km = T.kmin[e];
+          const uint32_t *pb = pix_bin + (size_t)v * HW;
+          for (int p2 = 0; p2 < HW; p2++) {
+            if (pb[p2] != b) continue;
+            if (ordered_key(pixel_key(c, rc, W, p2, depth[(size_t)v * HW + p2], key_axis)) == km) {
+              pix = (uint32_t)p2;
+              break;
+            }
+          }
+          row = (int)pix / W; col = (int)pix - row * W;
+          pixel_to_lidar(c, rc, col, row, depth[(size_t)v * HW + pix], x, y, z);
+        }
+      }
       uint32_t bits = 0u;
       if (masks) {
         const int m = n_inst[v];
@@ -582,6 +636,7 @@ __global__ __launch_bounds__(256) void k_bp_vox(
     }
     // leave the table clean for the next launch
     T.kmin[e] = ~0ull;
+    T.combo[e] = ~0ull;
     T.cnt[e] = 0u;
     T.first[e] = NOBIN;
     T.rep[e] = NOBIN;
@@ -671,13 +726,13 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
   if (!table || E <= 0) return DFU3D_EINVAL;
   const Table T = table_view(table, E);
   hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(256), 0, (hipStream_t)stream, T.kmin,
-                     T.cnt, T.first, T.rep, E);
+                     T.combo, T.cnt, T.first, T.rep, E);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
 
 // Scratch carve-up of blk_cnt (int32):
-//   [0, V*(nblk+1))                       block counts / offsets
+//   [0, 2*V*(nblk+1))                     look-back words of k_bp_emit (uint64 per block)
 //   then n_ovf[V], ovf_cursor[V], n_amb[V], ovf_cnt[V*cap_ovf], ovf_bins[V*cap_ovf]
 // and of pix_bin (uint32): [0, V*HW) bin ids, [V*HW, 2*V*HW) overflow pixel
 // lists, [2*V*HW, 2*V*HW + V*cap_vox) voxel bin list.
@@ -689,7 +744,7 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   const int64_t nblk = (HW + PBLK - 1) / PBLK;
   const int64_t cap_ovf = HW / (max_points + 1) + 1;
   if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
-  if (blk_words) *blk_words = V * (nblk + 1) + 3 * (int64_t)V + 2 * V * cap_ovf;
+  if (blk_words) *blk_words = 2 * V * (nblk + 1) + 3 * (int64_t)V + 2 * V * cap_ovf;
   return 0;
 }
 
@@ -717,7 +772,10 @@ extern "C" int dfu3d_backproject_bin(
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
   hipStream_t st = (hipStream_t)stream;
-  int *n_ovf = blk_cnt + (size_t)V * (nblk + 1);
+  unsigned long long *lb = (unsigned long long *)blk_cnt;
+  int *n_ovf = blk_cnt + 2 * (size_t)V * (nblk + 1);
+  int pix_bits = 1;
+  while ((1ll << pix_bits) < HW64) pix_bits++;
   int *ovf_cursor = n_ovf + V;
   int *n_amb = ovf_cursor + V;
   int *ovf_cnt = n_amb + V;
@@ -733,11 +791,11 @@ extern "C" int dfu3d_backproject_bin(
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
                      1.0 / geom->vsize_t, 1.0 / geom->vsize_p, W, H, tiles_x, key_axis, E_view,
-                     table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf, ovf_list, n_amb);
+                     table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf, ovf_list, n_amb, pix_bits);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
                      key_axis, E_view, table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf,
-                     ovf_list, n_amb, status);
+                     ovf_list, n_amb, status, pix_bits);
   DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {
@@ -754,23 +812,19 @@ extern "C" int dfu3d_backproject_bin(
                      ovf_bins, n_ovf, ovf_cnt, ovf_list);
   DFU3D_LAUNCH_CHECK();
   }
-  if (phases & DFU3D_BP_REP) {
-  hipLaunchKernelGGL(k_bp_rep, dim3(nblk, V), dim3(PB), 0, st, depth, cal, W, HW, key_axis,
-                     E_view, table, E_total, pix_bin, nblk, blk_cnt);
-  DFU3D_LAUNCH_CHECK();
-  }
+  // DFU3D_BP_REP: nothing to do any more (the representative is resolved per voxel in P4)
   if (phases & DFU3D_BP_EMIT) {
-  hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(1024), 0, st, nblk, blk_cnt, n_vox, cap_vox,
-                     status);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bp_emit, dim3(nblk, V), dim3(PB), 0, st, HW, E_view, table, E_total,
-                     pix_bin, nblk, blk_cnt, cap_vox, vox_bin);
+  const int nblk_e = (HW + EBLK - 1) / EBLK;
+  if (hipMemsetAsync(lb, 0, sizeof(unsigned long long) * (size_t)V * nblk_e, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_bp_emit, dim3(nblk_e, V), dim3(PB), 0, st, HW, E_view, table, E_total,
+                     pix_bin, nblk_e, lb, cap_vox, vox_bin, n_vox, status);
   DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
   hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + 255) / 256, V), dim3(256), 0, st, depth, cal,
                      masks, n_inst, max_inst, W, HW, geom->max_voxels, E_view, table,
-                     E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z);
+                     E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z, pix_bin,
+                     key_axis, pix_bits);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V,
                      geom->max_voxels, cap_vox, n_vox, n_ovf, ovf_cursor);

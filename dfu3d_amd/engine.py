@@ -198,7 +198,7 @@ class PseudoBoxEngine:
                          self.a_x, self.a_y, self.a_z)
         if self.dense and b.depth is not None:
             self._phased("bp_", st.backproject_bin,
-                         (("bin", st.BP_BIN), ("repair", st.BP_REPAIR), ("rep", st.BP_REP),
+                         (("bin", st.BP_BIN), ("repair", st.BP_REPAIR),
                           ("emit", st.BP_EMIT), ("vox", st.BP_VOX)),
                          b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
                          self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,

@@ -79,7 +79,7 @@ def backproject_scratch_words(V, H, W, cap_vox, max_points):
     return a.value, b.value
 
 
-TABLE_ENTRY_BYTES = 20
+TABLE_ENTRY_BYTES = 28
 
 
 def bin_table_init(table, entries_total):

@@ -40,6 +40,7 @@ extern "C" {
 #define DFU3D_VERSION 100          /* 0.1.0 */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
+#define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
 #define DFU3D_MAX_INST 32
 
 #define DFU3D_OK 0
@@ -126,9 +127,9 @@ int dfu3d_project_label(const float *points, const int32_t *pt_off,
  * (instance bits at that pixel; masks may be NULL -> 0).
  * `geom` is a HOST pointer (read at call time).
  * Scratch: pix_bin (uint32 words) and blk_cnt (int32 words) sized by
- * dfu3d_backproject_scratch_words; table: V*table_entries entries of 20 B
- * (uint64 min-key plane, then uint32 count / first-pixel / representative
- * planes), initialised once with dfu3d_bin_table_init and left clean by every
+ * dfu3d_backproject_scratch_words; table: V*table_entries entries of
+ * DFU3D_TABLE_ENTRY_BYTES (uint64 min-key and min-(key|pixel) planes, then
+ * uint32 count / first-pixel / representative planes), initialised once with dfu3d_bin_table_init and left clean by every
  * call that returns without DFU3D_ST_VOX_OVERFLOW. */
 int dfu3d_bin_table_init(void *table, int64_t table_entries_total, void *stream);
 int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
@@ -148,8 +149,8 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
  * on its stream).  The phases of one pass must be issued in this order. */
 #define DFU3D_BP_BIN 1     /* k_bp_bin: back-project + bin + table atomics      */
 #define DFU3D_BP_REPAIR 2  /* overflow-bin repair (no-op kernels when unused)   */
-#define DFU3D_BP_REP 4     /* k_bp_rep: representative + first-pixel counts     */
-#define DFU3D_BP_EMIT 8    /* k_bp_scan + k_bp_emit: ordered voxel list         */
+#define DFU3D_BP_REP 4     /* reserved (no kernel since 0.1.1)                  */
+#define DFU3D_BP_EMIT 8    /* k_bp_emit: ordered voxel list (one pass)          */
 #define DFU3D_BP_VOX 16    /* k_bp_vox + finalize: outputs, table reset         */
 #define DFU3D_BP_ALL 31
 

@@ -17,17 +17,17 @@ def run(ph):
     st.backproject_bin(b.depth, b.calib, b.masks, b.n_inst, V, eng.M, H, W, eng.geom, eng.E, 1, eng.table, eng.pix_bin,
                        eng.blk_cnt, eng.cap_vox, eng.n_vox, eng.vox_pix, eng.b_bits, eng.b_x, eng.b_y, eng.b_z, status, phases=ph)
 def t_all():
-    for ph in (1, 2, 4, 8, 16): run(ph)
+    for ph in (1, 2, 8, 16): run(ph)
 t_all(); torch.cuda.synchronize()
 nblk = (H * W + 1023) // 1024
 # n_amb is reset only by the next BIN phase -> still readable
-amb = eng.blk_cnt[V * (nblk + 1) + 2 * V: V * (nblk + 1) + 3 * V].cpu().numpy()
+amb = eng.blk_cnt[2 * V * (nblk + 1) + 2 * V: 2 * V * (nblk + 1) + 3 * V].cpu().numpy()
 kept = (eng.pix_bin[:V * H * W] != -1).view(V, -1).sum(1).cpu().numpy()
 print("ambiguous per view:", amb[:6], "kept per view:", kept[:6], "frac amb of kept: %.4f" % (amb.sum() / kept.sum()))
-for name, ph in (("bin", 1), ("repair", 2), ("rep", 4), ("emit", 8), ("vox", 16)):
+for name, ph in (("bin", 1), ("repair", 2), ("emit", 8), ("vox", 16)):
     ts = []
     for _ in range(3):
-        for q in (1, 2, 4, 8, 16):
+        for q in (1, 2, 8, 16):
             if q == ph:
                 torch.cuda.synchronize(); t0 = time.perf_counter(); run(q); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
             else:
