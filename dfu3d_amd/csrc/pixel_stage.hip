@@ -148,11 +148,28 @@ __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix,
 
 constexpr uint32_t AMBIG = 0xFFFFFFFEu;
 
+// constants of the tier-1 classification, prepared on the host
+struct FastGeom {
+  float r_lo, r_hi, theta_min;
+  double inv_t, inv_p;
+};
+inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
+  FastGeom f;
+  // r certain only for the 1-cell grid and well inside it; otherwise an empty interval
+  f.r_lo = (g.grid_r == 1) ? (float)(g.rmin_r + 2e-3) : 1.0f;
+  f.r_hi = (g.grid_r == 1) ? (float)((g.rmin_r + g.vsize_r) * 0.9998) : 0.0f;
+  f.theta_min = (float)g.theta_min;
+  f.inv_t = 1.0 / g.vsize_t;
+  f.inv_p = 1.0 / g.vsize_p;
+  return f;
+}
+
 // fp32 estimates of the spherical angles of an fp64 point, each with a bound on
 // |estimate - fp64 value| (my_loader.py:166-169 evaluated in double).  Error budget:
-//   cz = zf/rf       relative 3.3e-7 (three float conversions, the sum of squares, sqrtf, the
-//                    division), i.e. <= 3.3e-7/sin(theta) in theta; acosf <= 4 ulp <= 1e-6
-//   ph = atanf(y/x)  <= 1e-7 from the ratio, atanf <= 5 ulp <= 6e-7
+//   cz = zf/rf       relative 5.1e-7 (three float conversions, the sum of squares, v_sqrt and
+//                    v_rcp at 1 ulp each, one product), i.e. <= 5.1e-7/sin(theta) in theta;
+//                    acosf <= 4 ulp <= 1e-6
+//   ph = atanf(y/x)  <= 1.5e-7 from the ratio (v_rcp), atanf <= 5 ulp <= 6e-7
 // eps_t / eps_p carry a factor >= 3 on top; dfu3d_selftest_angles() measures the real
 // ratio error/bound on the device and the GPU tests require it to stay below 0.5.
 // Returns false where no bound is given (origin, poles, x == 0).
@@ -160,15 +177,15 @@ __device__ __forceinline__ bool angle_estimate(double x, double y, double z, flo
                                                float &eps_t, float &ph, float &eps_p) {
   const float xf = (float)x, yf = (float)y, zf = (float)z;
   const float r2 = xf * xf + yf * yf + zf * zf;
-  rf = sqrtf(r2);
+  rf = __builtin_amdgcn_sqrtf(r2);                               // 1 ulp, no denormal handling needed
   if (!(rf > 1e-3f) || !(rf < 1e15f)) return false;
-  const float cz = zf / rf;
+  const float cz = zf * __builtin_amdgcn_rcpf(rf);                // 1 ulp reciprocal
   const float s2 = 1.0f - cz * cz;
   if (!(s2 > 1e-4f)) return false;                                // near the poles: d(acos) blows up
   th = acosf(cz);
   eps_t = 3e-6f + 1e-6f * rsqrtf(s2);
   if (!(fabsf(xf) > 1e-20f)) return false;
-  ph = atanf(yf / xf);
+  ph = atanf(yf * __builtin_amdgcn_rcpf(xf));
   eps_p = 3e-6f;
   return true;
 }
@@ -180,8 +197,8 @@ __device__ __forceinline__ bool angle_estimate(double x, double y, double z, flo
 // the fp64 path of pixel_bin() would decide identically.  Everything else
 // returns AMBIG and is classified by pixel_bin() in k_bp_bin_amb.
 __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc,
-                                                   const dfu3d_bin_geom &g,
-                                                   double inv_t, double inv_p, int row, int col,
+                                                   const dfu3d_bin_geom &g, const FastGeom &fg,
+                                                   int row, int col,
                                                    float d, int key_axis, double &key, int &it_out,
                                                    int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
@@ -193,14 +210,12 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
   float rf, th, eps_t, ph, eps_p;
   if (!angle_estimate(x, y, z, rf, th, eps_t, ph, eps_p)) return AMBIG;
   // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
-  if (g.grid_r != 1 || !((double)rf * 1.0001 < g.rmin_r + g.vsize_r) ||
-      !((double)rf > g.rmin_r + 1e-3))
-    return AMBIG;
-  if (th < (float)g.theta_min - eps_t) return NOBIN;              // certainly theta <= theta_min
-  if (!(th > (float)g.theta_min + eps_t)) return AMBIG;
-  const double qt = ((double)th - g.rmin_t) * inv_t, qp = ((double)ph - g.rmin_p) * inv_p;
+  if (!(rf > fg.r_lo && rf < fg.r_hi)) return AMBIG;
+  if (th < fg.theta_min - eps_t) return NOBIN;                    // certainly theta <= theta_min
+  if (!(th > fg.theta_min + eps_t)) return AMBIG;
+  const double qt = ((double)th - g.rmin_t) * fg.inv_t, qp = ((double)ph - g.rmin_p) * fg.inv_p;
   const double ft = qt - floor(qt), fp = qp - floor(qp);
-  const double mt = (double)eps_t * inv_t + 1e-6, mp = (double)eps_p * inv_p + 1e-6;
+  const double mt = (double)eps_t * fg.inv_t + 1e-6, mp = (double)eps_p * fg.inv_p + 1e-6;
   if (!(ft > mt && ft < 1.0 - mt && fp > mp && fp < 1.0 - mp)) return AMBIG;
   const int it = (int)floor(qt) - g.t_lo, ip = (int)floor(qp) - g.p_lo;
   if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) return AMBIG;
@@ -219,7 +234,7 @@ constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x ph
 
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
-    dfu3d_bin_geom g, double inv_t, double inv_p, int W, int H, int tiles_x, int key_axis,
+    dfu3d_bin_geom g, FastGeom fg, int W, int H, int tiles_x, int key_axis,
     int64_t E_view, void *table, int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
     uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf, uint32_t *__restrict__ amb_list,
     int *__restrict__ n_amb, int pix_bits) {
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       keys[k] = 0.0;
       if (col + k < W) {
         its[k] = 0; ips[k] = 0;
-        const uint32_t b = pixel_bin_fast(c, rc, g, inv_t, inv_p, row, col + k, d[k], key_axis, keys[k],
+        const uint32_t b = pixel_bin_fast(c, rc, g, fg, row, col + k, d[k], key_axis, keys[k],
                                           its[k], ips[k]);
         if (b == AMBIG) {
           s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
@@ -279,30 +294,49 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   if (t0 == -12345)
 #endif
   if (inside) {
-#pragma unroll
-    for (int k = 0; k < PPT; k++) {
-      const uint32_t b = bins[k];
-      if (b == NOBIN) continue;
-      const int lt = its[k] - t0, lp = ips[k] - p0;
+    // runs of equal bins among the thread's four consecutive pixels are merged first
+    auto commit = [&](uint32_t b, int it, int ip, uint32_t c, uint32_t f, unsigned long long ok,
+                      unsigned long long cm) {
+      const int lt = it - t0, lp = ip - p0;
       if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
         const int w = lt * WIN_P + lp;
-        atomicAdd(&s_cnt[w], 1u);
-        atomicMin(&s_first[w], (uint32_t)(base + k));
-        const unsigned long long ok = ordered_key(keys[k]);
+        atomicAdd(&s_cnt[w], c);
+        atomicMin(&s_first[w], f);
         atomicMin(&s_kmin[w], ok);
-        atomicMin(&s_combo[w], combo_word(ok, (uint32_t)(base + k), pix_bits));
+        atomicMin(&s_combo[w], cm);
       } else {                                                    // outside the window: direct
         const int64_t e = tb0 + b;
-        const uint32_t old = atomicAdd(&T.cnt[e], 1u);
-        atomicMin(&T.first[e], (uint32_t)(base + k));
-        atomicMin(&T.kmin[e], ordered_key(keys[k]));
-        atomicMin(&T.combo[e], combo_word(ordered_key(keys[k]), (uint32_t)(base + k), pix_bits));
-        if (old == (uint32_t)g.max_points_per_voxel) {
+        const uint32_t old = atomicAdd(&T.cnt[e], c);
+        atomicMin(&T.first[e], f);
+        atomicMin(&T.kmin[e], ok);
+        atomicMin(&T.combo[e], cm);
+        const uint32_t mx = (uint32_t)g.max_points_per_voxel;
+        if (old <= mx && old + c > mx) {                          // this add crossed the cap
           const int slot = atomicAdd(&n_ovf[v], 1);
           if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
         }
       }
+    };
+    uint32_t rb = NOBIN, rc = 0u, rfirst = 0u;
+    unsigned long long rk = ~0ull, rcm = ~0ull;
+    int rit = 0, rip = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const uint32_t b = bins[k];
+      if (b != rb) {
+        if (rb != NOBIN) commit(rb, rit, rip, rc, rfirst, rk, rcm);
+        rb = b; rc = 0u; rk = ~0ull; rcm = ~0ull;
+        rfirst = (uint32_t)(base + k); rit = its[k]; rip = ips[k];
+      }
+      if (b != NOBIN) {
+        const unsigned long long ok = ordered_key(keys[k]);
+        const unsigned long long cm = combo_word(ok, (uint32_t)(base + k), pix_bits);
+        rc++;
+        rk = ok < rk ? ok : rk;
+        rcm = cm < rcm ? cm : rcm;
+      }
     }
+    if (rb != NOBIN) commit(rb, rit, rip, rc, rfirst, rk, rcm);
   }
   __syncthreads();
   // flush the window: one set of global atomics per touched bin
@@ -790,7 +824,7 @@ extern "C" int dfu3d_backproject_bin(
   if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 3 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
-                     1.0 / geom->vsize_t, 1.0 / geom->vsize_p, W, H, tiles_x, key_axis, E_view,
+                     make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view,
                      table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf, ovf_list, n_amb, pix_bits);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,

@@ -48,7 +48,7 @@ class PseudoBoxEngine:
     def __init__(self, params: Params, H: int, W: int, max_inst: int, cap_n: int,
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
-                 device="cuda:0", apply_fov: bool = True, lanes: int = 1):
+                 device="cuda:0", apply_fov: bool = True, lanes: int = 1, graphs: bool = False):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         if tuple(params.bounds_hw) != (int(H), int(W)):
@@ -70,6 +70,12 @@ class PseudoBoxEngine:
         # dealt round-robin so that the long single-workgroup tails of one chunk
         # (clustering / L-shape of a huge instance) overlap the streaming kernels
         # of the others.
+        # graphs=True: the launch chain of every chunk is captured into a hipGraph the first time a
+        # batch (identified by the addresses of its tensors) is seen and replayed afterwards --
+        # no per-launch host work, no gaps between the ~50 kernels of a chunk.
+        self.graphs = bool(graphs)
+        self._graph_key = None
+        self._graph_state = None
         self.lanes = [self._make_lane(i, cap_n) for i in range(max(1, int(lanes)))]
         self._bind(self.lanes[0])
         # optional per-kernel timing with HIP events on the launch stream
@@ -82,7 +88,8 @@ class PseudoBoxEngine:
 
     def _make_lane(self, index, cap_n):
         L = PseudoBoxEngine._Lane()
-        L.stream = torch.cuda.current_stream(self.dev) if index == 0 else torch.cuda.Stream(self.dev)
+        L.stream = (torch.cuda.current_stream(self.dev) if index == 0 and not self.graphs
+                    else torch.cuda.Stream(self.dev))
         with torch.cuda.stream(L.stream):
             V, S = self.Vc, self.Vc * self.M
             d = self.dev
@@ -259,6 +266,8 @@ class PseudoBoxEngine:
             raise Dfu3dError("depth: expected shape %s" % ((V, self.H, self.W),))
         nch = V // self.Vc
         d = self.dev
+        if self.graphs and not self.timing:
+            return self._run_graphed(b, nch, sync)
         rows = torch.empty((nch, self.cap_rows * st.ROW_DOUBLES), dtype=torch.float64, device=d)
         n_rows = torch.zeros((nch,), dtype=torch.int32, device=d)
         status = torch.zeros((nch,), dtype=torch.int32, device=d)
@@ -274,6 +283,48 @@ class PseudoBoxEngine:
                 self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
                             status[c:c + 1])
         for L in self.lanes[1:]:
+            main.wait_stream(L.stream)
+        self._last = (rows, n_rows, status)
+        if not sync:
+            return None, None
+        return self.collect()
+
+    @staticmethod
+    def _batch_key(b: ViewBatch):
+        return tuple((k, t.data_ptr(), tuple(t.shape)) for k, t in sorted(b.__dict__.items())
+                     if isinstance(t, torch.Tensor))
+
+    def _run_graphed(self, b: ViewBatch, nch: int, sync: bool):
+        d = self.dev
+        main = torch.cuda.current_stream(d)
+        key = self._batch_key(b)
+        if key != self._graph_key:
+            # static outputs + one captured graph per chunk (on the chunk's lane)
+            rows = torch.empty((nch, self.cap_rows * st.ROW_DOUBLES), dtype=torch.float64, device=d)
+            n_rows = torch.zeros((nch,), dtype=torch.int32, device=d)
+            status = torch.zeros((nch,), dtype=torch.int32, device=d)
+            torch.cuda.synchronize(d)
+            graphs = []
+            for c in range(nch):
+                L = self.lanes[c % len(self.lanes)]
+                self._bind(L)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=L.stream):
+                    n_rows[c:c + 1].zero_()
+                    status[c:c + 1].zero_()
+                    self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
+                                status[c:c + 1])
+                graphs.append(g)
+            torch.cuda.synchronize(d)
+            self._graph_key = key
+            self._graph_state = (graphs, rows, n_rows, status, b)     # b: keeps the captured addresses alive
+        graphs, rows, n_rows, status, _ = self._graph_state
+        for L in self.lanes:
+            L.stream.wait_stream(main)
+        for c, g in enumerate(graphs):
+            with torch.cuda.stream(self.lanes[c % len(self.lanes)].stream):
+                g.replay()
+        for L in self.lanes:
             main.wait_stream(L.stream)
         self._last = (rows, n_rows, status)
         if not sync:
