@@ -132,6 +132,8 @@ __device__ __forceinline__ int block_sum_i(int v, int *s_red) {
   return t;
 }
 
+constexpr int RB = 16;   // RANSAC trials scored per sweep over the candidates
+
 __global__ __launch_bounds__(NT) void k_plane_ransac(
     const float4 *__restrict__ pts, const int *__restrict__ pt_off,
     const int *__restrict__ view_frame, const int *__restrict__ fov_idx,
@@ -143,6 +145,8 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
   __shared__ unsigned long long s_sel[2];
   __shared__ double s_red[NW];
   __shared__ int s_redi[NW];
+  __shared__ double s_model[RB][3];
+  __shared__ int s_valid[RB], s_tot[RB], s_cnt[NW][RB];
   const int v = blockIdx.x;
   const int p0 = pt_off[view_frame[v]];
   const int nf = n_fov[v];
@@ -176,38 +180,77 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
   auto dev = [&](int i) { return fabs((double)pts[p0 + cidx[i]].z - med); };
   const double thr = block_median(n, dev, s_hist, s_sel);
 
+  // trials in batches of RB: thread t < RB draws the samples of trial t0+t and fits its
+  // plane, then every thread scores its points against the RB planes at once and the RB
+  // inlier counts are reduced together (3 barriers per batch instead of 2 per trial);
+  // the winner is still the FIRST trial with the largest count
   int best_cnt = -1;
   double ba = 0.0, bb = 0.0, bc = 0.0;
   const unsigned long long vkey = (unsigned long long)key[v];
-  for (int t = 0; t < trials; t++) {
-    // every thread derives the same three sample indices
-    int idx[3];
-    int got = 0;
-    for (int a = 0; a < 64 && got < 3; a++) {
-      const unsigned long long r = mix64(seed ^ mix64((vkey << 20) ^ ((unsigned long long)t << 8) ^ (unsigned long long)a));
-      const int i = (int)__umul64hi(r, (unsigned long long)n);
-      bool dup = false;
-      for (int q = 0; q < got; q++) dup |= (idx[q] == i);
-      if (!dup) idx[got++] = i;
+  for (int t0 = 0; t0 < trials; t0 += RB) {
+    if (threadIdx.x < RB) {
+      const int t = t0 + (int)threadIdx.x;
+      bool valid = false;
+      double ca = 0.0, cb = 0.0, cc = 0.0;
+      if (t < trials) {
+        int idx[3];
+        int got = 0;
+        for (int a = 0; a < 64 && got < 3; a++) {
+          const unsigned long long r = mix64(seed ^ mix64((vkey << 20) ^ ((unsigned long long)t << 8) ^ (unsigned long long)a));
+          const int i = (int)__umul64hi(r, (unsigned long long)n);
+          bool dup = false;
+          for (int q = 0; q < got; q++) dup |= (idx[q] == i);
+          if (!dup) idx[got++] = i;
+        }
+        if (got == 3) {
+          const float4 q0 = pts[p0 + cidx[idx[0]]], q1 = pts[p0 + cidx[idx[1]]], q2 = pts[p0 + cidx[idx[2]]];
+          const double x0 = q0.x, y0 = q0.y, z0 = q0.z;
+          const double dx1 = (double)q1.x - x0, dy1 = (double)q1.y - y0, dz1 = (double)q1.z - z0;
+          const double dx2 = (double)q2.x - x0, dy2 = (double)q2.y - y0, dz2 = (double)q2.z - z0;
+          const double det = dx1 * dy2 - dx2 * dy1;
+          if (fabs(det) > 1e-12) {
+            ca = (dz1 * dy2 - dz2 * dy1) / det;
+            cb = (dx1 * dz2 - dx2 * dz1) / det;
+            cc = (z0 - ca * x0) - cb * y0;
+            valid = true;
+          }
+        }
+      }
+      s_model[threadIdx.x][0] = ca; s_model[threadIdx.x][1] = cb; s_model[threadIdx.x][2] = cc;
+      s_valid[threadIdx.x] = valid ? 1 : 0;
     }
-    if (got < 3) continue;
-    const float4 q0 = pts[p0 + cidx[idx[0]]], q1 = pts[p0 + cidx[idx[1]]], q2 = pts[p0 + cidx[idx[2]]];
-    const double x0 = q0.x, y0 = q0.y, z0 = q0.z;
-    const double dx1 = (double)q1.x - x0, dy1 = (double)q1.y - y0, dz1 = (double)q1.z - z0;
-    const double dx2 = (double)q2.x - x0, dy2 = (double)q2.y - y0, dz2 = (double)q2.z - z0;
-    const double det = dx1 * dy2 - dx2 * dy1;
-    if (!(fabs(det) > 1e-12)) continue;
-    const double ca = (dz1 * dy2 - dz2 * dy1) / det;
-    const double cb = (dx1 * dz2 - dx2 * dz1) / det;
-    const double cc = (z0 - ca * x0) - cb * y0;
-    int cnt = 0;
+    __syncthreads();
+    int cnt[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) cnt[k] = 0;
     for (int i = threadIdx.x; i < n; i += NT) {
       const float4 p = pts[p0 + cidx[i]];
-      const double res = fabs((double)p.z - ((ca * (double)p.x + cb * (double)p.y) + cc));
-      cnt += (res <= thr) ? 1 : 0;
+      const double px_ = (double)p.x, py_ = (double)p.y, pz_ = (double)p.z;
+#pragma unroll
+      for (int k = 0; k < RB; k++) {
+        const double res = fabs(pz_ - ((s_model[k][0] * px_ + s_model[k][1] * py_) + s_model[k][2]));
+        cnt[k] += (res <= thr) ? 1 : 0;
+      }
     }
-    cnt = block_sum_i(cnt, s_redi);
-    if (cnt > best_cnt) { best_cnt = cnt; ba = ca; bb = cb; bc = cc; }
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+      const int c = wave_sum_i(cnt[k]);
+      if (lane_id() == 0) s_cnt[threadIdx.x >> 6][k] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < RB) {
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) c += s_cnt[w][threadIdx.x];
+      s_tot[threadIdx.x] = c;
+    }
+    __syncthreads();
+    for (int k = 0; k < RB; k++) {                 // in trial order, in every thread alike
+      if (!s_valid[k]) continue;
+      const int c = s_tot[k];
+      if (c > best_cnt) { best_cnt = c; ba = s_model[k][0]; bb = s_model[k][1]; bc = s_model[k][2]; }
+    }
+    __syncthreads();
   }
   if (best_cnt < 0) {
     if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 1e30; }
