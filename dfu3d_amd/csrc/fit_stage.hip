@@ -708,7 +708,7 @@ __global__ __launch_bounds__(CT) void k_range_cluster_large(
 constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
-constexpr int LDS_MEMBERS = 1024;   // clusters up to this size: members cached in LDS, one wave per heading
+constexpr int LDS_MEMBERS = 4096;   // clusters up to this size: members cached in LDS, one wave per heading
 constexpr int TB = 8;               // larger clusters: headings per point-parallel sweep
 
 // block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
@@ -1211,8 +1211,11 @@ __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ 
       double acc[4 * TB];
 #pragma unroll
       for (int t = 0; t < TB; t++) { acc[4 * t] = INFINITY; acc[4 * t + 1] = -INFINITY; acc[4 * t + 2] = INFINITY; acc[4 * t + 3] = -INFINITY; }
+      double xn = 0.0, yn = 0.0;
+      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
       for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
+        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
+        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
 #pragma unroll
         for (int t = 0; t < TB; t++) {
           const double ct = s_ct[t], st = s_st[t];
@@ -1238,8 +1241,11 @@ __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ 
       // sums and counts of E1 / E2
 #pragma unroll
       for (int k = 0; k < 4 * TB; k++) acc[k] = 0.0;
+      xn = 0.0; yn = 0.0;
+      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
       for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
+        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
+        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
 #pragma unroll
         for (int t = 0; t < TB; t++) {
           const double ct = s_ct[t], st = s_st[t];
@@ -1267,8 +1273,11 @@ __global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ 
       // squared deviations from the means
 #pragma unroll
       for (int k = 0; k < 2 * TB; k++) acc[k] = 0.0;
+      xn = 0.0; yn = 0.0;
+      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
       for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = mx[i], y = my[i];
+        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
+        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
 #pragma unroll
         for (int t = 0; t < TB; t++) {
           const double ct = s_ct[t], st = s_st[t];

@@ -170,12 +170,19 @@ __global__ __launch_bounds__(QT) void k_radius_flags(
   int s = find_segment(tile_off, S, t);
   const int lane = lane_id();
   const int w_in_tile = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  // segment facts stay in registers while consecutive tiles belong to the same segment
+  int t_first = tile_off[s], t_next = tile_off[s + 1];
+  int n = seg_cnt[s];
+  long long base = seg_base[s];
+  double r = radius[s];
   for (; t < t_end; t++) {
-    while (tile_off[s + 1] <= t) s++;
-    const int n = seg_cnt[s];
-    const long long base = seg_base[s];
-    const double r = radius[s];
-    const int w0 = (t - tile_off[s]) * QT + w_in_tile;     // first point of this wave (uniform)
+    if (t >= t_next) {
+      do { s++; t_first = t_next; t_next = tile_off[s + 1]; } while (t >= t_next);
+      n = seg_cnt[s];
+      base = seg_base[s];
+      r = radius[s];
+    }
+    const int w0 = (t - t_first) * QT + w_in_tile;         // first point of this wave (uniform)
     if (w0 >= n) continue;
     const int q = w0 + lane;
     const bool valid = q < n;

@@ -124,7 +124,10 @@ class PseudoBoxEngine:
             L.base_a = torch.empty(S, dtype=torch.int64, device=d)
             L.base_b = torch.empty(S, dtype=torch.int64, device=d)
             L.cnt_a, L.cnt_b, L.cnt_all = i32(S), i32(S), i32(S)
-            L.tile_off = i32(S + 1)
+            L.tile_off = i32(2 * S + 1)
+            L.base_ab = torch.empty(2 * S, dtype=torch.int64, device=d)
+            L.cnt_ab = i32(2 * S)
+            L.rad_ab = f64(2 * S)
             L.queue = i32(2 + 2 * pc)
             L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
             L.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
@@ -151,7 +154,10 @@ class PseudoBoxEngine:
     def _phased(self, prefix, fn, phases, *a):
         """Issue a multi-kernel stage phase by phase so each kernel is bracketed."""
         if not self.timing:
-            return fn(*a)
+            allbits = 0
+            for _, bit in phases:
+                allbits |= bit
+            return fn(*a, phases=allbits)
         for tag, bit in phases:
             self._run(prefix + tag, fn, *a, phases=bit)
 
@@ -224,20 +230,27 @@ class PseudoBoxEngine:
                  ("compact", st.RF_COMPACT))
         if self.timing:
             self.rf_points += self.cnt_a.sum() + self.cnt_b.sum()
-        self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
-                     self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
-                     self.queue)
-        # pseudo lists: flags only -- the fuse below compacts once for both filters, unless the
-        # (dormant) statistical filter sits in between and needs the filtered lists
         fused = not p.stat_filter
-        if fused and not self.timing:
-            st.radius_filter(self.px, self.py, self.pz, self.base_b, self.cnt_b, rp, p.nb_points, S,
-                             self.pool_cap, self.tile_off, self.flags, self.queue,
-                             phases=st.RF_ALL & ~st.RF_COMPACT)
-        else:
-            self._phased("rf_", st.radius_filter, rf_ph[:3] if fused else rf_ph, self.px, self.py, self.pz,
-                         self.base_b, self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off,
+        if fused:
+            # ONE flag pass over the LiDAR and the pseudo lists of all instances (2S segments);
+            # the LiDAR lists are compacted in place, the pseudo lists stay as they are -- the
+            # fuse below compacts them once for both filters (dfu3d_ballquery_fuse_masked)
+            torch.cat((self.base_a, self.base_b), out=self.base_ab)
+            torch.cat((self.cnt_a, self.cnt_b), out=self.cnt_ab)
+            torch.cat((rl, rp), out=self.rad_ab)
+            self._phased("rf_", st.radius_filter, rf_ph[:3], self.px, self.py, self.pz, self.base_ab,
+                         self.cnt_ab, self.rad_ab, p.nb_points, 2 * S, self.pool_cap, self.tile_off,
                          self.flags, self.queue)
+            self._run("rf_compact", st.radius_filter, self.px, self.py, self.pz, self.base_a, self.cnt_a,
+                      rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags, self.queue,
+                      phases=st.RF_COMPACT)
+        else:           # the (dormant) statistical filter sits in between and needs the filtered lists
+            self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
+                         self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
+                         self.queue)
+            self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_b,
+                         self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
+                         self.queue)
         if p.stat_filter:
             R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
