@@ -5,6 +5,8 @@ hand-written kernel is launched (a faulting kernel can reset the whole node).
 """
 import ctypes
 import math
+
+import numpy as np
 from dataclasses import dataclass
 
 import torch
@@ -246,6 +248,50 @@ def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, til
         float(C), S, pool_cap, _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
         _chk(flags, "flags", torch.uint8, numel=pool_cap), _stream())
     _lib.check(rc, "dfu3d_ballquery_fuse")
+
+
+def points_in_boxes_mask(points, boxes):
+    """points (n,3|4) float32 CUDA, boxes (B,7) float64 CUDA -> int32 (B,n)
+    (roiaware_pool3d_utils.points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/roiaware_pool3d_utils.py:9-25)."""
+    if points.dim() != 2 or points.shape[1] not in (3, 4) or boxes.dim() != 2 or boxes.shape[1] != 7:
+        raise Dfu3dError("points must be (n,3|4), boxes (B,7)")
+    n, B = int(points.shape[0]), int(boxes.shape[0])
+    out = torch.zeros((B, n), dtype=torch.int32, device=points.device)
+    rc = _lib.lib().dfu3d_points_in_boxes_mask(
+        _chk(points, "points", torch.float32, numel=n * points.shape[1]), n, int(points.shape[1]),
+        _chk(boxes, "boxes", torch.float64, numel=B * 7), B, _chk(out, "out", torch.int32, numel=B * n),
+        _stream())
+    _lib.check(rc, "dfu3d_points_in_boxes_mask")
+    return out
+
+
+def gt_database(points, pt_off, box_frame, boxes, cap_out, host_pt_off=None):
+    """Many frames at once -> (box_cnt (Bt,), box_off (Bt+1,), idx (cap_out,), gt_pts (cap_out,4), status)."""
+    Bt = int(boxes.shape[0])
+    dev = points.device
+    if Bt == 0:
+        raise Dfu3dError("no boxes")
+    if points.dim() != 2 or points.shape[1] != 4:
+        raise Dfu3dError("points must be (N,4) float32")
+    if host_pt_off is not None:
+        hp = np.asarray(host_pt_off)
+        if hp[0] != 0 or np.any(np.diff(hp) < 0) or hp[-1] > points.shape[0]:
+            raise Dfu3dError("pt_off must be non-decreasing within the point tensor")
+    cnt = torch.zeros(Bt, dtype=torch.int32, device=dev)
+    off = torch.zeros(Bt + 1, dtype=torch.int64, device=dev)
+    idx = torch.empty(cap_out, dtype=torch.int32, device=dev)
+    gt = torch.empty((cap_out, 4), dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().dfu3d_gt_database(
+        _chk(points, "points", torch.float32, numel=points.shape[0] * 4),
+        _chk(pt_off, "pt_off", torch.int32, min_numel=2),
+        _chk(box_frame, "box_frame", torch.int32, numel=Bt),
+        _chk(boxes, "boxes", torch.float64, numel=Bt * 7), Bt,
+        _chk(cnt, "cnt", torch.int32, numel=Bt), _chk(off, "off", torch.int64, numel=Bt + 1), int(cap_out),
+        _chk(idx, "idx", torch.int32, numel=cap_out), _chk(gt, "gt", torch.float32, numel=cap_out * 4),
+        _chk(status, "status", torch.int32, numel=1), _stream())
+    _lib.check(rc, "dfu3d_gt_database")
+    return cnt, off, idx, gt, status
 
 
 def selftest_angles(n, seed=1, range_xy=100.0, z_lo=-6.0, z_hi=1.0, device="cuda:0"):

@@ -220,6 +220,30 @@ int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
                                 int32_t S, int64_t pool_cap, int32_t *tile_off,
                                 uint8_t *flags, void *stream);
 
+/* ---- f-2: points in boxes / ground-truth database --------------------------
+ * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-171 points_in_boxes_cpu;
+ *  pcdet/datasets/kitti/kitti_dataset.py:284-331 create_groundtruth_database)
+ * boxes: float64 (B,7) [x y z dx dy dz heading] in the LiDAR frame (converted to
+ * float32 for the test exactly as the reference's `.float()` does).
+ * dfu3d_points_in_boxes_mask: one frame, pts float32 with row stride pt_stride
+ * (3 or 4 floats), out int32 (B,n) = the reference's return value.
+ * dfu3d_gt_database: many frames at once.  points (N,4) float32 packed by frame
+ * (pt_off), box b belongs to frame box_frame[b].  Outputs: box_cnt[b] points
+ * inside box b; box_off (Bt+1) exclusive scan; for box b, at
+ * [box_off[b], box_off[b+1]): idx_out = in-frame point indices in ascending
+ * order, gt_pts (.,4) float32 = (float32)(double(xyz) - box centre), intensity
+ * -- the bytes kitti_dataset.py:317-321 writes to gt_database/<frame>_<class>_<i>.bin.
+ * More than cap_out points in total raise DFU3D_ST_POOL_OVERFLOW (counts stay
+ * exact, lists are cut). */
+int dfu3d_points_in_boxes_mask(const float *pts, int32_t n, int32_t pt_stride,
+                               const double *boxes, int32_t B, int32_t *out,
+                               void *stream);
+int dfu3d_gt_database(const float *points, const int32_t *pt_off,
+                      const int32_t *box_frame, const double *boxes, int32_t Bt,
+                      int32_t *box_cnt, int64_t *box_off, int64_t cap_out,
+                      int32_t *idx_out, float *gt_pts, uint32_t *status,
+                      void *stream);
+
 /* ---- self test of the two-tier bin classification ---------------------------
  * dfu3d_backproject_bin decides a pixel's spherical bin from fp32 angle
  * estimates when they are farther from every bin edge than a bound on their
