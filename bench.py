@@ -101,6 +101,9 @@ def main():
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2: 3.7k vs 4.7k frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="after the timed region, time the same kernels once more with nothing else on the GPU (one stream, "
+                         "all frames in one launch chain) and report them under \"single_stream\"")
     ap.add_argument("--timing-steps", type=int, default=3,
                     help="steps of the timed region whose kernels are bracketed with HIP events (the brackets "
                          "split multi-kernel stages into separate calls and cost a few percent)")
@@ -224,6 +227,34 @@ def main():
                 out["radius_filter_roofline"] = {"achieved": rf["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                                  "unit": "GB/s", "frac": round(rf["achieved_GBs"] / HBM_PEAK_GBS, 6),
                                                  "points_per_launch": int(rf_pts / max(n_rf_launch, 1))}
+        if kern and world == 1 and args.single_stream:
+            # the same kernels with nothing else on the GPU: one stream, all frames in one launch chain.
+            # (Informational, outside the timed region: with several streams the durations above include the
+            # contention that buys the overlap of the single-workgroup tails.)
+            del eng
+            torch.cuda.empty_cache()
+            eng1 = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=frames * CAMS, dense=dense,
+                                   cap_vox=1 << 18, pool_per_view=1 << 17, device=dev, lanes=1)
+            eng1.run(batch)
+            eng1.timing = True
+            eng1.reset_timing()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng1.run(batch)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) / 3 * 1e3
+            k1 = eng1.timing_summary()
+            v1 = frames * CAMS
+            pts1 = eng1.rf_points_total() / max(k1.get("rf_flags", (0, 1))[1], 1)
+            ss = {"ms_per_step": round(ms1, 3), "frames_per_s": round(frames / (ms1 * 1e-3), 1)}
+            for name, byts in (("bp_bin", v1 * H * W * 4), ("bp_emit", v1 * H * W * 4), ("rf_flags", 21.0 * pts1)):
+                if name in k1:
+                    avg = k1[name][0] / k1[name][1]
+                    ss[name] = {"avg_ms": round(avg, 4), "achieved_GBs": round(byts / (avg * 1e-3) / 1e9, 1),
+                                "frac": round(byts / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            out["single_stream"] = ss
+            del eng1
         if cpu_scenes is not None and world == 1:
             fps, nf, secs = cpu_baseline(cpu_scenes, params, dense)
             out["cpu_baseline"] = {"value": round(fps, 4), "unit": "frames/s", "cores": 1, "kind": "port",
