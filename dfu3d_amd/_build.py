@@ -29,7 +29,8 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(INCLUDE, "dfu3d.h")]
+    deps = (sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
+            + [os.path.join(INCLUDE, "dfu3d.h")])
     return any(os.path.getmtime(d) > t for d in deps)
 
 

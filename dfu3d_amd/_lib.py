@@ -64,6 +64,8 @@ SIGNATURES = {
                                     _P]),
     "dfu3d_points_in_boxes_mask": (c_i32, [_P, c_i32, c_i32, _P, c_i32, _P, _P]),
     "dfu3d_gt_database": (c_i32, [_P, _P, _P, _P, c_i32, _P, _P, c_i64, _P, _P, _P, _P]),
+    "dfu3d_boxes_bev": (c_i32, [_P, c_i32, _P, c_i32, _P, c_i32, _P]),
+    "dfu3d_nms_bev": (c_i32, [_P, c_i32, ctypes.c_float, _P, _P, _P, _P]),
     "dfu3d_selftest_angles": (c_i32, [c_i64, ctypes.c_uint64, c_f64, c_f64, c_f64, _P, _P]),
     "dfu3d_lshape_fit_ws_doubles": (c_i64, [c_i64, c_i32]),
     "dfu3d_lshape_fit": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, _P, _P, _P, _P, _P,

@@ -294,6 +294,35 @@ def gt_database(points, pt_off, box_frame, boxes, cap_out, host_pt_off=None):
     return cnt, off, idx, gt, status
 
 
+def boxes_bev(boxes_a, boxes_b, iou=True):
+    """(N,7),(M,7) float32 CUDA -> (N,M) float32 BEV IoU (iou=True) or overlap area."""
+    n, m = int(boxes_a.shape[0]), int(boxes_b.shape[0])
+    out = torch.zeros((n, m), dtype=torch.float32, device=boxes_a.device)
+    if n == 0 or m == 0:
+        return out
+    rc = _lib.lib().dfu3d_boxes_bev(_chk(boxes_a, "boxes_a", torch.float32, numel=n * 7), n,
+                                    _chk(boxes_b, "boxes_b", torch.float32, numel=m * 7), m,
+                                    _chk(out, "out", torch.float32, numel=n * m), 1 if iou else 0, _stream())
+    _lib.check(rc, "dfu3d_boxes_bev")
+    return out
+
+
+def nms_bev(boxes, thresh):
+    """boxes (N,7) float32 CUDA sorted by descending score -> (keep int64 (N,), number kept)."""
+    n = int(boxes.shape[0])
+    dev = boxes.device
+    keep = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+    if n == 0:
+        return keep[:0], 0
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    mask = torch.empty(max(n * ((n + 63) // 64), 1), dtype=torch.int64, device=dev)
+    rc = _lib.lib().dfu3d_nms_bev(_chk(boxes, "boxes", torch.float32, numel=n * 7), n, ctypes.c_float(thresh),
+                                  _chk(mask, "mask", torch.int64, min_numel=1), _chk(keep, "keep", torch.int64, min_numel=1),
+                                  _chk(num, "num_keep", torch.int32, numel=1), _stream())
+    _lib.check(rc, "dfu3d_nms_bev")
+    return keep, int(num.item())
+
+
 def selftest_angles(n, seed=1, range_xy=100.0, z_lo=-6.0, z_hi=1.0, device="cuda:0"):
     """-> (max error/bound for theta, for phi) of the fp32 angle estimates on this device."""
     out = torch.zeros(2, dtype=torch.float64, device=device)

@@ -244,6 +244,21 @@ int dfu3d_gt_database(const float *points, const int32_t *pt_off,
                       int32_t *idx_out, float *gt_pts, uint32_t *status,
                       void *stream);
 
+/* ---- f-3: rotated BEV overlap / IoU and rotated NMS --------------------------
+ * (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:14-339, iou3d_nms.cpp:120-177)
+ * boxes: float32 (.,7) [x y z dx dy dz heading].
+ * dfu3d_boxes_bev: out float32 (n,m); mode 0 = overlap area (boxes_overlap_bev_gpu),
+ * mode 1 = BEV IoU (boxes_iou_bev_gpu).
+ * dfu3d_nms_bev: boxes already sorted by descending score (iou3d_nms_utils.nms_gpu
+ * does that before the call); keep[0..num_keep) = kept positions in ascending
+ * order, box i suppressed iff an earlier kept box j has iou_bev(j,i) > thresh.
+ * Scratch: mask uint64 (n * ceil(n/64)).  The walk over the mask runs on the
+ * device (the reference copies the mask to the host).  n <= 32768. */
+int dfu3d_boxes_bev(const float *boxes_a, int32_t n, const float *boxes_b,
+                    int32_t m, float *out, int32_t mode, void *stream);
+int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
+                  int64_t *keep, int32_t *num_keep, void *stream);
+
 /* ---- self test of the two-tier bin classification ---------------------------
  * dfu3d_backproject_bin decides a pixel's spherical bin from fp32 angle
  * estimates when they are farther from every bin edge than a bound on their

@@ -1,6 +1,6 @@
 """Build recipe for the oracle's C part (TEST INFRASTRUCTURE ONLY).
 
-`python -m oracle.build` compiles oracle/csrc/dfu3d_oracle.c into
+`python -m oracle.build` compiles oracle/csrc/*.c into
 oracle/libdfu3d_oracle.so with gcc.  The reference ships no native code on this
 path, so there is no `oracle/_ref` build: the oracle is pinned
 by golden vectors captured from the importable reference modules instead
@@ -12,15 +12,17 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "dfu3d_oracle.c")
+SRCS = [SRC, os.path.join(HERE, "csrc", "iou3d_oracle.c")]
+DEPS = SRCS + [os.path.join(os.path.dirname(HERE), "dfu3d_amd", "csrc", "iou_common.inc")]
 OUT = os.path.join(HERE, "libdfu3d_oracle.so")
 
 
 def build(force: bool = False) -> str:
     if (not force and os.path.exists(OUT)
-            and os.path.getmtime(OUT) >= os.path.getmtime(SRC)):
+            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)):
         return OUT
     cmd = ["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fno-fast-math",
-           "-shared", "-fPIC", SRC, "-o", OUT, "-lm"]
+           "-shared", "-fPIC"] + SRCS + ["-o", OUT, "-lm"]
     subprocess.check_call(cmd)
     return OUT
 
