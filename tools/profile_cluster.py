@@ -59,4 +59,3 @@ dump = {}
 for s_ in (123, 168, 28, 18):
     b0 = int(eng.base_a[s_]); n_ = int(cnt[s_])
     dump["seg%d" % s_] = torch.stack([eng.px[b0:b0+n_], eng.py[b0:b0+n_]], 1).cpu().numpy()
-np.savez_compressed("gpurun_out/slow_segments.npz", **dump)
