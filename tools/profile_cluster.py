@@ -53,9 +53,3 @@ for s_ in allorder[12:30]:
     roots, sizes = torch.unique(lab, return_counts=True)
     xs = eng.px[b0:b0+n_]; ys = eng.py[b0:b0+n_]
     print("seg %4d n=%6d clusters=%3d top sizes %s extent %.1f x %.1f  %.3f ms" % (s_, n_, roots.numel(), sorted(sizes.tolist())[::-1][:5], float(xs.max()-xs.min()), float(ys.max()-ys.min()), t))
-import os
-os.makedirs("gpurun_out", exist_ok=True)
-dump = {}
-for s_ in (123, 168, 28, 18):
-    b0 = int(eng.base_a[s_]); n_ = int(cnt[s_])
-    dump["seg%d" % s_] = torch.stack([eng.px[b0:b0+n_], eng.py[b0:b0+n_]], 1).cpu().numpy()
