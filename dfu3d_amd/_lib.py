@@ -31,6 +31,23 @@ class BinGeom(ctypes.Structure):
     ]
 
 
+class ChainCfg(ctypes.Structure):
+    """dfu3d_chain_cfg (include/dfu3d.h)."""
+    _fields_ = [
+        ("V", c_i32), ("H", c_i32), ("W", c_i32), ("max_inst", c_i32), ("cap_n", c_i32), ("cap_vox", c_i32),
+        ("cap_rows", c_i32),
+        ("dense", c_i32), ("apply_fov", c_i32), ("fov_h", c_i32), ("fov_w", c_i32), ("stat_filter", c_i32),
+        ("pool_cap", c_i64),
+        ("plane_max_hs", c_f64), ("plane_range", c_f64), ("plane_offset", c_f64),
+        ("ransac_trials", c_i32), ("nb_points", c_i32),
+        ("ransac_seed", c_u64),
+        ("fuse_C", c_f64), ("R0", c_f64), ("Rd", c_f64),
+        ("n_theta", c_i32), ("stat_nb_neighbors", c_i32),
+        ("dtheta", c_f64), ("car_aspect_max", c_f64), ("stat_std_ratio", c_f64),
+        ("geom", BinGeom),
+    ]
+
+
 _P = c_void_p
 # argument lists mirror include/dfu3d.h exactly (pointers as void*)
 SIGNATURES = {
@@ -66,6 +83,9 @@ SIGNATURES = {
     "dfu3d_gt_database": (c_i32, [_P, _P, _P, _P, c_i32, _P, _P, c_i64, _P, _P, _P, _P]),
     "dfu3d_boxes_bev": (c_i32, [_P, c_i32, _P, c_i32, _P, c_i32, _P]),
     "dfu3d_nms_bev": (c_i32, [_P, c_i32, ctypes.c_float, _P, _P, _P, _P]),
+    "dfu3d_chain_workspace_bytes": (c_i64, [ctypes.POINTER(ChainCfg)]),
+    "dfu3d_chain_workspace_init": (c_i32, [ctypes.POINTER(ChainCfg), _P, _P]),
+    "dfu3d_pseudo_boxes": (c_i32, [ctypes.POINTER(ChainCfg)] + [_P] * 20),
     "dfu3d_selftest_angles": (c_i32, [c_i64, ctypes.c_uint64, c_f64, c_f64, c_f64, _P, _P]),
     "dfu3d_lshape_fit_ws_doubles": (c_i64, [c_i64, c_i32]),
     "dfu3d_lshape_fit": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, _P, _P, _P, _P, _P,

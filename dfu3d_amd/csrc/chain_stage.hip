@@ -1,0 +1,232 @@
+// chain_stage.hip -- the whole pseudo-box path for V views behind ONE C call
+// (vis_utils.py:136-166 -> my_loader.py:502-702 -> label rows), for hosts that do not want
+// to sequence the stage entry points themselves.  It only sequences them: every kernel is
+// the one the per-stage entry points launch, the workspace is carved from one caller-owned
+// buffer, nothing is allocated, nothing synchronises.
+#include "common.hpp"
+
+namespace {
+
+struct ChainWs {
+  int32_t *fov_idx, *cand_idx, *ag_pt, *ib_pix, *n_fov, *n_ag, *K;
+  double *plane;
+  uint32_t *a_bits;
+  double *a_x, *a_y, *a_z;
+  int32_t *n_vox;
+  uint32_t *vox_pix, *b_bits;
+  double *b_x, *b_y, *b_z;
+  void *table;
+  uint32_t *pix_bin;
+  int32_t *blk_cnt;
+  double *px, *py, *pz, *sx, *sy;
+  int32_t *label, *sroot, *si3;
+  double *fit_ws;
+  uint8_t *flags;
+  int64_t *base_a, *base_b, *base_ab;
+  int32_t *cnt_a, *cnt_b, *cnt_all, *cnt_ab, *tile_off, *queue, *stat_enable;
+  double *rad_ab, *mean_d;
+  int64_t *pool_cursor;
+  int64_t table_entries;
+};
+
+// carve the workspace; with base == nullptr only the size is computed
+int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) -> char * {
+    char *p = base ? base + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return p;
+  };
+  const int64_t V = c->V, S = (int64_t)c->V * c->max_inst, N = V * c->cap_n, X = V * c->cap_vox, P = c->pool_cap;
+  ChainWs t;
+  t.fov_idx = (int32_t *)take(4 * N); t.cand_idx = (int32_t *)take(4 * N);
+  t.ag_pt = (int32_t *)take(4 * N); t.ib_pix = (int32_t *)take(4 * N);
+  t.n_fov = (int32_t *)take(4 * V); t.n_ag = (int32_t *)take(4 * V); t.K = (int32_t *)take(4 * V);
+  t.plane = (double *)take(8 * V * 4);
+  t.a_bits = (uint32_t *)take(4 * N);
+  t.a_x = (double *)take(8 * N); t.a_y = (double *)take(8 * N); t.a_z = (double *)take(8 * N);
+  t.n_vox = (int32_t *)take(4 * V);
+  t.vox_pix = (uint32_t *)take(4 * X); t.b_bits = (uint32_t *)take(4 * X);
+  t.b_x = (double *)take(8 * X); t.b_y = (double *)take(8 * X); t.b_z = (double *)take(8 * X);
+  t.table_entries = (int64_t)c->geom.t_n * c->geom.p_n;
+  int64_t pw = 0, bw = 0;
+  if (c->dense) {
+    dfu3d_backproject_scratch_words(c->V, c->H, c->W, c->cap_vox, c->geom.max_points_per_voxel, &pw, &bw);
+    t.table = take(V * t.table_entries * DFU3D_TABLE_ENTRY_BYTES);
+    t.pix_bin = (uint32_t *)take(4 * pw);
+    t.blk_cnt = (int32_t *)take(4 * bw);
+  } else {
+    t.table = nullptr; t.pix_bin = nullptr; t.blk_cnt = nullptr;
+  }
+  t.px = (double *)take(8 * P); t.py = (double *)take(8 * P); t.pz = (double *)take(8 * P);
+  t.sx = (double *)take(8 * P); t.sy = (double *)take(8 * P);
+  t.label = (int32_t *)take(4 * P); t.sroot = (int32_t *)take(4 * P); t.si3 = (int32_t *)take(4 * 3 * P);
+  t.fit_ws = (double *)take(8 * dfu3d_lshape_fit_ws_doubles(P, c->cap_rows));
+  t.flags = (uint8_t *)take(P);
+  t.base_a = (int64_t *)take(8 * S); t.base_b = (int64_t *)take(8 * S); t.base_ab = (int64_t *)take(8 * 2 * S);
+  t.cnt_a = (int32_t *)take(4 * S); t.cnt_b = (int32_t *)take(4 * S); t.cnt_all = (int32_t *)take(4 * S);
+  t.cnt_ab = (int32_t *)take(4 * 2 * S); t.tile_off = (int32_t *)take(4 * (2 * S + 1));
+  t.queue = (int32_t *)take(4 * (2 + 2 * P)); t.stat_enable = (int32_t *)take(4 * S);
+  t.rad_ab = (double *)take(8 * 2 * S);
+  t.mean_d = c->stat_filter ? (double *)take(8 * P) : nullptr;
+  t.pool_cursor = (int64_t *)take(8);
+  if (w) *w = t;
+  return off;
+}
+
+bool cfg_ok(const dfu3d_chain_cfg *c) {
+  return c && c->V > 0 && c->H > 0 && c->W > 0 && c->max_inst > 0 && c->max_inst <= DFU3D_MAX_INST &&
+         c->cap_n > 0 && c->cap_vox > 0 && c->cap_rows > 0 && c->pool_cap > 0 && c->n_theta > 0 &&
+         (!c->dense || (c->geom.t_n > 0 && c->geom.p_n > 0));
+}
+
+// apply_fov == 0: the caller's points are already the FOV points (vis_utils.py:152-154 done upstream)
+__global__ void k_all_points(const int *__restrict__ pt_off, const int *__restrict__ view_frame,
+                             int cap_n, int *__restrict__ fov_idx, int *__restrict__ n_fov) {
+  const int v = blockIdx.y;
+  const int f = view_frame[v];
+  const int n = min(pt_off[f + 1] - pt_off[f], cap_n);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap_n; i += gridDim.x * blockDim.x)
+    fov_idx[(size_t)v * cap_n + i] = i;
+  if (blockIdx.x == 0 && threadIdx.x == 0) n_fov[v] = n;
+}
+
+// the 2S-segment view of (LiDAR lists | pseudo lists) for the joint radius-filter pass
+__global__ void k_join_segments(int S, const long long *__restrict__ base_a, const long long *__restrict__ base_b,
+                                const int *__restrict__ cnt_a, const int *__restrict__ cnt_b,
+                                const double *__restrict__ r_lidar, const double *__restrict__ r_pseudo,
+                                long long *__restrict__ base_ab, int *__restrict__ cnt_ab,
+                                double *__restrict__ rad_ab) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  base_ab[s] = base_a[s]; base_ab[S + s] = base_b[s];
+  cnt_ab[s] = cnt_a[s]; cnt_ab[S + s] = cnt_b[s];
+  rad_ab[s] = r_lidar[s]; rad_ab[S + s] = r_pseudo[s];
+}
+
+__global__ void k_sum_counts(int S, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) out[s] = a[s] + b[s];
+}
+
+__global__ void k_fill_i32(int n, int v, int *__restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t dfu3d_chain_workspace_bytes(const dfu3d_chain_cfg *cfg) {
+  if (!cfg_ok(cfg)) return DFU3D_EINVAL;
+  return carve(cfg, nullptr, nullptr);
+}
+
+extern "C" int dfu3d_chain_workspace_init(const dfu3d_chain_cfg *cfg, void *workspace, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!cfg_ok(cfg) || !workspace) return DFU3D_EINVAL;
+  ChainWs w;
+  carve(cfg, (char *)workspace, &w);
+  if (cfg->dense) {
+    const int rc = dfu3d_bin_table_init(w.table, (int64_t)cfg->V * w.table_entries, stream);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_fill_i32, dim3((cfg->V * cfg->max_inst + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, cfg->V * cfg->max_inst, 1, w.stat_enable);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+#define CHAIN_TRY(call)      \
+  do {                       \
+    const int rc_ = (call);  \
+    if (rc_) return rc_;     \
+  } while (0)
+
+extern "C" int dfu3d_pseudo_boxes(
+    const dfu3d_chain_cfg *cfg, const float *points, const int32_t *pt_off,
+    const int32_t *view_frame, const float *calib, const uint8_t *masks, const int32_t *n_inst,
+    const float *depth, const int64_t *view_key, const double *plane_in, const int32_t *inst_class,
+    const int32_t *inst_is_car, const double *inst_r_lidar, const double *inst_r_pseudo,
+    const float *inst_box, const float *inst_score, void *workspace, double *rows, int32_t *n_rows,
+    uint32_t *status, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!cfg_ok(cfg) || !points || !pt_off || !view_frame || !calib || !masks || !n_inst || !inst_class ||
+      !inst_is_car || !inst_r_lidar || !inst_r_pseudo || !inst_box || !inst_score || !workspace || !rows ||
+      !n_rows || !status)
+    return DFU3D_EINVAL;
+  if (!plane_in && !view_key) return DFU3D_EINVAL;
+  if (cfg->dense && !depth) return DFU3D_EINVAL;
+  ChainWs w;
+  carve(cfg, (char *)workspace, &w);
+  hipStream_t st = (hipStream_t)stream;
+  const int V = cfg->V, M = cfg->max_inst, S = V * M, cap_n = cfg->cap_n;
+  if (hipMemsetAsync(n_rows, 0, sizeof(int32_t), st) != hipSuccess) return DFU3D_ELAUNCH;
+  if (hipMemsetAsync(status, 0, sizeof(uint32_t), st) != hipSuccess) return DFU3D_ELAUNCH;
+  if (hipMemsetAsync(w.pool_cursor, 0, sizeof(int64_t), st) != hipSuccess) return DFU3D_ELAUNCH;
+  // a4
+  if (cfg->apply_fov) {
+    CHAIN_TRY(dfu3d_fov_filter(points, pt_off, view_frame, calib, V, cfg->fov_h, cfg->fov_w, cap_n,
+                               w.fov_idx, w.n_fov, stream));
+  } else {
+    hipLaunchKernelGGL(k_all_points, dim3((cap_n + 255) / 256 < 64 ? (cap_n + 255) / 256 : 64, V), dim3(256), 0, st,
+                       pt_off, view_frame, cap_n, w.fov_idx, w.n_fov);
+    DFU3D_LAUNCH_CHECK();
+  }
+  // a5
+  const double *plane = plane_in;
+  if (!plane) {
+    CHAIN_TRY(dfu3d_plane_ransac(points, pt_off, view_frame, w.fov_idx, w.n_fov, V, cap_n, cfg->plane_max_hs,
+                                 cfg->plane_range, cfg->ransac_trials, cfg->ransac_seed, view_key,
+                                 w.cand_idx, w.plane, stream));
+    plane = w.plane;
+  }
+  // a5/a6
+  CHAIN_TRY(dfu3d_project_label(points, pt_off, view_frame, calib, plane, w.fov_idx, w.n_fov, masks, n_inst,
+                                V, M, cfg->H, cfg->W, cap_n, cfg->plane_offset, cfg->plane_range, w.ag_pt,
+                                w.ib_pix, w.n_ag, w.K, w.a_bits, w.a_x, w.a_y, w.a_z, stream));
+  // a7-a9
+  if (cfg->dense) {
+    CHAIN_TRY(dfu3d_backproject_bin(depth, calib, masks, n_inst, V, M, cfg->H, cfg->W, &cfg->geom, 1, w.table,
+                                    w.pix_bin, w.blk_cnt, cfg->cap_vox, w.n_vox, w.vox_pix, w.b_bits, w.b_x,
+                                    w.b_y, w.b_z, status, DFU3D_BP_ALL, stream));
+  } else {
+    if (hipMemsetAsync(w.n_vox, 0, sizeof(int32_t) * V, st) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  CHAIN_TRY(dfu3d_segments_build(w.a_bits, w.a_x, w.a_y, w.a_z, w.K, cap_n, w.b_bits, w.b_x, w.b_y, w.b_z,
+                                 w.n_vox, cfg->cap_vox, V, M, cfg->pool_cap, w.pool_cursor, w.px, w.py, w.pz,
+                                 w.base_a, w.cnt_a, w.base_b, w.cnt_b, status, stream));
+  // a10 (+a11) + a12
+  if (!cfg->stat_filter) {
+    hipLaunchKernelGGL(k_join_segments, dim3((S + 255) / 256), dim3(256), 0, st, S, (const long long *)w.base_a,
+                       (const long long *)w.base_b, w.cnt_a, w.cnt_b, inst_r_lidar, inst_r_pseudo,
+                       (long long *)w.base_ab, w.cnt_ab, w.rad_ab);
+    DFU3D_LAUNCH_CHECK();
+    CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_ab, w.cnt_ab, w.rad_ab, cfg->nb_points, 2 * S,
+                                  cfg->pool_cap, w.tile_off, w.flags, w.queue,
+                                  DFU3D_RF_ALL & ~DFU3D_RF_COMPACT, stream));
+    CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,
+                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_COMPACT, stream));
+    CHAIN_TRY(dfu3d_ballquery_fuse_masked(w.px, w.py, w.pz, w.base_a, w.cnt_a, w.base_b, w.cnt_b, cfg->fuse_C,
+                                          S, cfg->pool_cap, w.tile_off, w.flags, stream));
+  } else {
+    CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,
+                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_ALL, stream));
+    CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, inst_r_pseudo, cfg->nb_points, S,
+                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_ALL, stream));
+    CHAIN_TRY(dfu3d_stat_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, w.stat_enable, cfg->stat_nb_neighbors,
+                                cfg->stat_std_ratio, S, cfg->pool_cap, w.tile_off, w.flags, w.mean_d, nullptr,
+                                stream));
+    CHAIN_TRY(dfu3d_ballquery_fuse(w.px, w.py, w.pz, w.base_a, w.cnt_a, w.base_b, w.cnt_b, cfg->fuse_C, S,
+                                   cfg->pool_cap, w.tile_off, w.flags, stream));
+  }
+  hipLaunchKernelGGL(k_sum_counts, dim3((S + 255) / 256), dim3(256), 0, st, S, w.cnt_a, w.cnt_b, w.cnt_all);
+  DFU3D_LAUNCH_CHECK();
+  // a13-a15
+  CHAIN_TRY(dfu3d_range_cluster(w.px, w.py, w.base_a, w.cnt_all, S, cfg->R0, cfg->Rd, w.label, w.sx, w.sy,
+                                w.si3, cfg->pool_cap, stream));
+  CHAIN_TRY(dfu3d_lshape_fit(w.px, w.py, w.pz, w.label, w.base_a, w.cnt_all, S, M, calib, inst_class,
+                             inst_is_car, inst_box, inst_score, cfg->n_theta, cfg->dtheta, cfg->car_aspect_max,
+                             w.sx, w.sy, w.sroot, cfg->cap_rows, rows, n_rows, status, w.fit_ws, cfg->pool_cap,
+                             stream));
+  return DFU3D_OK;
+}

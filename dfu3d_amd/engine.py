@@ -14,6 +14,8 @@ device -- and one sync at the end of run() collects the row counters.
 from dataclasses import dataclass, field
 from typing import Optional
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -48,7 +50,8 @@ class PseudoBoxEngine:
     def __init__(self, params: Params, H: int, W: int, max_inst: int, cap_n: int,
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
-                 device="cuda:0", apply_fov: bool = True, lanes: int = 1, graphs: bool = False):
+                 device="cuda:0", apply_fov: bool = True, lanes: int = 1, graphs: bool = False,
+                 chain: bool = False):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         if tuple(params.bounds_hw) != (int(H), int(W)):
@@ -73,6 +76,10 @@ class PseudoBoxEngine:
         # graphs=True: the launch chain of every chunk is captured into a hipGraph the first time a
         # batch (identified by the addresses of its tensors) is seen and replayed afterwards --
         # no per-launch host work, no gaps between the ~50 kernels of a chunk.
+        # chain=True: every chunk is ONE C call (dfu3d_pseudo_boxes) that sequences the same stage entry
+        # points over a single workspace -- what a non-Python host would bind.  Per-kernel timing needs the
+        # stage-by-stage path, so `timing` overrides it.
+        self.chain = bool(chain)
         self.graphs = bool(graphs)
         self._graph_key = None
         self._graph_state = None
@@ -132,6 +139,30 @@ class PseudoBoxEngine:
             L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
             L.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
             L.rf_points = torch.zeros(1, dtype=torch.int64, device=d)   # timing mode only
+            if self.chain:
+                from ._lib import ChainCfg
+                p = self.p
+                c = ChainCfg()
+                c.V, c.H, c.W, c.max_inst, c.cap_n, c.cap_vox, c.cap_rows = (V, self.H, self.W, self.M, cap_n,
+                                                                            self.cap_vox, self.cap_rows)
+                c.dense, c.apply_fov, c.fov_h, c.fov_w = int(self.dense), int(self.apply_fov), int(p.fov_hw[0]), int(p.fov_hw[1])
+                c.stat_filter, c.pool_cap = int(p.stat_filter), self.pool_cap
+                c.plane_max_hs, c.plane_range, c.plane_offset = p.plane_max_hs, p.plane_range, p.plane_offset
+                c.ransac_trials, c.nb_points = int(p.ransac_trials), int(p.nb_points)
+                c.ransac_seed = int(p.ransac_seed) & ((1 << 64) - 1)
+                c.fuse_C, c.R0, c.Rd = p.fuse_C, p.R0, p.Rd
+                c.n_theta, c.stat_nb_neighbors = int(self.n_theta), int(p.stat_nb_neighbors)
+                c.dtheta, c.car_aspect_max, c.stat_std_ratio = self.dtheta, p.car_aspect_max, p.stat_std_ratio
+                if self.dense:
+                    c.geom = L.geom
+                lib = st._lib.lib()
+                nbytes = int(lib.dfu3d_chain_workspace_bytes(c))
+                if nbytes <= 0:
+                    raise Dfu3dError("dfu3d_chain_workspace_bytes: invalid configuration")
+                L.chain_cfg = c
+                L.chain_ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+                st._lib.check(lib.dfu3d_chain_workspace_init(c, L.chain_ws.data_ptr(), st._stream()),
+                              "dfu3d_chain_workspace_init")
         return L
 
     def _bind(self, L):
@@ -179,7 +210,25 @@ class PseudoBoxEngine:
         return int(sum(int(L.rf_points.item()) for L in self.lanes))
 
     # ------------------------------------------------------------------
+    def _chunk_chain(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
+        """One dfu3d_pseudo_boxes call for the chunk [v0, v1)."""
+        V = v1 - v0
+        st._check_frames(b.points, b.pt_off, b.view_frame[v0:v1], V, self.cap_n, b.host_pt_off,
+                         b.host_view_frame[v0:v1])
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        c = lambda t: t.contiguous()
+        f = lambda t: c(t[v0:v1].reshape(-1))
+        keep = [c(b.points), c(b.pt_off), c(b.view_frame[v0:v1]), c(b.calib[v0:v1]), c(b.masks[v0:v1]),
+                c(b.n_inst[v0:v1]), None if b.depth is None or not self.dense else c(b.depth[v0:v1]),
+                c(b.view_key[v0:v1]), None if b.plane is None else c(b.plane[v0:v1]), f(b.inst_class),
+                f(b.inst_is_car), f(b.inst_r_lidar), f(b.inst_r_pseudo), f(b.inst_box), f(b.inst_score)]
+        rc = st._lib.lib().dfu3d_pseudo_boxes(self.chain_cfg, *[ptr(t) for t in keep], ptr(self.chain_ws), ptr(rows),
+                                              ptr(n_rows), ptr(status), st._stream())
+        st._lib.check(rc, "dfu3d_pseudo_boxes")
+
     def _chunk(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
+        if self.chain and not self.timing:
+            return self._chunk_chain(b, v0, v1, rows, n_rows, status)
         p, V, M, H, W = self.p, v1 - v0, self.M, self.H, self.W
         if V != self.Vc:
             raise Dfu3dError("internal: chunk size mismatch")

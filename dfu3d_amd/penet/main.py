@@ -33,6 +33,7 @@ def build_parser():
     ap.add_argument('--overrides', nargs=argparse.REMAINDER, default=[])
     # additive
     ap.add_argument('--depth-dir', default=None, help='<dir>/<idx>.npy dense metric depth (H,W); default <detpath>/depth_2')
+    ap.add_argument('--seg-dir', default=None, help='<dir>/<idx>.npz instance masks / classes / scores / boxes; default <detpath>/seg_2')
     ap.add_argument('--label-out', default=None, help='default <detpath>/label_2')
     ap.add_argument('--start', type=int, default=0)
     ap.add_argument('--end', type=int, default=None)
@@ -69,7 +70,7 @@ def main(argv=None):
                              workers=max(1, args.workers),
                              device="cuda:%d" % (local if world > 1 else 0),
                              want_points=not args.no_virtual_points)
-        stats = lab.run(args.detpath, mine, label_out, depth_dir)
+        stats = lab.run(args.detpath, mine, label_out, depth_dir, seg_dir=args.seg_dir)
         if rank == 0:
             dt = time.time() - t0
             print("%d frames, %d boxes, %.2f frames/s (files in, files out)" % (stats["frames"], stats["boxes"],
@@ -79,7 +80,9 @@ def main(argv=None):
         if args.skip_existing and os.path.exists(os.path.join(label_out, idx + '.txt')):
             continue
         depth = np.load(os.path.join(depth_dir, idx + '.npy')).astype(np.float32)
+        from .vis_utils import load_seg_npz
         save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
+                             seg_provider=(lambda path, _i=idx: load_seg_npz(args.detpath, _i, args.seg_dir)),
                              device="cuda:%d" % (local if world > 1 else 0))
         if rank == 0 and (k + 1) % 10 == 0:
             print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))

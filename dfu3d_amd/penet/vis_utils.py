@@ -15,9 +15,9 @@ from ..params import Params
 from .my_loader import depth2pointsrgbpm
 
 
-def load_seg_npz(root_path, file_idx):
+def load_seg_npz(root_path, file_idx, seg_dir=None):
     """-> (thing_classes, masks (M,H,W), classes (M,), scores (M,), boxes2D (M,4))."""
-    z = np.load(os.path.join(root_path, 'seg_2', file_idx + '.npz'), allow_pickle=False)
+    z = np.load(os.path.join(seg_dir or os.path.join(root_path, 'seg_2'), file_idx + '.npz'), allow_pickle=False)
     names = [str(s) for s in z['thing_classes']]
     keep = z['scores'] > 0.7                                          # vis_utils.py:218
     return names, z['masks'][keep], z['classes'][keep], z['scores'][keep], z['boxes'][keep]

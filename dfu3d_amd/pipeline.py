@@ -70,12 +70,12 @@ def _npz_arrays(path):
     return out
 
 
-def read_frame(root, stem, depth_dir=None, want_image=False, score_min=0.7) -> Frame:
+def read_frame(root, stem, depth_dir=None, want_image=False, score_min=0.7, seg_dir=None) -> Frame:
     """One frame of the directory layout written by dfu3d_amd.kitti_io.write_frame."""
     pts = np.fromfile(os.path.join(root, 'velodyne', stem + '.bin'), dtype=np.float32).reshape(-1, 4)
     calib = Calibration(os.path.join(root, 'calib', stem + '.txt'))
     depth = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), stem + '.npy')).astype(np.float32, copy=False)
-    z = _npz_arrays(os.path.join(root, 'seg_2', stem + '.npz'))
+    z = _npz_arrays(os.path.join(seg_dir or os.path.join(root, 'seg_2'), stem + '.npz'))
     keep = z['scores'] > score_min                                  # vis_utils.py:218
     if keep.all():
         keep = slice(None)
@@ -104,6 +104,7 @@ class BatchedLabeler:
         self._engines = {}
         self._copy_stream = torch.cuda.Stream(self.dev)
         self._stage = {}
+        self.seg_dir = None
         self.stats = {"frames": 0, "boxes": 0, "t_read": 0.0, "t_pack": 0.0, "t_wait": 0.0, "t_gpu": 0.0}
 
     # ------------------------------------------------------------------
@@ -249,14 +250,15 @@ class BatchedLabeler:
     def _prepare(self, root, batch, depth_dir, pool, slot):
         torch.cuda.set_device(self.dev)
         t0 = time.perf_counter()
-        frames = list(pool.map(lambda s: read_frame(root, s, depth_dir, self.want_points), batch))
+        frames = list(pool.map(lambda s: read_frame(root, s, depth_dir, self.want_points, seg_dir=self.seg_dir), batch))
         t1 = time.perf_counter()
         packed = self._pack(frames, slot, pool)
         self.stats["t_read"] += t1 - t0
         self.stats["t_pack"] += time.perf_counter() - t1
         return frames, packed
 
-    def run(self, root, stems: List[str], label_out, depth_dir=None, npy_out=None):
+    def run(self, root, stems: List[str], label_out, depth_dir=None, npy_out=None, seg_dir=None):
+        self.seg_dir = seg_dir
         os.makedirs(label_out, exist_ok=True)
         if self.want_points:
             npy_out = npy_out or os.path.join(root, 'velodyne_depth')

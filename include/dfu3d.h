@@ -309,6 +309,43 @@ int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
                      int32_t *n_rows, uint32_t *status, double *fit_ws,
                      int64_t pool_cap, void *stream);
 
+/* ---- the whole path behind one call ------------------------------------------
+ * vis_utils.py:136-166 -> my_loader.py:502-702 for V views: FOV filter, plane,
+ * label inheritance, back-projection + voxel sampling, per-instance lists,
+ * radius filter (+ statistical filter), BallQuery fuse, clustering, L-shape fit,
+ * box rows.  It sequences the stage entry points above on `stream`, with their
+ * scratch carved from ONE caller-owned workspace (dfu3d_chain_workspace_bytes;
+ * dfu3d_chain_workspace_init once, it initialises the spherical-bin table).
+ * Segment arrays (inst_*) are (V*max_inst); inst_r_lidar / inst_r_pseudo are the
+ * radius-filter radii per instance (0 = no filter, < 0 = drop all: hazard H4).
+ * plane_in: fp64 (V,4) planes to use, or NULL = seeded RANSAC keyed by view_key.
+ * depth: float32 (V,H,W), required when cfg->dense.  rows / n_rows / status as
+ * in dfu3d_lshape_fit; n_rows and status are reset by the call. */
+typedef struct dfu3d_chain_cfg {
+  int32_t V, H, W, max_inst, cap_n, cap_vox, cap_rows;
+  int32_t dense, apply_fov, fov_h, fov_w, stat_filter;
+  int64_t pool_cap;
+  double plane_max_hs, plane_range, plane_offset;
+  int32_t ransac_trials, nb_points;
+  uint64_t ransac_seed;
+  double fuse_C, R0, Rd;
+  int32_t n_theta, stat_nb_neighbors;
+  double dtheta, car_aspect_max, stat_std_ratio;
+  dfu3d_bin_geom geom;              /* after dfu3d_bin_table_geometry */
+} dfu3d_chain_cfg;
+int64_t dfu3d_chain_workspace_bytes(const dfu3d_chain_cfg *cfg);
+int dfu3d_chain_workspace_init(const dfu3d_chain_cfg *cfg, void *workspace, void *stream);
+int dfu3d_pseudo_boxes(const dfu3d_chain_cfg *cfg, const float *points,
+                       const int32_t *pt_off, const int32_t *view_frame,
+                       const float *calib, const uint8_t *masks,
+                       const int32_t *n_inst, const float *depth,
+                       const int64_t *view_key, const double *plane_in,
+                       const int32_t *inst_class, const int32_t *inst_is_car,
+                       const double *inst_r_lidar, const double *inst_r_pseudo,
+                       const float *inst_box, const float *inst_score,
+                       void *workspace, double *rows, int32_t *n_rows,
+                       uint32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

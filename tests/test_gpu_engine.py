@@ -129,3 +129,29 @@ def test_engine_reproduces_reference_label_rows(golden_dir, tmp_path, tag):
     for got, w in zip(R, ref):
         assert NUSC_CLASSES[int(got[3])] == w[0]
         np.testing.assert_allclose(got[4:16], np.array(w[3:], float), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["dense", "sparse", "stat_filter", "given_plane", "no_fov"])
+def test_single_call_chain_equals_stage_by_stage(variant):
+    """dfu3d_pseudo_boxes (the whole path behind one C call, one workspace) gives bit-identical rows to the
+    engine that sequences the stage entry points from Python."""
+    _need_gpu()
+    from dfu3d_amd import synth
+    from dfu3d_amd.engine import PseudoBoxEngine
+    from dfu3d_amd.params import Params
+    H, W, M, cams = 180, 320, 5, 3
+    dense = variant != "sparse"
+    p = Params(bounds_hw=(H, W), fov_hw=(H, W), stat_filter=(variant == "stat_filter"))
+    scenes = [synth.make_scene(70 + f, H=H, W=W, M=M, cams=cams, dense=dense, k_min=12, k_max=18) for f in range(4)]
+    b = synth.to_view_batch(scenes, p, DEV, dense=dense)
+    if variant == "given_plane":
+        b.plane = torch.tensor([[0.0, 0.0, 1.0, 1.6]] * (cams * 4), dtype=torch.float64, device=DEV)
+    cap_n = max(s.points.shape[0] for s in scenes)
+    kw = dict(views_per_chunk=cams * 2, dense=dense, cap_vox=1 << 17, lanes=2, apply_fov=(variant != "no_fov"))
+    rows_a, st_a = PseudoBoxEngine(p, H, W, M, cap_n, **kw).run(b)
+    eng = PseudoBoxEngine(p, H, W, M, cap_n, chain=True, **kw)
+    rows_b, st_b = eng.run(b)
+    assert st_a == 0 and st_b == 0 and rows_a.shape[0] > 3
+    assert torch.equal(rows_a, rows_b)
+    rows_c, _ = eng.run(b)                       # the workspace is reusable
+    assert torch.equal(rows_b, rows_c)
