@@ -97,8 +97,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="concurrent HIP streams (one chunk each)")
     ap.add_argument("--sparse", action="store_true", help="depth off (hazard H20 extension)")
     ap.add_argument("--boxes", type=int, nargs=2, default=[30, 40], help="objects per scene (min max)")
-    ap.add_argument("--chain", action="store_true",
-                    help="issue every chunk as ONE C call (dfu3d_pseudo_boxes) except on the kernel-timing steps")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="sequence the stage entry points from Python on every step (default: every chunk is ONE C call, "
+                         "dfu3d_pseudo_boxes, except on the kernel-timing steps; same kernels, same results)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2: 3.7k vs 4.7k frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +150,7 @@ def main():
 
     eng = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=args.chunk_frames * CAMS,
                           dense=dense, cap_vox=1 << 18, pool_per_view=1 << 17, device=dev,
-                          lanes=args.lanes, graphs=args.graphs, chain=args.chain)
+                          lanes=args.lanes, graphs=args.graphs, chain=not args.no_chain)
 
     def step():
         rows, status = eng.run(batch)
