@@ -155,3 +155,37 @@ def test_single_call_chain_equals_stage_by_stage(variant):
     assert torch.equal(rows_a, rows_b)
     rows_c, _ = eng.run(b)                       # the workspace is reusable
     assert torch.equal(rows_b, rows_c)
+
+
+def test_engine_matches_oracle_at_the_bench_configuration():
+    """One frame exactly as bench.py generates them (34 720 points, 6 cameras 1600x900, dense depth, 8 masks per
+    camera, 30-40 objects): every label row against the oracle, plus properties that do not need the oracle --
+    rows sorted by (view, instance, cluster), clusters of an instance partition its points, chunking / streams
+    do not change a bit."""
+    _need_gpu()
+    from dfu3d_amd import synth
+    from dfu3d_amd.engine import PseudoBoxEngine
+    from dfu3d_amd.params import Params
+    H, W, M, cams = 900, 1600, 8, 6
+    p = Params()
+    scenes = [synth.make_scene(7, H=H, W=W, M=M, cams=cams, dense=True, k_min=30, k_max=40)]
+    b = synth.to_view_batch(scenes, p, DEV, dense=True)
+    cap_n = scenes[0].points.shape[0]
+    assert cap_n == 34720
+    eng = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=cams, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17)
+    rows, status = eng.run(b)
+    assert status == 0
+    exp, _ = _oracle_rows(scenes, p, True)
+    assert len(exp) >= 20
+    _compare(rows, exp)
+    R = rows.cpu().numpy()
+    key = (R[:, 0] * M + R[:, 1]) * 1e6 + R[:, 2]
+    assert np.all(np.diff(key) > 0)                                   # sorted, no duplicates
+    for v in range(cams):                                             # cluster sizes of an instance: disjoint, >= 1 point each
+        for j in range(M):
+            sel = R[(R[:, 0] == v) & (R[:, 1] == j)]
+            assert np.all(sel[:, 17] >= 1) and len(set(sel[:, 23].tolist())) == len(sel)
+    eng2 = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=2, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17,
+                           lanes=3, chain=True)
+    rows2, status2 = eng2.run(b)
+    assert status2 == 0 and torch.equal(rows, rows2)

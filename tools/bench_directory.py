@@ -26,6 +26,7 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 streams = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 workers = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 root = sys.argv[5] if len(sys.argv) > 5 else "/dev/shm/dfu3d_dir"
+compress = (sys.argv[6] != "raw") if len(sys.argv) > 6 else True
 H, W, M, CAMS = 900, 1600, 8, 6
 
 shutil.rmtree(root, ignore_errors=True)
@@ -39,7 +40,7 @@ for s in range(samples):
         n = int(sc.n_inst[c])
         kitti_io.write_frame(root, idx, pts, sc.calibs[c], img, sc.masks[c][:n].cpu().numpy(),
                              sc.inst_class[c][:n].cpu().numpy(), np.full(n, 0.9, np.float32),
-                             sc.inst_box[c][:n].cpu().numpy(), NUSC_CLASSES, sc.depth[c].cpu().numpy())
+                             sc.inst_box[c][:n].cpu().numpy(), NUSC_CLASSES, sc.depth[c].cpu().numpy(), compress=compress)
         idx += 1
 t_write = time.perf_counter() - t0
 stems = ["%06d" % i for i in range(idx)]
@@ -81,6 +82,6 @@ torch.cuda.synchronize()
 out["engine_only_ms_per_batch"] = round((time.perf_counter() - t0) * 100, 2)
 out.update({"camera_frames": idx, "input_MB": round(bytes_in / 1e6, 1), "read_one_frame_ms_one_thread": round(t_read1 * 1e3, 1),
             "write_dataset_s": round(t_write, 1), "batch_frames": batch, "streams": streams, "workers": workers,
-            "cpus": os.cpu_count(), "scratch": root})
+            "cpus": os.cpu_count(), "scratch": root, "masks": "deflated npz" if compress else "stored npz"})
 print(json.dumps(out))
 shutil.rmtree(root, ignore_errors=True)
