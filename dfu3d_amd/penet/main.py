@@ -43,6 +43,8 @@ def build_parser():
     ap.add_argument('--no-virtual-points', action='store_true',
                     help='labels only: skip the velodyne_depth/*.npy files of vis_utils.py:164-166')
     ap.add_argument('--streams', type=int, default=2)
+    ap.add_argument('--reader-procs', type=int, default=8,
+                    help='forked reader processes for the batched path (0 = reader threads only)')
     return ap
 
 
@@ -54,6 +56,14 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.cpu:
         raise SystemExit("--cpu: this build has no CPU path (the oracle under oracle/ is test-only)")
+    # reader processes must be forked before this process touches the GPU (dfu3d_amd/reader_pool.py)
+    rpool = None
+    if args.batch_frames > 0 and args.reader_procs > 0:
+        try:
+            from ..reader_pool import ReaderPool
+            rpool = ReaderPool(args.reader_procs)
+        except RuntimeError:
+            rpool = None                      # GPU already initialised in this process: threads
     from .. import dist as D
     from .vis_utils import save_depth_as_points
     rank, world, local = D.init_from_env()
@@ -69,8 +79,9 @@ def main(argv=None):
         lab = BatchedLabeler(batch_frames=max(1, min(args.batch_frames, len(mine))), lanes=args.streams,
                              workers=max(1, args.workers),
                              device="cuda:%d" % (local if world > 1 else 0),
-                             want_points=not args.no_virtual_points)
+                             want_points=not args.no_virtual_points, reader_pool=rpool)
         stats = lab.run(args.detpath, mine, label_out, depth_dir, seg_dir=args.seg_dir)
+        lab.close()
         if rank == 0:
             dt = time.time() - t0
             print("%d frames, %d boxes, %.2f frames/s (files in, files out)" % (stats["frames"], stats["boxes"],
@@ -86,6 +97,8 @@ def main(argv=None):
                              device="cuda:%d" % (local if world > 1 else 0))
         if rank == 0 and (k + 1) % 10 == 0:
             print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))
+    if rpool is not None:
+        rpool.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -93,7 +93,7 @@ class BatchedLabeler:
     """Directory -> label files, `batch_frames` single-camera frames per engine call."""
 
     def __init__(self, params: Params = None, batch_frames=16, lanes=2, workers=8, device="cuda:0",
-                 cap_n=1 << 17, want_points=False):
+                 cap_n=1 << 17, want_points=False, reader_pool=None, max_masks=32):
         self.p = params or Params()
         self.B = int(batch_frames)
         self.lanes = int(lanes)
@@ -104,6 +104,9 @@ class BatchedLabeler:
         self._engines = {}
         self._copy_stream = torch.cuda.Stream(self.dev)
         self._stage = {}
+        self.pool_procs = reader_pool        # dfu3d_amd.reader_pool.ReaderPool (forked before the GPU was touched) or None
+        self.max_masks = int(max_masks)
+        self._shm = {}
         self.seg_dir = None
         self.stats = {"frames": 0, "boxes": 0, "t_read": 0.0, "t_pack": 0.0, "t_wait": 0.0, "t_gpu": 0.0}
 
@@ -257,6 +260,130 @@ class BatchedLabeler:
         self.stats["t_pack"] += time.perf_counter() - t1
         return frames, packed
 
+    # ---- reader processes: shared-memory staging, page-locked once --------------------------------
+    def _shm_slot(self, slot, H, W):
+        from multiprocessing import shared_memory
+        from .reader_pool import ReaderPool
+        st = self._shm.get(slot)
+        if st is not None and (st["lay"]["H"], st["lay"]["W"]) == (H, W):
+            if st["done"] is not None:
+                st["done"].synchronize()
+            return st
+        if st is not None:
+            self._release_slot(st)
+        lay = ReaderPool.layout(self.B, H, W, self.cap_n, self.max_masks, self.want_points)
+        shm = shared_memory.SharedMemory(create=True, size=lay["bytes"])
+        buf = torch.frombuffer(shm.buf, dtype=torch.uint8)
+        rc = torch.cuda.cudart().cudaHostRegister(buf.data_ptr(), lay["bytes"], 0)
+        B = self.B
+        esz = {torch.float32: 4, torch.uint8: 1}
+        view = lambda key, shape, dt: buf[lay[key]:lay[key] + int(np.prod(shape)) * esz[dt]].view(dt).view(shape)
+        st = {"lay": lay, "shm": shm, "buf": buf, "registered": (getattr(rc, "value", rc) == 0), "done": None,
+              "pts": view("pts", (B, self.cap_n, 4), torch.float32), "depth": view("depth", (B, H, W), torch.float32),
+              "masks": view("masks", (B, self.max_masks, H, W), torch.uint8),
+              "image": view("image", (B, H, W, 3), torch.uint8) if self.want_points else None}
+        st["depth"].zero_()
+        self._shm[slot] = st
+        return st
+
+    def _release_slot(self, st):
+        try:
+            if st["registered"]:
+                torch.cuda.cudart().cudaHostUnregister(st["buf"].data_ptr())
+        except Exception:
+            pass
+        for k in ("pts", "depth", "masks", "image", "buf"):
+            st[k] = None
+        try:
+            st["shm"].close()
+            st["shm"].unlink()
+        except Exception:
+            pass
+
+    def close(self):
+        """Unpin and unlink the shared-memory staging (reader-process mode)."""
+        for st in self._shm.values():
+            self._release_slot(st)
+        self._shm = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    class _Meta:
+        def __init__(self, stem):
+            self.stem, self.image, self.points = stem, None, None
+
+    def _prepare_procs(self, root, batch, depth_dir, slot):
+        torch.cuda.set_device(self.dev)
+        t0 = time.perf_counter()
+        d0 = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), batch[0] + '.npy'), mmap_mode='r')
+        H, W = int(d0.shape[0]), int(d0.shape[1])
+        del d0
+        st = self._shm_slot(slot, H, W)
+        metas = self.pool_procs.read_batch(root, batch, depth_dir, self.seg_dir, self.want_points, st["shm"].name,
+                                           st["lay"])
+        t1 = time.perf_counter()
+        B, nb = self.B, len(batch)
+        if nb < B:
+            st["depth"][nb:].zero_()
+        M = min(self.max_masks, (max([m["m"] for m in metas] + [1]) + 7) // 8 * 8)
+        n_pts = [m["n"] for m in metas] + [0] * (B - nb)
+        off = np.zeros(B + 1, np.int64)
+        off[1:] = np.cumsum(n_pts)
+        calib = torch.zeros((B, 48), dtype=torch.float32)
+        n_inst = torch.zeros(B, dtype=torch.int32)
+        cls = torch.zeros((B, M), dtype=torch.int32)
+        car = torch.zeros((B, M), dtype=torch.int32)
+        rl = torch.zeros((B, M), dtype=torch.float64)
+        rp = torch.zeros((B, M), dtype=torch.float64)
+        box = torch.zeros((B, M, 4), dtype=torch.float32)
+        score = torch.zeros((B, M), dtype=torch.float32)
+        key = torch.zeros(B, dtype=torch.int64)
+        frames = []
+        for i, m in enumerate(metas):
+            k = min(m["m"], M)
+            calib[i] = torch.from_numpy(m["calib"])
+            n_inst[i] = k
+            for j in range(k):
+                nm = m["thing_classes"][int(m["classes"][j])]
+                cls[i, j] = int(m["classes"][j])
+                car[i, j] = 1 if nm == "Car" else 0
+                rl[i, j], rp[i, j] = self.p.instance_radii(nm)
+            if k:
+                box[i, :k] = torch.from_numpy(np.asarray(m["boxes"][:k], np.float32))
+                score[i, :k] = torch.from_numpy(np.asarray(m["scores"][:k], np.float32))
+            key[i] = int(m["stem"]) if m["stem"].isdigit() else i
+            f = BatchedLabeler._Meta(m["stem"])
+            if self.want_points:
+                f.image = st["image"][i].numpy()
+                f.points = st["pts"][i, :m["n"]].numpy()
+            frames.append(f)
+        d = self.dev
+        with torch.cuda.stream(self._copy_stream):
+            g = lambda t: t.to(d, non_blocking=True)
+            pts_d = torch.empty((max(int(off[-1]), 1), 4), dtype=torch.float32, device=d)
+            masks_d = torch.empty((B, M, H, W), dtype=torch.uint8, device=d)
+            for i, m in enumerate(metas):
+                if m["n"]:
+                    pts_d[off[i]:off[i + 1]].copy_(st["pts"][i, :m["n"]], non_blocking=True)
+                k = min(m["m"], M)
+                if k:
+                    masks_d[i, :k].copy_(st["masks"][i, :k], non_blocking=True)
+            vb = ViewBatch(points=pts_d, pt_off=g(torch.from_numpy(off).to(torch.int32)),
+                           view_frame=torch.arange(B, dtype=torch.int32, device=d), calib=g(calib),
+                           masks=masks_d, n_inst=g(n_inst), inst_class=g(cls), inst_is_car=g(car), inst_r_lidar=g(rl),
+                           inst_r_pseudo=g(rp), inst_box=g(box), inst_score=g(score), view_key=g(key),
+                           host_pt_off=off, host_view_frame=np.arange(B), depth=g(st["depth"]))
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        st["done"] = ready
+        self.stats["t_read"] += t1 - t0
+        self.stats["t_pack"] += time.perf_counter() - t1
+        return frames, (vb, ready, (H, W, M))
+
     def run(self, root, stems: List[str], label_out, depth_dir=None, npy_out=None, seg_dir=None):
         self.seg_dir = seg_dir
         os.makedirs(label_out, exist_ok=True)
@@ -270,14 +397,16 @@ class BatchedLabeler:
         prep = ThreadPoolExecutor(1)                  # reads + packs + uploads the NEXT batch
         writers = ThreadPoolExecutor(2)
         pending = []
-        fut = prep.submit(self._prepare, root, batches[0], depth_dir, pool, 0)
+        prepare = (lambda b_, slot_: self._prepare_procs(root, b_, depth_dir, slot_)) if self.pool_procs is not None \
+            else (lambda b_, slot_: self._prepare(root, b_, depth_dir, pool, slot_))
+        fut = prep.submit(prepare, batches[0], 0)
         for bi in range(len(batches)):
             t0 = time.perf_counter()
             frames, (vb, ready, (H, W, M)) = fut.result()
             t1 = time.perf_counter()
             self.stats["t_wait"] += t1 - t0
             if bi + 1 < len(batches):
-                fut = prep.submit(self._prepare, root, batches[bi + 1], depth_dir, pool, (bi + 1) & 1)
+                fut = prep.submit(prepare, batches[bi + 1], (bi + 1) & 1)
             eng = self._engine(H, W, M)
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_event(ready)

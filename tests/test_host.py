@@ -66,3 +66,45 @@ def test_synthetic_scene_shapes_and_oracle_runs():
                               s.inst_box[0][:n].numpy(), op, want_points=False)
     assert res.plane.shape == (4,)
     assert abs(res.plane[3] - 1.84) < 0.1       # ground at z = -1.84
+
+
+def test_reader_pool_fills_shared_staging(tmp_path):
+    """dfu3d_amd.reader_pool: forked workers read frames into shared memory at fixed strides; the bytes equal what
+    pipeline.read_frame returns (CPU only: the pool refuses to start once the GPU is initialised)."""
+    from multiprocessing import shared_memory
+    import numpy as np
+    from dfu3d_amd import kitti_io, synth
+    from dfu3d_amd.params import NUSC_CLASSES
+    from dfu3d_amd.pipeline import read_frame
+    from dfu3d_amd.reader_pool import ReaderPool
+    H, W, M = 48, 64, 4
+    root = str(tmp_path / "k")
+    for f in range(3):
+        s = synth.make_scene(50 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=5, k_max=7)
+        n = int(s.n_inst[0])
+        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], np.full((H, W, 3), 7 + f, np.uint8),
+                             s.masks[0][:n].numpy(), s.inst_class[0][:n].numpy(), np.full(n, 0.9, np.float32),
+                             s.inst_box[0][:n].numpy(), NUSC_CLASSES, s.depth[0].numpy(), compress=bool(f % 2))
+    pool = ReaderPool(2)
+    lay = ReaderPool.layout(4, H, W, 40000, 8, True)
+    shm = shared_memory.SharedMemory(create=True, size=lay["bytes"])
+    try:
+        stems = ["%06d" % f for f in range(3)]
+        metas = pool.read_batch(root, stems, None, None, True, shm.name, lay)
+        for i, (st, m) in enumerate(zip(stems, metas)):
+            ref = read_frame(root, st, want_image=True)
+            assert m["stem"] == st and m["n"] == ref.points.shape[0] and m["m"] == ref.masks.shape[0]
+            v = lambda off, shape, dt: np.ndarray(shape, dt, buffer=shm.buf, offset=off)
+            assert np.array_equal(v(lay["pts"] + i * lay["cap_n"] * 16, (m["n"], 4), np.float32), ref.points)
+            assert np.array_equal(v(lay["depth"] + i * H * W * 4, (H, W), np.float32), ref.depth)
+            assert np.array_equal(v(lay["masks"] + i * 8 * H * W, (m["m"], H, W), np.uint8), ref.masks)
+            assert np.array_equal(v(lay["image"] + i * H * W * 3, (H, W, 3), np.uint8), ref.image)
+            assert np.array_equal(m["calib"], ref.calib.record()) and np.array_equal(m["classes"], ref.classes)
+        import pytest
+        with pytest.raises(RuntimeError):
+            pool.read_batch(root, ["999999"], None, None, False, shm.name, lay)      # missing frame is reported
+        assert len(pool.read_batch(root, stems[:1], None, None, False, shm.name, lay)) == 1   # and the pool lives on
+    finally:
+        pool.close()
+        shm.close()
+        shm.unlink()
