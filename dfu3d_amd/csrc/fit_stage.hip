@@ -22,7 +22,7 @@ constexpr int BLK = 32;            // groups per block (1024 points): second pru
 constexpr int SMALL_N = 4096;      // segments up to this size: 32-bit parents, 20 KB of LDS
 constexpr int LARGE_N = 61440;     // up to this size: 16-bit parents in LDS (120 KB)
 constexpr int LARGE_GRP = LARGE_N / GRP;
-constexpr int GRID_NC_SMALL = 2048;   // grid path: cells kept in LDS (24 KB) ...
+constexpr int GRID_NC_SMALL = 4096;   // grid path: cells kept in LDS (48 KB) ...
 constexpr int GRID_NC_LARGE = 12288;  // ... or 144 KB for wide instances
 
 // ---- parent-array accessors: 32-bit (LDS or global) and 16-bit (LDS only) ----
