@@ -132,7 +132,7 @@ __device__ __forceinline__ int block_sum_i(int v, int *s_red) {
   return t;
 }
 
-constexpr int RB = 16;   // RANSAC trials scored per sweep over the candidates
+constexpr int RB = 8;   // RANSAC trials scored per sweep over the candidates
 
 __global__ __launch_bounds__(NT) void k_plane_ransac(
     const float4 *__restrict__ pts, const int *__restrict__ pt_off,

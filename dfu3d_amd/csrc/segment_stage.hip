@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_radius_resolve_long(
 constexpr int BT = 1024;                       // queries per tile = threads per workgroup
 constexpr int BH_HEADS = 8192;                 // 32 KB of LDS
 constexpr int BH_MAX = 4096;                   // nodes: 32 KB of LDS; 12-bit index
-constexpr int BQ_TPB = 4;
+constexpr int BQ_TPB = 1;
 
 __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
   uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
