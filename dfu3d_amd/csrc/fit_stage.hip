@@ -708,7 +708,7 @@ __global__ __launch_bounds__(CT) void k_range_cluster_large(
 constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
-constexpr int LDS_MEMBERS = 4096;   // clusters up to this size: members cached in LDS, one wave per heading
+constexpr int LDS_MEMBERS = 2048;   // clusters up to this size: members cached in LDS, one wave per heading
 constexpr int TB = 8;               // larger clusters: headings per point-parallel sweep
 
 // block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
