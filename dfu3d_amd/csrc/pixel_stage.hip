@@ -526,15 +526,16 @@ __global__ __launch_bounds__(256) void k_ovf_select(
 // prefix (decoupled look-back; blocks of a view are dispatched in order of b).
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
 
-constexpr int EPT = 32;                       // pixels per thread in P3 (eight uint4 loads)
-constexpr int EBLK = PB * EPT;                 // 8192 pixels per block: few look-backs per view
+constexpr int EPB = 512;                      // threads per P3 workgroup
+constexpr int EPT = 16;                       // pixels per thread in P3 (four uint4 loads)
+constexpr int EBLK = EPB * EPT;                 // 8192 pixels per block: few look-backs per view
 
-__global__ __launch_bounds__(PB) void k_bp_emit(
+__global__ __launch_bounds__(EPB) void k_bp_emit(
     int HW, int64_t E_view, void *table, int64_t E_total,
     const uint32_t *__restrict__ pix_bin, int nblk, unsigned long long *__restrict__ lb,
     int cap_vox, uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
     uint32_t *__restrict__ status) {
-  __shared__ int s_w[PB / 64];
+  __shared__ int s_w[EPB / 64];
   __shared__ int s_excl;
   const int v = blockIdx.y, bk = blockIdx.x;
   const Table T = table_view(table, E_total);
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(PB) void k_bp_emit(
     if ((bins[k] != NOBIN) && (T.first[tb0 + bins[k]] == (uint32_t)(base + k))) isf |= 1u << k;
   const int mine = __popc(isf);
   int tot;
-  const int r_in = block_excl_scan<PB / 64>(mine, s_w, tot);
+  const int r_in = block_excl_scan<EPB / 64>(mine, s_w, tot);
   unsigned long long *my = lb + (size_t)v * nblk;
   if (threadIdx.x < 64) {                       // first wave: publish, look back, publish
     const int lane = threadIdx.x;
@@ -610,7 +611,9 @@ __global__ __launch_bounds__(PB) void k_bp_emit(
 }
 
 // ---- P4: per voxel output + table reset --------------------------------------
-__global__ __launch_bounds__(256) void k_bp_vox(
+constexpr int VXB = 1024;                     // threads per P4 workgroup
+constexpr int VXG = 65535;                      // workgroups per view (grid-stride over the voxels)
+__global__ __launch_bounds__(VXB) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const uint8_t *__restrict__ masks, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox,
@@ -621,8 +624,7 @@ __global__ __launch_bounds__(256) void k_bp_vox(
   const int v = blockIdx.y;
   const int ntouched = min(n_vox[v], cap_vox);
   const int nout = min(ntouched, max_voxels);
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < ntouched) {
+  for (int k = blockIdx.x * VXB + threadIdx.x; k < ntouched; k += gridDim.x * VXB) {
     const Table T = table_view(table, E_total);
     const size_t o = (size_t)v * cap_vox + k;
     const int64_t e = (int64_t)v * E_view + vox_bin[o];
@@ -850,12 +852,12 @@ extern "C" int dfu3d_backproject_bin(
   if (phases & DFU3D_BP_EMIT) {
   const int nblk_e = (HW + EBLK - 1) / EBLK;
   if (hipMemsetAsync(lb, 0, sizeof(unsigned long long) * (size_t)V * nblk_e, st) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_bp_emit, dim3(nblk_e, V), dim3(PB), 0, st, HW, E_view, table, E_total,
+  hipLaunchKernelGGL(k_bp_emit, dim3(nblk_e, V), dim3(EPB), 0, st, HW, E_view, table, E_total,
                      pix_bin, nblk_e, lb, cap_vox, vox_bin, n_vox, status);
   DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-  hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + 255) / 256, V), dim3(256), 0, st, depth, cal,
+  hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + VXB - 1) / VXB < VXG ? (cap_vox + VXB - 1) / VXB : VXG, V), dim3(VXB), 0, st, depth, cal,
                      masks, n_inst, max_inst, W, HW, geom->max_voxels, E_view, table,
                      E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z, pix_bin,
                      key_axis, pix_bits);
