@@ -142,6 +142,32 @@ class BatchedLabeler:
             st["done"].synchronize()                   # the upload that last read these buffers
         return st
 
+    def _instance_tensors(self, B, M, items):
+        """Per-view small inputs from [(stem, calib record (48,), classes, scores, boxes, thing_classes)]."""
+        calib = torch.zeros((B, 48), dtype=torch.float32)
+        n_inst = torch.zeros(B, dtype=torch.int32)
+        cls = torch.zeros((B, M), dtype=torch.int32)
+        car = torch.zeros((B, M), dtype=torch.int32)
+        rl = torch.zeros((B, M), dtype=torch.float64)
+        rp = torch.zeros((B, M), dtype=torch.float64)
+        box = torch.zeros((B, M, 4), dtype=torch.float32)
+        score = torch.zeros((B, M), dtype=torch.float32)
+        key = torch.zeros(B, dtype=torch.int64)
+        for i, (stem, rec, classes, scores, boxes, names) in enumerate(items):
+            m = min(len(classes), M)
+            calib[i] = torch.from_numpy(np.asarray(rec, np.float32))
+            n_inst[i] = m
+            for j in range(m):
+                nm = names[int(classes[j])]
+                cls[i, j] = int(classes[j])
+                car[i, j] = 1 if nm == "Car" else 0
+                rl[i, j], rp[i, j] = self.p.instance_radii(nm)
+            if m:
+                box[i, :m] = torch.from_numpy(np.asarray(boxes[:m], np.float32))
+                score[i, :m] = torch.from_numpy(np.asarray(scores[:m], np.float32))
+            key[i] = int(stem) if stem.isdigit() else i
+        return calib, n_inst, cls, car, rl, rp, box, score, key
+
     def _pack(self, frames: List[Frame], slot, pool):
         """Frames -> pinned host tensors -> device ViewBatch (async on the copy stream)."""
         B = self.B
@@ -172,28 +198,8 @@ class BatchedLabeler:
         list(pool.map(fill, range(len(frames))))
         if len(frames) < B:
             depth[len(frames):].zero_()                # padded views: no pixels, no points, no instances
-        calib = torch.zeros((B, 48), dtype=torch.float32)
-        n_inst = torch.zeros(B, dtype=torch.int32)
-        cls = torch.zeros((B, M), dtype=torch.int32)
-        car = torch.zeros((B, M), dtype=torch.int32)
-        rl = torch.zeros((B, M), dtype=torch.float64)
-        rp = torch.zeros((B, M), dtype=torch.float64)
-        box = torch.zeros((B, M, 4), dtype=torch.float32)
-        score = torch.zeros((B, M), dtype=torch.float32)
-        key = torch.zeros(B, dtype=torch.int64)
-        for i, f in enumerate(frames):
-            m = min(f.masks.shape[0], M)
-            calib[i] = torch.from_numpy(f.calib.record())
-            n_inst[i] = m
-            for j in range(m):
-                nm = f.thing_classes[int(f.classes[j])]
-                cls[i, j] = int(f.classes[j])
-                car[i, j] = 1 if nm == "Car" else 0
-                rl[i, j], rp[i, j] = self.p.instance_radii(nm)
-            if m:
-                box[i, :m] = torch.from_numpy(f.boxes[:m])
-                score[i, :m] = torch.from_numpy(f.scores[:m])
-            key[i] = int(f.stem) if f.stem.isdigit() else i
+        calib, n_inst, cls, car, rl, rp, box, score, key = self._instance_tensors(
+            B, M, [(f.stem, f.calib.record(), f.classes, f.scores, f.boxes, f.thing_classes) for f in frames])
         d = self.dev
         with torch.cuda.stream(self._copy_stream):
             g = lambda t: t.to(d, non_blocking=True)
@@ -333,29 +339,10 @@ class BatchedLabeler:
         n_pts = [m["n"] for m in metas] + [0] * (B - nb)
         off = np.zeros(B + 1, np.int64)
         off[1:] = np.cumsum(n_pts)
-        calib = torch.zeros((B, 48), dtype=torch.float32)
-        n_inst = torch.zeros(B, dtype=torch.int32)
-        cls = torch.zeros((B, M), dtype=torch.int32)
-        car = torch.zeros((B, M), dtype=torch.int32)
-        rl = torch.zeros((B, M), dtype=torch.float64)
-        rp = torch.zeros((B, M), dtype=torch.float64)
-        box = torch.zeros((B, M, 4), dtype=torch.float32)
-        score = torch.zeros((B, M), dtype=torch.float32)
-        key = torch.zeros(B, dtype=torch.int64)
+        calib, n_inst, cls, car, rl, rp, box, score, key = self._instance_tensors(
+            B, M, [(m["stem"], m["calib"], m["classes"], m["scores"], m["boxes"], m["thing_classes"]) for m in metas])
         frames = []
         for i, m in enumerate(metas):
-            k = min(m["m"], M)
-            calib[i] = torch.from_numpy(m["calib"])
-            n_inst[i] = k
-            for j in range(k):
-                nm = m["thing_classes"][int(m["classes"][j])]
-                cls[i, j] = int(m["classes"][j])
-                car[i, j] = 1 if nm == "Car" else 0
-                rl[i, j], rp[i, j] = self.p.instance_radii(nm)
-            if k:
-                box[i, :k] = torch.from_numpy(np.asarray(m["boxes"][:k], np.float32))
-                score[i, :k] = torch.from_numpy(np.asarray(m["scores"][:k], np.float32))
-            key[i] = int(m["stem"]) if m["stem"].isdigit() else i
             f = BatchedLabeler._Meta(m["stem"])
             if self.want_points:
                 f.image = st["image"][i].numpy()
