@@ -203,12 +203,21 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
                                                    int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
   double x, y, z;
+#ifdef DFU3D_DBG_NOBACKPROJ
+  x = (double)d * 0.9; y = (double)(col - 800) * (double)d * 1e-3; z = -1.5 + (double)(450 - row) * (double)d * 1e-3;
+#else
   pixel_to_lidar(c, rc, col, row, d, x, y, z);
+#endif
   if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
   key = (key_axis == 2) ? z : y;
   if (key == 0.0) key = 0.0;
   float rf, th, eps_t, ph, eps_p;
+#ifdef DFU3D_DBG_NOANGLE
+  rf = 10.f; th = 1.6f + 1.3e-4f * (float)row; ph = -0.5f + 7.7e-4f * (float)col; eps_t = 3e-6f; eps_p = 3e-6f;
+  if (x == 1234.5) return AMBIG;
+#else
   if (!angle_estimate(x, y, z, rf, th, eps_t, ph, eps_p)) return AMBIG;
+#endif
   // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
   if (!(rf > fg.r_lo && rf < fg.r_hi)) return AMBIG;
   if (th < fg.theta_min - eps_t) return NOBIN;                    // certainly theta <= theta_min
@@ -259,11 +268,11 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   int its[PPT], ips[PPT];
   const bool inside = (row < H) && (col < W);
   const int base = row * W + col;
+  int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
   if (inside) {
     const float *dv = depth + (size_t)v * HW;
     float d[PPT];
     load4(dv + (size_t)row * W, col, W, d);
-    int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       bins[k] = NOBIN;
@@ -280,7 +289,6 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         }
       }
     }
-    if (tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
     if (col + PPT <= W) {
       *(uint4 *)(pix_bin + (size_t)v * HW + base) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
     } else {
@@ -288,6 +296,14 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         if (col + k < W) pix_bin[(size_t)v * HW + base + k] = bins[k];
     }
   }
+  // window origin: wave minimum first (all lanes), then one LDS atomic per wave -- 256 lanes on two
+  // addresses serialise
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    tmin = min(tmin, __shfl_xor(tmin, m, 64));
+    pmin = min(pmin, __shfl_xor(pmin, m, 64));
+  }
+  if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
 #ifdef DFU3D_DBG_BP_NOAGG
