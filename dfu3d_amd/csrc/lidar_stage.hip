@@ -364,21 +364,21 @@ __global__ __launch_bounds__(256) void k_label_rows(
     double *__restrict__ it_y, double *__restrict__ it_z) {
   const int v = blockIdx.y;
   const int K = Kin[v];
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= K) return;
-  const size_t o = (size_t)v * capN + t;
   const int p0 = pt_off[view_frame[v]];
-  const float4 p = pts[p0 + ag_pt[o]];
-  const int pix = ib_pix[o];
-  uint32_t bits = 0u;
   const int m = n_inst[v];
   const uint8_t *mb = masks + (size_t)v * max_inst * HW;
-  for (int j = 0; j < m; j++)
-    bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
-  it_bits[o] = bits;
-  it_x[o] = (double)p.x;
-  it_y[o] = (double)p.y;
-  it_z[o] = (double)p.z;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < K; t += gridDim.x * 256) {   // K is a few hundred rows
+    const size_t o = (size_t)v * capN + t;
+    const float4 p = pts[p0 + ag_pt[o]];
+    const int pix = ib_pix[o];
+    uint32_t bits = 0u;
+    for (int j = 0; j < m; j++)
+      bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
+    it_bits[o] = bits;
+    it_x[o] = (double)p.x;
+    it_y[o] = (double)p.y;
+    it_z[o] = (double)p.z;
+  }
 }
 
 }  // namespace
@@ -437,7 +437,7 @@ extern "C" int dfu3d_project_label(
                      (float)H, (float)W, W, plane_offset, (float)xy_range, ag_pt,
                      ib_pix, n_ag, K);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_label_rows, dim3((cap_n + 255) / 256, V), dim3(256), 0,
+  hipLaunchKernelGGL(k_label_rows, dim3((cap_n + 255) / 256 < 8 ? (cap_n + 255) / 256 : 8, V), dim3(256), 0,
                      (hipStream_t)stream, (const float4 *)points, pt_off, view_frame,
                      ag_pt, ib_pix, K, masks, n_inst, max_inst, H * W, cap_n, it_bits,
                      it_x, it_y, it_z);

@@ -432,18 +432,19 @@ __global__ __launch_bounds__(PB) void k_ovf_gather(
     const uint32_t *__restrict__ pix_bin, void *table, int64_t E_total, int64_t E_view,
     int HW, const int *__restrict__ n_ovf, uint32_t *__restrict__ ovf_list) {
   const int v = blockIdx.y;
-  if (n_ovf[v] == 0) return;
+  if (n_ovf[v] == 0) return;                       // the usual case: a few workgroups per view leave at once
   const Table T = table_view(table, E_total);
-  const int base = blockIdx.x * PBLK + threadIdx.x * PPT;
-  for (int k = 0; k < PPT; k++) {
-    const int pix = base + k;
-    if (pix >= HW) break;
-    const uint32_t b = pix_bin[(size_t)v * HW + pix];
-    if (b == NOBIN) continue;
-    const int64_t e = (int64_t)v * E_view + b;
-    if (T.cnt[e] & OVF_FLAG) {
-      const uint32_t pos = atomicAdd(&T.cnt[e], 1u) & ~OVF_FLAG;
-      ovf_list[(size_t)v * HW + T.rep[e] + pos] = (uint32_t)pix;
+  for (int base = blockIdx.x * PBLK + threadIdx.x * PPT; base < HW; base += gridDim.x * PBLK) {
+    for (int k = 0; k < PPT; k++) {
+      const int pix = base + k;
+      if (pix >= HW) break;
+      const uint32_t b = pix_bin[(size_t)v * HW + pix];
+      if (b == NOBIN) continue;
+      const int64_t e = (int64_t)v * E_view + b;
+      if (T.cnt[e] & OVF_FLAG) {
+        const uint32_t pos = atomicAdd(&T.cnt[e], 1u) & ~OVF_FLAG;
+        ovf_list[(size_t)v * HW + T.rep[e] + pos] = (uint32_t)pix;
+      }
     }
   }
 }
@@ -856,7 +857,7 @@ extern "C" int dfu3d_backproject_bin(
                      E_total, E_view, cap_ovf, ovf_bins, n_ovf, ovf_cnt, ovf_cursor, HW,
                      status);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ovf_gather, dim3(nblk, V), dim3(PB), 0, st, pix_bin, table, E_total,
+  hipLaunchKernelGGL(k_ovf_gather, dim3(nblk < 128 ? nblk : 128, V), dim3(PB), 0, st, pix_bin, table, E_total,
                      E_view, HW, n_ovf, ovf_list);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_ovf_select, dim3(cap_ovf < 32 ? cap_ovf : 32, V), dim3(256), 0, st, depth, cal, W, HW,
