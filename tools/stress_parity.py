@@ -10,7 +10,7 @@ from dfu3d_amd.params import Params
 from tests.test_gpu_engine import _oracle_rows, _compare
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
