@@ -511,7 +511,7 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
     double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
-    int *__restrict__ perm_all) {
+    int *__restrict__ perm_all, long long pool_cap) {
   __shared__ int s_end[NC];          // cell -> end of its run in sorted order
   __shared__ int s_par[NC];          // union-find over cells (volatile use through pointers)
   __shared__ int s_min[NC];          // smallest original index per root cell
@@ -524,12 +524,14 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
   const double *X = px + base, *Y = py + base;
   double *SX = sx + base, *SY = sy + base;
   int *perm = perm_all + base;
+  // "handled" mark of the segment, in the first word of its third scratch plane (only the point-level
+  // fallback uses that plane): the first variant writes it, the later kernels of the call read it and
+  // leave at once instead of measuring the instance again
+  int *mark = perm_all + 2 * pool_cap + base;
+  if (NC_MIN > 0 && *mark) return;                     // the smaller variant did it
   const GridGeom<NC> G = grid_geometry<NC>(X, Y, n, R0, Rd, s_red);
-  if (!G.ok) return;                                   // too wide: point-level kernels
-  if (NC_MIN > 0) {                                    // the smaller variant owns it
-    const GridGeom<(NC_MIN > 0 ? NC_MIN : 1)> Gs = grid_geometry<(NC_MIN > 0 ? NC_MIN : 1)>(X, Y, n, R0, Rd, s_red);
-    if (Gs.ok) return;
-  }
+  if (threadIdx.x == 0 && (NC_MIN == 0 || G.ok)) *mark = G.ok ? 1 : 0;
+  if (!G.ok) return;                                   // too wide: a larger variant / the point-level kernels
   const int ncell = G.ncell;
   // ---- counting sort by cell ------------------------------------------------
   for (int c = threadIdx.x; c < ncell; c += CT) { s_end[c] = 0; s_par[c] = c; s_min[c] = 0x7FFFFFFF; }
@@ -660,13 +662,12 @@ __global__ __launch_bounds__(CT) void k_range_cluster_small(
   __shared__ int s_summ2[SMALL_N / GRP / BLK];
   __shared__ float4 s_box2[SMALL_N / GRP / BLK];
   __shared__ double s_red[4 * (CT / 64)];
-  __shared__ double s_red5[5 * (CT / 64)];
   __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0 || n > SMALL_N) return;
   const long long base = seg_base[s];
-  if (grid_geometry<GRID_NC_LARGE>(px + base, py + base, n, R0, Rd, s_red5).ok) return;   // grid path did it
+  if (si[2 * pool_cap + base]) return;                 // a grid variant did it (mark written there)
   cell_sort<SMALL_N>(px + base, py + base, n, s_parent, s_red, s_w, sx + base, sy + base, si + base);
   ParI par{s_parent, false};
   cluster_body<ParI, SMALL_N / GRP>(par, s_summ, s_box, s_summ2, s_box2, s_red, sx + base, sy + base,
@@ -684,13 +685,12 @@ __global__ __launch_bounds__(CT) void k_range_cluster_large(
   __shared__ int s_summ2[LARGE_GRP / BLK];
   __shared__ float4 s_box2[LARGE_GRP / BLK];
   __shared__ double s_red[4 * (CT / 64)];
-  __shared__ double s_red5[5 * (CT / 64)];
   __shared__ int s_w[CT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n <= SMALL_N) return;
   const long long base = seg_base[s];
-  if (grid_geometry<GRID_NC_LARGE>(px + base, py + base, n, R0, Rd, s_red5).ok) return;   // grid path did it
+  if (si[2 * pool_cap + base]) return;                 // a grid variant did it (mark written there)
   cell_sort<LARGE_N / 2>(px + base, py + base, n, (int *)s_parent, s_red, s_w, sx + base, sy + base,
                          si + base);
   if (n <= LARGE_N) {
@@ -1375,11 +1375,11 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0>), dim3(S), dim3(CT), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si);
+                     label, sx, sy, si, (long long)pool_cap);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL>), dim3(S), dim3(CT), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si);
+                     label, sx, sy, si, (long long)pool_cap);
   DFU3D_LAUNCH_CHECK();
   // fallback for instances wider than the largest grid: point-level union-find
   // (two LDS footprints; each kernel returns at once for segments it does not own)
