@@ -76,33 +76,62 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt
   if (threadIdx.x == 0) *cursor = running < pool_cap ? running : pool_cap;
 }
 
-__global__ __launch_bounds__(256) void k_seg_write(
+// One workgroup per VIEW writes the ordered lists of all its instances in a single sweep over the view's
+// items (a workgroup per instance read the 100k+ items of the view once per instance: L2-bound).  Per step of
+// 1024 items: per-instance ballots inside each wave, wave totals through LDS, two barriers.
+constexpr int SWT = 1024;
+__global__ __launch_bounds__(SWT) void k_seg_write(
     const uint32_t *__restrict__ bits, const double *__restrict__ ix,
     const double *__restrict__ iy, const double *__restrict__ iz,
     const int *__restrict__ n_item, int cap_item, int max_inst,
     const long long *__restrict__ base, const int *__restrict__ cnt,
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz) {
-  __shared__ int s_w[4];
-  const int s = blockIdx.x;
-  const int total = cnt[s];
-  if (total == 0) return;
-  const int v = s / max_inst, j = s - v * max_inst;
+  __shared__ int s_wc[SWT / 64][DFU3D_MAX_INST];      // per wave: items of instance j in this step
+  __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items written before this step
+  const int v = blockIdx.x;
   const int n = min(n_item[v], cap_item);
-  const long long b = base[s];
-  int running = 0;
-  for (int t0 = 0; t0 < n && running < total; t0 += 256) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  uint32_t live = 0u;                                  // instances of this view with a non-empty list
+  for (int j = 0; j < max_inst; j++)
+    if (cnt[v * max_inst + j] > 0) live |= 1u << j;
+  if (live == 0u || n == 0) return;
+  if (threadIdx.x < DFU3D_MAX_INST) s_run[threadIdx.x] = 0;
+  int mytot = 0;                                       // thread j < max_inst: instance j's total of the previous step
+  for (int t0 = 0; t0 < n; t0 += SWT) {
     const int t = t0 + threadIdx.x;
     const size_t o = (size_t)v * cap_item + t;
-    const bool f = (t < n) && ((bits[o] >> j) & 1u);
-    int tot;
-    const int r = block_rank<4>(f, s_w, tot);
-    if (f) {
-      const long long d = b + running + r;
-      px[d] = ix[o];
-      py[d] = iy[o];
-      pz[d] = iz[o];
+    const uint32_t b = (t < n) ? (bits[o] & live) : 0u;
+    __syncthreads();                                   // A: the previous step's s_wc / s_run have been read
+    if ((int)threadIdx.x < max_inst) s_run[threadIdx.x] += mytot;
+    for (uint32_t w = live; w; w &= w - 1u) {          // uniform: every live instance, every wave
+      const int j = __ffs((int)w) - 1;
+      const unsigned long long m = __ballot((b >> j) & 1u);
+      if (lane == 0) s_wc[wave][j] = __popcll(m);
     }
-    running += tot;
+    __syncthreads();                                   // B: counts of all waves, running totals up to date
+    if ((int)threadIdx.x < max_inst) {
+      int tsum = 0;
+#pragma unroll
+      for (int w = 0; w < SWT / 64; w++) tsum += s_wc[w][threadIdx.x];
+      mytot = ((live >> threadIdx.x) & 1u) ? tsum : 0;
+    }
+    uint32_t wany = b;                                 // instances present in this wave (uniform after the OR)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wany |= (uint32_t)__shfl_xor((int)wany, m, 64);
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (b) { x = ix[o]; y = iy[o]; z = iz[o]; }
+    for (uint32_t w = wany; w; w &= w - 1u) {          // uniform per wave
+      const int j = __ffs((int)w) - 1;
+      const unsigned long long m = __ballot((b >> j) & 1u);
+      int before = s_run[j];
+      for (int ww = 0; ww < wave; ww++) before += s_wc[ww][j];
+      if ((b >> j) & 1u) {
+        const long long d = base[v * max_inst + j] + before + __popcll(m & ((1ull << lane) - 1ull));
+        px[d] = x;
+        py[d] = y;
+        pz[d] = z;
+      }
+    }
   }
 }
 
@@ -722,10 +751,10 @@ extern "C" int dfu3d_segments_build(
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
                      (long long *)pool_cursor, status);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(S), dim3(256), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
+  hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
                      max_inst, (const long long *)base_a, cnt_a, px, py, pz);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(S), dim3(256), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
+  hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
                      max_inst, (const long long *)base_b, cnt_b, px, py, pz);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
