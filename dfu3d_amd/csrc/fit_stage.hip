@@ -863,27 +863,28 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
 
-  // max z over ALL instance points (my_loader.py:647-648)
+  // ordered list of cluster roots, and in the same sweep the max z over ALL instance points
+  // (my_loader.py:647-648)
   double zm = -INFINITY;
-  for (int i = threadIdx.x; i < n; i += FT) zm = fmax(zm, pz[base + i]);
+  int nroots = 0;
+  for (int t0 = 0; t0 < n; t0 += FT) {
+    const int i = t0 + threadIdx.x;
+    bool f = false;
+    if (i < n) {
+      f = (label[base + i] == i);
+      zm = fmax(zm, pz[base + i]);
+    }
+    int tot;
+    const int r = block_rank<FW>(f, s_w, tot);
+    if (f) sroot[base + nroots + r] = i;
+    nroots += tot;
+  }
   zm = wave_max_d(zm);
   if (lane == 0) s_red[wave] = zm;
   __syncthreads();
   double zmax = s_red[0];
 #pragma unroll
   for (int w = 1; w < FW; w++) zmax = fmax(zmax, s_red[w]);
-  __syncthreads();
-
-  // ordered list of cluster roots
-  int nroots = 0;
-  for (int t0 = 0; t0 < n; t0 += FT) {
-    const int i = t0 + threadIdx.x;
-    const bool f = (i < n) && (label[base + i] == i);
-    int tot;
-    const int r = block_rank<FW>(f, s_w, tot);
-    if (f) sroot[base + nroots + r] = i;
-    nroots += tot;
-  }
   if (threadIdx.x == 0) s_q0 = atomicAdd(&W.counters[0], nroots);
   __syncthreads();
   const int q0 = s_q0;

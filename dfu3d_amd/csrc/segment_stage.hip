@@ -20,7 +20,7 @@ constexpr int QT = 256;    // queries per workgroup tile
 constexpr int PT = 1024;   // points per LDS tile
 
 // ---------------------------------------------------------------- build
-__global__ __launch_bounds__(256) void k_seg_count(const uint32_t *__restrict__ bits,
+__global__ __launch_bounds__(1024) void k_seg_count(const uint32_t *__restrict__ bits,
                                                    const int *__restrict__ n_item,
                                                    int cap_item, int max_inst,
                                                    int *__restrict__ cnt) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_seg_count(const uint32_t *__restrict__ 
   if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
   __syncthreads();
   const int n = min(n_item[v], cap_item);
-  for (int t = threadIdx.x; t < n; t += 256) {
+  for (int t = threadIdx.x; t < n; t += 1024) {
     uint32_t b = bits[(size_t)v * cap_item + t];
     while (b) {
       const int j = __ffs((int)b) - 1;
@@ -743,9 +743,9 @@ extern "C" int dfu3d_segments_build(
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
   hipStream_t st = (hipStream_t)stream;
   const int S = V * max_inst;
-  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(256), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a);
+  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(256), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b);
+  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_alloc, dim3(1), dim3(1024), 0, st, S, cnt_a, cnt_b,
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
