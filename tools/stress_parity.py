@@ -35,7 +35,7 @@ for case in range(n_cases):
     V = cams * frames
     vpc = int(rng.choice([d for d in range(1, V + 1) if V % d == 0]))
     lanes = int(rng.integers(1, 4))
-    eng = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=vpc, dense=dense, cap_vox=1 << 18, lanes=lanes)
+    eng = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=vpc, dense=dense, cap_vox=1 << 18, pool_per_view=1 << 18, lanes=lanes)
     rows, status = eng.run(b)
     exp, _ = _oracle_rows(scenes, p, dense)
     try:
