@@ -87,6 +87,95 @@ def cpu_baseline(scenes_cpu, params, dense, max_seconds=18.0):
     return done / dt, done, dt
 
 
+def _cpu_worker(go, barrier, tasks, done):
+    """Forked before the GPU is touched; sleeps until the timed GPU region is over, then runs the oracle on one
+    frame read from shared memory, together with its siblings (all-cores CPU figure)."""
+    try:
+        go.wait()
+        t = tasks.get()
+        if t is None:
+            return
+        from multiprocessing import shared_memory, resource_tracker
+        import torch as _t
+        _t.set_num_threads(1)
+        from oracle import penet_oracle as O
+        shm = shared_memory.SharedMemory(name=t["shm"])
+        try:
+            resource_tracker.unregister(shm._name, "shared_memory")
+        except Exception:
+            pass
+        v = lambda key, shape, dt: np.ndarray(shape, dt, buffer=shm.buf, offset=t["off"][key])
+        pts = v("points", t["n_pts"], np.float32).reshape(-1, 4)
+        depth = v("depth", (CAMS, H, W), np.float32)
+        masks = v("masks", (CAMS, MAX_INST, H, W), np.uint8)
+        op = O.Params()
+        barrier.wait(timeout=120)
+        t0 = time.time()
+        for c in range(CAMS):
+            P2, R0, V2C = t["calib"][c]
+            oc = O.Calibration({"P2": P2, "R0": R0, "Tr_velo2cam": V2C})
+            lid, _ = O.fov_filter(pts, oc, t["fov_hw"])
+            n = int(t["n_inst"][c])
+            d = depth[c].copy() if t["dense"] else np.zeros((H, W), np.float32)
+            O.depth2pointsrgbpm(d[:, :, None], None, oc, lid, O.NUSC_CLASSES, masks[c][:n].astype(np.float32),
+                                t["classes"][c][:n], t["boxes"][c][:n], op, plane_key=c, want_points=False)
+        done.put(time.time() - t0)
+        shm.close()
+    except Exception as e:                                   # never break the benchmark
+        done.put("error: %s" % e)
+
+
+def cpu_all_cores_start(nproc):
+    """Fork the idle workers (must happen before the first GPU call of this process)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    st = {"go": ctx.Event(), "barrier": ctx.Barrier(nproc), "tasks": ctx.Queue(), "done": ctx.Queue(), "n": nproc}
+    st["procs"] = [ctx.Process(target=_cpu_worker, args=(st["go"], st["barrier"], st["tasks"], st["done"]), daemon=True)
+                   for _ in range(nproc)]
+    for p_ in st["procs"]:
+        p_.start()
+    return st
+
+
+def cpu_all_cores_run(st, scene_cpu, params, dense):
+    """Every worker runs the oracle on the same frame at the same time -> frames/s of the whole host share."""
+    from multiprocessing import shared_memory
+    n = int(scene_cpu.n_inst.max())
+    arrs = {"points": scene_cpu.points.numpy().astype(np.float32), "depth": scene_cpu.depth.numpy().astype(np.float32),
+            "masks": scene_cpu.masks.numpy().astype(np.uint8)}
+    off, cur = {}, 0
+    for k, a in arrs.items():
+        off[k] = cur
+        cur += (a.nbytes + 4095) // 4096 * 4096
+    shm = shared_memory.SharedMemory(create=True, size=cur)
+    try:
+        for k, a in arrs.items():
+            np.ndarray(a.shape, a.dtype, buffer=shm.buf, offset=off[k])[...] = a
+        task = {"shm": shm.name, "off": off, "n_pts": (arrs["points"].size,), "fov_hw": tuple(params.fov_hw), "dense": dense,
+                "calib": [(c.P2, c.R0, c.V2C) for c in scene_cpu.calibs], "n_inst": scene_cpu.n_inst.numpy(),
+                "classes": scene_cpu.inst_class.numpy(), "boxes": scene_cpu.inst_box.numpy()}
+        for _ in range(st["n"]):
+            st["tasks"].put(task)
+        st["go"].set()
+        res = [st["done"].get(timeout=180) for _ in range(st["n"])]
+    finally:
+        for p_ in st["procs"]:
+            p_.join(timeout=5)
+        shm.close()
+        shm.unlink()
+    if any(isinstance(r, str) for r in res):
+        raise RuntimeError([r for r in res if isinstance(r, str)][0])
+    return st["n"] / max(res), max(res)
+
+
+def cpu_all_cores_cancel(st):
+    for _ in range(st["n"]):
+        st["tasks"].put(None)
+    st["go"].set()
+    for p_ in st["procs"]:
+        p_.join(timeout=5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +192,8 @@ def main():
     ap.add_argument("--graphs", action="store_true",
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2: 3.7k vs 4.7k frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=16,
+                    help="host processes of the all-cores CPU figure (0 = skip; forked before the GPU is initialised)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
                     help="after the timed region, time the same kernels once more with nothing else on the GPU (one stream, "
@@ -115,6 +206,14 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
+
+    cpu_pool = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.cpu_procs > 0
+            and not torch.cuda.is_initialized()):
+        try:
+            cpu_pool = cpu_all_cores_start(min(args.cpu_procs, os.cpu_count() or 1))
+        except Exception as e:                       # the single-thread baseline below does not depend on it
+            log("all-cores CPU baseline disabled: %s" % e)
 
     if args.single_device:
         os.environ["LOCAL_RANK_OVERRIDE"] = "0"
@@ -260,9 +359,21 @@ def main():
             del eng1
         if cpu_scenes is not None and world == 1:
             fps, nf, secs = cpu_baseline(cpu_scenes, params, dense)
+            if cpu_pool is not None:
+                try:
+                    fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)
+                    out["cpu_baseline_all_cores"] = {
+                        "value": round(fps_all, 3), "unit": "frames/s", "cores": cpu_pool["n"], "kind": "port",
+                        "sample": "%d processes, each the same synthetic frame (6 cams) through the oracle at the same time; "
+                                  "slowest %.1fs" % (cpu_pool["n"], t_all)}
+                    cpu_pool = None
+                except Exception as e:
+                    log("all-cores CPU baseline failed: %s" % e)
             out["cpu_baseline"] = {"value": round(fps, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d of the same synthetic frames (6 cams each) through oracle/penet_oracle.py "
                                              "(NumPy + C, 1 thread) in %.1fs; host has %d cores" % (nf, secs, os.cpu_count())}
+        if cpu_pool is not None:
+            cpu_all_cores_cancel(cpu_pool)
         if args.dump:
             with open(args.dump, "w") as f:
                 json.dump(out, f, indent=1)
