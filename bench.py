@@ -208,8 +208,10 @@ def main():
     args = ap.parse_args()
 
     cpu_pool = None
+    under_profiler = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+                      or any(k.upper().startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ))
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.cpu_procs > 0
-            and not torch.cuda.is_initialized()):
+            and not torch.cuda.is_initialized() and not under_profiler):   # a profiler's preload already owns the GPU
         try:
             cpu_pool = cpu_all_cores_start(min(args.cpu_procs, os.cpu_count() or 1))
         except Exception as e:                       # the single-thread baseline below does not depend on it
