@@ -28,6 +28,7 @@ from dfu3d_amd.engine import PseudoBoxEngine  # noqa: E402
 from dfu3d_amd.params import Params        # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0        # what a float4 device copy reaches on this part (MI355X_MICROARCH.md: 79 % of the spec peak)
 H, W, CAMS, MAX_INST, N_PTS = 900, 1600, 6, 8, 34720
 
 
@@ -325,11 +326,13 @@ def main():
                 out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
+                                   "frac_of_copy_peak": round(dom["achieved_GBs"] / HBM_COPY_GBS, 5),
                                    "traffic": pmc_traffic(dom["kernel"], views_per_launch)}
             rf = next((r for r in table if r["kernel"] == "rf_flags"), None)
             if rf is not None:
                 out["radius_filter_roofline"] = {"achieved": rf["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                                  "unit": "GB/s", "frac": round(rf["achieved_GBs"] / HBM_PEAK_GBS, 6),
+                                                 "frac_of_copy_peak": round(rf["achieved_GBs"] / HBM_COPY_GBS, 6),
                                                  "points_per_launch": int(rf_pts / max(n_rf_launch, 1))}
         if kern and world == 1 and args.single_stream:
             # the same kernels with nothing else on the GPU: one stream, all frames in one launch chain.
