@@ -48,3 +48,32 @@ def test_bin_table_geometry_covers_reachable_bins():
     pb = np.floor((ph + 5.0) / p.vsize[2])
     assert g.t_lo <= tb.min() and tb.max() < g.t_lo + g.t_n
     assert g.p_lo <= pb.min() and pb.max() < g.p_lo + g.p_n
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of dfu3d_bin_geom and dfu3d_chain_cfg as a C compiler sees include/dfu3d.h == the ctypes
+    mirrors in dfu3d_amd/_lib.py (a silent drift would corrupt every dfu3d_pseudo_boxes call)."""
+    import ctypes
+    import os
+    import subprocess
+    from dfu3d_amd import _build, _lib
+    fields_geom = [f[0] for f in _lib.BinGeom._fields_]
+    fields_cfg = [f[0] for f in _lib.ChainCfg._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dfu3d.h"', 'int main(void) {',
+           'printf("%zu\\n", sizeof(dfu3d_bin_geom));', 'printf("%zu\\n", sizeof(dfu3d_chain_cfg));']
+    src += ['printf("%%zu\\n", offsetof(dfu3d_bin_geom, %s));' % f for f in fields_geom]
+    src += ['printf("%%zu\\n", offsetof(dfu3d_chain_cfg, %s));' % f for f in fields_cfg]
+    src += ['return 0; }']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I", _build.INCLUDE, str(c), "-o", exe])
+    vals = [int(v) for v in subprocess.check_output([exe]).decode().split()]
+    assert vals[0] == ctypes.sizeof(_lib.BinGeom) and vals[1] == ctypes.sizeof(_lib.ChainCfg)
+    k = 2
+    for f in fields_geom:
+        assert vals[k] == getattr(_lib.BinGeom, f).offset, f
+        k += 1
+    for f in fields_cfg:
+        assert vals[k] == getattr(_lib.ChainCfg, f).offset, f
+        k += 1
