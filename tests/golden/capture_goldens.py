@@ -381,74 +381,198 @@ def g7_scene(seed, dense):
                 lidar=lidar, masks=masks, boxes=boxes, depth=depth, image=image, classes=classes)
 
 
+def run_reference(sc, stem, tmp, fov_hw):
+    """vis_utils.py:152-154 (FOV pre-filter with `fov_hw`) + the reference's
+    depth2pointsrgbpm on scene `sc`; records what it hands to Open3D and to
+    GenerateAnns, the label text and the returned virtual points."""
+    cpath = os.path.join(tmp, "%s.txt" % stem)
+    write_calib(cpath, sc["P2"], sc["R0"], sc["V2C"])
+    calib = ref_calib.Calibration(cpath)
+    flag = ref_loader.get_fov_flag(calib.lidar_to_rect(sc["lidar"][:, :3]), fov_hw, calib)
+    lidar = sc["lidar"][flag]
+    label_buf = io.StringIO()
+    label_buf.close = lambda: None
+    ann_inputs = []
+    orig_ann = ref_loader.GenerateAnns
+
+    def rec_ann(cls_name, pts, *a, **k):
+        ann_inputs.append(np.array(pts, np.float64).reshape(-1, 3))
+        return orig_ann(cls_name, pts, *a, **k)
+
+    def fake_open(path, mode="r", *a, **k):
+        if "w" in mode:
+            return label_buf
+        return open(os.path.join(tmp, os.path.basename(path)), mode, *a, **k)
+
+    class _CalibShim:
+        @staticmethod
+        def Calibration(path):
+            return ref_calib.Calibration(os.path.join(tmp, os.path.basename(path)))
+
+    ref_loader.open = fake_open
+    ref_loader.GenerateAnns = rec_ann
+    ref_loader.calibration_kitti = _CalibShim
+    RECORD["v3d"].clear()
+    np.random.seed(0)
+    plane = ref_loader.estimate_plane(lidar[:, :3])
+    np.random.seed(0)                     # same RNG state inside the call
+    depth_in = sc["depth"].copy()
+    boxes = [_Boxes(b) for b in sc["boxes"]]
+    all_points = ref_loader.depth2pointsrgbpm(
+        depth_in, sc["image"], sc["image"], calib, lidar, O.NUSC_CLASSES,
+        torch.from_numpy(sc["masks"]), sc["classes"],
+        np.ones(len(boxes), np.float32), boxes, None, stem)
+    ref_loader.GenerateAnns = orig_ann
+    ref_loader.calibration_kitti = ref_calib
+    del ref_loader.open
+    rows = label_buf.getvalue()
+    out = dict(P2=sc["P2"], R0=sc["R0"], V2C=sc["V2C"],
+               calib_text=np.frombuffer(open(cpath, "rb").read(), np.uint8),
+               lidar_all=sc["lidar"], fov=flag,
+               masks=sc["masks"].astype(np.uint8), boxes=sc["boxes"],
+               depth=sc["depth"][:, :, 0], classes=sc["classes"],
+               plane=plane, all_points=all_points,
+               rows=np.frombuffer(rows.encode(), np.uint8),
+               n_v3d=np.array(len(RECORD["v3d"])), n_ann=np.array(len(ann_inputs)))
+    for i, a in enumerate(RECORD["v3d"]):
+        out["v3d_%d" % i] = a
+    for i, a in enumerate(ann_inputs):
+        out["ann_%d" % i] = a
+    return out, calib, lidar, plane, rows
+
+
 def g7(tmp):
     for tag, seed, dense in (("dense", 700, True), ("dense2", 701, True)):
         sc = g7_scene(seed, dense)
-        cpath = os.path.join(tmp, "%06d.txt" % seed)
-        write_calib(cpath, sc["P2"], sc["R0"], sc["V2C"])
-        calib = ref_calib.Calibration(cpath)
         # vis_utils.py:152-154 FOV pre-filter with the canonical (900,1600)
-        flag = ref_loader.get_fov_flag(calib.lidar_to_rect(sc["lidar"][:, :3]), (900, 1600), calib)
-        lidar = sc["lidar"][flag]
-        label_buf = io.StringIO()
-        label_buf.close = lambda: None
-        ann_inputs = []
-        orig_ann = ref_loader.GenerateAnns
-
-        def rec_ann(cls_name, pts, *a, **k):
-            ann_inputs.append(np.array(pts, np.float64).reshape(-1, 3))
-            return orig_ann(cls_name, pts, *a, **k)
-
-        def fake_open(path, mode="r", *a, **k):
-            if "w" in mode:
-                return label_buf
-            return open(os.path.join(tmp, os.path.basename(path)), mode, *a, **k)
-
-        class _CalibShim:
-            @staticmethod
-            def Calibration(path):
-                return ref_calib.Calibration(os.path.join(tmp, os.path.basename(path)))
-
-        ref_loader.open = fake_open
-        ref_loader.GenerateAnns = rec_ann
-        ref_loader.calibration_kitti = _CalibShim
-        RECORD["v3d"].clear()
-        np.random.seed(0)
-        plane = ref_loader.estimate_plane(lidar[:, :3])
-        np.random.seed(0)                     # same RNG state inside the call
-        depth_in = sc["depth"].copy()
-        boxes = [_Boxes(b) for b in sc["boxes"]]
-        all_points = ref_loader.depth2pointsrgbpm(
-            depth_in, sc["image"], sc["image"], calib, lidar, O.NUSC_CLASSES,
-            torch.from_numpy(sc["masks"]), sc["classes"],
-            np.ones(len(boxes), np.float32), boxes, None, "%06d" % seed)
-        ref_loader.GenerateAnns = orig_ann
-        ref_loader.calibration_kitti = ref_calib
-        del ref_loader.open
-        rows = label_buf.getvalue()
-        out = dict(P2=sc["P2"], R0=sc["R0"], V2C=sc["V2C"],
-                   calib_text=np.frombuffer(open(cpath, "rb").read(), np.uint8),
-                   lidar_all=sc["lidar"], fov=flag,
-                   masks=sc["masks"].astype(np.uint8), boxes=sc["boxes"],
-                   depth=sc["depth"][:, :, 0], classes=sc["classes"],
-                   plane=plane, all_points=all_points,
-                   rows=np.frombuffer(rows.encode(), np.uint8),
-                   n_v3d=np.array(len(RECORD["v3d"])), n_ann=np.array(len(ann_inputs)))
-        for i, a in enumerate(RECORD["v3d"]):
-            out["v3d_%d" % i] = a
-        for i, a in enumerate(ann_inputs):
-            out["ann_%d" % i] = a
+        out, _, _, _, rows = run_reference(sc, "%06d" % seed, tmp, (900, 1600))
         np.savez_compressed(os.path.join(HERE, "g7_%s.npz" % tag), **out)
         print(tag, "rows:\n" + rows)
 
 
+# ---------------------------------------------------------------- G3 label inheritance (hazards H3 / H11)
+def plant_pixel(calib, rng, u_lo, u_hi, v_lo, v_hi, d_lo, d_hi, fov_hw):
+    """A float32 LiDAR point whose float32 projection (the reference's lidar_to_img)
+    lands in [u_lo,u_hi) x [v_lo,v_hi) and passes the FOV pre-filter of `fov_hw`."""
+    for _ in range(2000):
+        u, v, d = rng.uniform(u_lo, u_hi), rng.uniform(v_lo, v_hi), rng.uniform(d_lo, d_hi)
+        p = calib.rect_to_lidar(calib.img_to_rect(np.array([u]), np.array([v]), np.array([d])))
+        p32 = p.astype(np.float32)
+        img, _ = calib.lidar_to_img(p32)
+        ok = ref_loader.get_fov_flag(calib.lidar_to_rect(p32), fov_hw, calib)[0]
+        if ok and u_lo <= img[0, 0] < u_hi and v_lo <= img[0, 1] < v_hi:
+            return p32[0]
+    raise RuntimeError("could not plant a point")
+
+
+def g3_scene(kind):
+    """Two vehicles + ground; `kind`:
+      'crop'   -- the shipped size mix (hazard H11): KITTI-like intrinsics, FOV pre-filter and
+                  depth on the [:352,:1216] crop (vis_utils.py:147,153,161), masks and the bounds
+                  test on the hard-coded 1600x900 canvas (my_loader.py:526); points are planted
+                  whose pixel ROUNDS to column 1216 / row 352 -- outside the crop, inside the
+                  bounds, looked up in the mask there;
+      'border' -- canonical 900x1600 everywhere with points planted at u in [1599.5,1600) and
+                  v in [899.5,900): they pass the unrounded FOV test, round to 1600 / 900 and fail
+                  the bounds test, so K < n_ag and every later row inherits the label of the
+                  NEXT in-bounds pixel (hazard H3)."""
+    crop = kind == "crop"
+    rng = np.random.default_rng(310 if crop else 311)
+    H, W = 900, 1600
+    fov_hw = (352, 1216) if crop else (900, 1600)
+    P2, R0, V2C = make_calib(rng, 0.0, 0.0)
+    if crop:
+        P2[0, 0] = P2[1, 1] = 721.5377
+        P2[0, 2], P2[1, 2] = 609.5593, 172.854
+    calib = ref_calib.Calibration({"P2": P2.astype(np.float32), "R0": R0.astype(np.float32),
+                                   "Tr_velo2cam": V2C.astype(np.float32), "P3": P2.astype(np.float32)})
+    n_g = 1800
+    ang = rng.uniform(-0.75, 0.75, n_g)
+    rad = rng.uniform(3.0, 60.0, n_g)
+    ground = np.stack([rad * np.cos(ang), rad * np.sin(ang), -1.84 + rng.normal(0, 0.02, n_g)], 1)
+    objs = [("Car", 0, (11.0, 1.2), (4.6, 1.9, 1.6), 20.0),
+            ("Bus", 3, (21.0, -4.0), (9.0, 2.8, 2.6), 65.0)]
+    pts, obj_pts = [ground], []
+    for _, _, (cx, cy), (L, Wd, Hh), yaw in objs:
+        m = int(70 * (10.0 / cx) ** 1.2) + 12
+        e = lshape(rng, cx, cy, L, Wd, yaw, m, 0.015)
+        z = rng.uniform(-1.7, -1.84 + Hh, m)
+        p = np.concatenate([e, z[:, None]], 1)
+        obj_pts.append(p)
+        pts.append(p)
+    fh, fw = fov_hw
+    planted = []
+    for _ in range(6):          # right border: rounds to column fw
+        planted.append(plant_pixel(calib, rng, fw - 0.5, fw, 40.0, fh - 40.0, 4.0, 18.0, fov_hw))
+    for _ in range(6):          # bottom border: rounds to row fh (near, so that it is above the ground plane)
+        planted.append(plant_pixel(calib, rng, 200.0, fw - 200.0, fh - 0.5, fh, 1.6, 3.2, fov_hw))
+    planted = np.stack(planted).astype(np.float64)
+    lidar = np.concatenate(pts + [planted]).astype(np.float32)
+    lidar = lidar[rng.permutation(lidar.shape[0])]
+    lidar = np.concatenate([lidar, rng.uniform(0, 255, (lidar.shape[0], 1)).astype(np.float32)], 1)
+    masks = np.zeros((len(objs), H, W), np.float32)
+    boxes = np.zeros((len(objs), 4), np.float32)
+    dh, dw = fov_hw
+    depth = np.zeros((dh, dw, 1), np.float32)
+    for k, p in enumerate(obj_pts):
+        img, dep = calib.lidar_to_img(p.astype(np.float32))
+        x0, y0 = np.floor(img.min(0)).astype(int) - 3
+        x1, y1 = np.ceil(img.max(0)).astype(int) + 3
+        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, W - 1), min(y1, H - 1)
+        masks[k, y0:y1 + 1, x0:x1 + 1] = 1.0
+        boxes[k] = (x0, y0, x1, y1)
+        xa, ya, xb, yb = x0, y0, min(x1, dw - 1), min(y1, dh - 1)
+        if xb >= xa and yb >= ya:
+            yy, xx = np.mgrid[ya:yb + 1, xa:xb + 1]
+            dd = float(np.median(dep)) + 0.002 * (xx - xa) + rng.normal(0, 0.03, xx.shape)
+            depth[ya:yb + 1, xa:xb + 1, 0] = dd.astype(np.float32)
+    # the masks also cover the border strips the planted points round into
+    masks[0, :, min(fw, W - 1) - 2:min(fw, W - 1) + 3] = 1.0
+    masks[1, min(fh, H - 1) - 2:min(fh, H - 1) + 3, :] = 1.0
+    image = pattern_image(H, W)[:dh, :dw]
+    classes = np.array([o[1] for o in objs], np.int64)
+    return dict(P2=P2.astype(np.float32), R0=R0.astype(np.float32), V2C=V2C.astype(np.float32),
+                lidar=lidar, masks=masks, boxes=boxes, depth=depth, image=image, classes=classes), fov_hw
+
+
+def g3(tmp):
+    for kind in ("crop", "border"):
+        sc, fov_hw = g3_scene(kind)
+        out, calib, lidar, plane, rows = run_reference(sc, "0003%s" % ("10" if kind == "crop" else "11"), tmp, fov_hw)
+        # n_ag / K of my_loader.py:512-527 with the reference's own functions
+        lm = lidar[ref_loader.above_plane(lidar[:, :3], plane)]
+        pts_img, _ = calib.lidar_to_img(lm[:, :3])
+        r = np.round(pts_img)
+        inb = (0 <= r[:, 0]) & (r[:, 0] < 1600) & (0 <= r[:, 1]) & (r[:, 1] < 900)
+        n_ag, K = int(lm.shape[0]), int(min(inb.sum(), lm.shape[0]))
+        beyond_crop = int(((r[:, 0] >= fov_hw[1]) | (r[:, 1] >= fov_hw[0])).sum())
+        print("g3", kind, "n_ag", n_ag, "K", K, "rounded beyond the FOV size", beyond_crop)
+        if kind == "border":
+            assert K < n_ag, "the border scene must be misaligned (hazard H3)"
+            assert (~inb)[: n_ag // 2].any(), "an out-of-bounds row must precede in-bounds rows"
+        else:
+            assert K == n_ag and beyond_crop >= 6
+        out.update(n_ag=np.array(n_ag), K=np.array(K), fov_hw=np.array(fov_hw), beyond=np.array(beyond_crop))
+        np.savez_compressed(os.path.join(HERE, "g3_%s.npz" % kind), **out)
+        print(kind, "rows:\n" + rows)
+
+
 def main():
+    """python capture_goldens.py [g1 g2 g3 g4 g5 g7]   (default: all)"""
     tmp = tempfile.mkdtemp(prefix="dfu3d_gold_")
-    g1(tmp)
-    g2()
-    g4()
-    g5_g6(tmp)
-    g7(tmp)
+    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g7"}
+    if "g1" in want:
+        g1(tmp)
+    if "g2" in want:
+        g2()
+    if "g3" in want:
+        g3(tmp)
+    if "g4" in want:
+        g4()
+    if "g5" in want:
+        g5_g6(tmp)
+    if "g7" in want:
+        g7(tmp)
     print("goldens written to", HERE)
 
 

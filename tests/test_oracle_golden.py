@@ -157,6 +157,59 @@ def test_g6_generate_anns_rows(golden_dir, tmp_path):
     assert n_checked > 20
 
 
+# ---------------------------------------------------------------- G3
+def _check_whole_function(g, res, lidar, check_points=True):
+    """Oracle result `res` against what the reference recorded in fixture `g`:
+    arrays handed to Open3D, arrays handed to GenerateAnns, label rows, virtual points."""
+    v3d = [g["v3d_%d" % i] for i in range(int(g["n_v3d"]))]
+    k = 0
+    for i, cls in enumerate(g["classes"]):
+        name = O.NUSC_CLASSES[int(cls)]
+        lidar_i = lidar[O.above_plane(lidar[:, :3], g["plane"])][:res.dbg["K"]][res.dbg["inst_lidar"][i]][:, :3]
+        if name in O.VEHICLE_CLASSES:
+            assert np.array_equal(v3d[k], lidar_i.astype(np.float64))
+            k += 1
+        np.testing.assert_allclose(res.dbg["inst_pseudo"][i], v3d[k], rtol=1e-12, atol=1e-11)
+        assert res.dbg["inst_pseudo"][i].shape == v3d[k].shape
+        k += 1
+    assert k == len(v3d)
+    for i in range(int(g["n_ann"])):
+        np.testing.assert_allclose(res.dbg["inst_points"][i], g["ann_%d" % i], rtol=1e-12, atol=1e-11)
+    ref_rows = [r.split(" ") for r in bytes(g["rows"]).decode().strip().split("\n")]
+    assert len(res.rows) == len(ref_rows)
+    for r, w in zip(res.rows, ref_rows):
+        assert r.name == w[0]
+        got = O.format_row(r).split(" ")
+        np.testing.assert_allclose(np.array(got[3:], float), np.array(w[3:], float), rtol=1e-9, atol=1e-9)
+    if check_points:
+        assert res.all_points.shape == g["all_points"].shape
+        np.testing.assert_allclose(res.all_points, g["all_points"], rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind", ["crop", "border"])
+def test_g3_label_inheritance(golden_dir, tmp_path, kind):
+    """my_loader.py:517-530 against the reference itself: 'border' is MISALIGNED (K < n_ag,
+    hazard H3: points rounding to column 1600 / row 900 are dropped from the value list only),
+    'crop' is the shipped size mix (FOV filter + depth on [:352,:1216], masks / bounds on
+    900x1600, hazard H11) with pixels that round beyond the crop."""
+    g = _load(golden_dir, "g3_%s.npz" % kind)
+    calib = _calib_from_text(tmp_path, g["calib_text"])
+    fov_hw = tuple(int(x) for x in g["fov_hw"])
+    lidar, flag = O.fov_filter(g["lidar_all"], calib, fov_hw)
+    assert np.array_equal(flag, g["fov"])
+    dh, dw = g["depth"].shape
+    assert (dh, dw) == fov_hw
+    res = O.depth2pointsrgbpm(g["depth"].copy().reshape(dh, dw, 1), pattern_image()[:dh, :dw], calib, lidar,
+                              O.NUSC_CLASSES, g["masks"].astype(np.float32), g["classes"], g["boxes"],
+                              O.Params(fov_hw=fov_hw), plane=g["plane"], debug=True)
+    assert res.dbg["n_ag"] == int(g["n_ag"]) and res.dbg["K"] == int(g["K"])
+    if kind == "border":
+        assert res.dbg["K"] < res.dbg["n_ag"]
+    else:
+        assert int(g["beyond"]) >= 6 and res.dbg["K"] == res.dbg["n_ag"]
+    _check_whole_function(g, res, lidar)
+
+
 # ---------------------------------------------------------------- G7
 @pytest.mark.parametrize("tag", ["dense", "dense2"])
 def test_g7_whole_function(golden_dir, tmp_path, tag):
