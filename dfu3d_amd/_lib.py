@@ -37,6 +37,7 @@ class ChainCfg(ctypes.Structure):
         ("V", c_i32), ("H", c_i32), ("W", c_i32), ("max_inst", c_i32), ("cap_n", c_i32), ("cap_vox", c_i32),
         ("cap_rows", c_i32),
         ("dense", c_i32), ("apply_fov", c_i32), ("fov_h", c_i32), ("fov_w", c_i32), ("stat_filter", c_i32),
+        ("bounds_h", c_i32), ("bounds_w", c_i32), ("mask_format", c_i32), ("reserved0", c_i32),
         ("pool_cap", c_i64),
         ("plane_max_hs", c_f64), ("plane_range", c_f64), ("plane_offset", c_f64),
         ("ransac_trials", c_i32), ("nb_points", c_i32),
@@ -57,13 +58,14 @@ SIGNATURES = {
     "dfu3d_fov_filter": (c_i32, [_P, _P, _P, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P]),
     "dfu3d_plane_ransac": (c_i32, [_P, _P, _P, _P, _P, c_i32, c_i32, c_f64, c_f64, c_i32,
                                    c_u64, _P, _P, _P, _P]),
-    "dfu3d_project_label": (c_i32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i32,
-                                    c_i32, c_i32, c_f64, c_f64, _P, _P, _P, _P, _P, _P, _P,
+    "dfu3d_pack_masks": (c_i32, [_P, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, _P]),
+    "dfu3d_project_label": (c_i32, [_P, _P, _P, _P, _P, _P, _P, _P, c_i32, _P, c_i32, c_i32, c_i32,
+                                    c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P]),
     "dfu3d_bin_table_init": (c_i32, [_P, c_i64, _P]),
     "dfu3d_backproject_scratch_words": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
-    "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, _P, c_i32, c_i32, c_i32, c_i32,
+    "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32,
                                       ctypes.POINTER(BinGeom), c_i32, _P, _P, _P, c_i32, _P,
                                       _P, _P, _P, _P, _P, _P, c_i32, _P]),
     "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,

@@ -77,6 +77,8 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
 bool cfg_ok(const dfu3d_chain_cfg *c) {
   return c && c->V > 0 && c->H > 0 && c->W > 0 && c->max_inst > 0 && c->max_inst <= DFU3D_MAX_INST &&
          c->cap_n > 0 && c->cap_vox > 0 && c->cap_rows > 0 && c->pool_cap > 0 && c->n_theta > 0 &&
+         c->bounds_h > 0 && c->bounds_w > 0 && c->bounds_h <= c->H && c->bounds_w <= c->W &&
+         mask_format_ok(c->mask_format, c->max_inst) &&
          (!c->dense || (c->geom.t_n > 0 && c->geom.p_n > 0));
 }
 
@@ -144,7 +146,7 @@ extern "C" int dfu3d_chain_workspace_init(const dfu3d_chain_cfg *cfg, void *work
 
 extern "C" int dfu3d_pseudo_boxes(
     const dfu3d_chain_cfg *cfg, const float *points, const int32_t *pt_off,
-    const int32_t *view_frame, const float *calib, const uint8_t *masks, const int32_t *n_inst,
+    const int32_t *view_frame, const float *calib, const void *masks, const int32_t *n_inst,
     const float *depth, const int64_t *view_key, const double *plane_in, const int32_t *inst_class,
     const int32_t *inst_is_car, const double *inst_r_lidar, const double *inst_r_pseudo,
     const float *inst_box, const float *inst_score, void *workspace, double *rows, int32_t *n_rows,
@@ -181,12 +183,13 @@ extern "C" int dfu3d_pseudo_boxes(
     plane = w.plane;
   }
   // a5/a6
-  CHAIN_TRY(dfu3d_project_label(points, pt_off, view_frame, calib, plane, w.fov_idx, w.n_fov, masks, n_inst,
-                                V, M, cfg->H, cfg->W, cap_n, cfg->plane_offset, cfg->plane_range, w.ag_pt,
+  CHAIN_TRY(dfu3d_project_label(points, pt_off, view_frame, calib, plane, w.fov_idx, w.n_fov, masks,
+                                cfg->mask_format, n_inst, V, M, cfg->H, cfg->W, cfg->bounds_h, cfg->bounds_w,
+                                cap_n, cfg->plane_offset, cfg->plane_range, w.ag_pt,
                                 w.ib_pix, w.n_ag, w.K, w.a_bits, w.a_x, w.a_y, w.a_z, stream));
   // a7-a9
   if (cfg->dense) {
-    CHAIN_TRY(dfu3d_backproject_bin(depth, calib, masks, n_inst, V, M, cfg->H, cfg->W, &cfg->geom, 1, w.table,
+    CHAIN_TRY(dfu3d_backproject_bin(depth, calib, masks, cfg->mask_format, n_inst, V, M, cfg->H, cfg->W, &cfg->geom, 1, w.table,
                                     w.pix_bin, w.blk_cnt, cfg->cap_vox, w.n_vox, w.vox_pix, w.b_bits, w.b_x,
                                     w.b_y, w.b_z, status, DFU3D_BP_ALL, stream));
   } else {

@@ -167,10 +167,42 @@ __device__ __forceinline__ void pixel_to_lidar(const ViewCalib &c, const Recip &
   const double xr = div_reused(((double)u - (double)c.cu) * dd, (double)c.fu, rc.rfu) + (double)c.tx;
   const double yr = div_reused(((double)v - (double)c.cv) * dd, (double)c.fv, rc.rfv) + (double)c.ty;
   const double zr = dd;
+  // [xr,yr,zr,1] @ Minv: the reference's np.dot is a dgemm, i.e. a sequential-k FMA chain
+  // (measured bit-exact: tests/test_oracle_golden.py::test_fp64_chain_matches_numpy_dgemm, golden G1)
   const float *M = c.Minv;   // (4,3) row-major
-  x = ((xr * (double)M[0] + yr * (double)M[3]) + zr * (double)M[6]) + (double)M[9];
-  y = ((xr * (double)M[1] + yr * (double)M[4]) + zr * (double)M[7]) + (double)M[10];
-  z = ((xr * (double)M[2] + yr * (double)M[5]) + zr * (double)M[8]) + (double)M[11];
+  x = fma(zr, (double)M[6], fma(yr, (double)M[3], xr * (double)M[0])) + (double)M[9];
+  y = fma(zr, (double)M[7], fma(yr, (double)M[4], xr * (double)M[1])) + (double)M[10];
+  z = fma(zr, (double)M[8], fma(yr, (double)M[5], xr * (double)M[2])) + (double)M[11];
+}
+// only the coordinate that serves as the voxel key (key_axis 1 = y, 2 = z)
+__device__ __forceinline__ double pixel_to_lidar_axis(const ViewCalib &c, const Recip &rc, int u, int v,
+                                                      float d, int axis) {
+  const double dd = (double)d;
+  const double xr = div_reused(((double)u - (double)c.cu) * dd, (double)c.fu, rc.rfu) + (double)c.tx;
+  const double yr = div_reused(((double)v - (double)c.cv) * dd, (double)c.fv, rc.rfv) + (double)c.ty;
+  const float *M = c.Minv + axis;
+  return fma(dd, (double)M[6], fma(yr, (double)M[3], xr * (double)M[0])) + (double)M[9];
+}
+
+// ---- instance masks -------------------------------------------------------------
+// DFU3D_MASK_BYTES (0): uint8 planes (V, max_inst, H, W), bit j <- plane j > 0 for j < m.
+// 1 / 2 / 4: ONE word of that many bytes per pixel (V, H, W), bit j = instance j -- what
+// dfu3d_pack_masks writes; bits >= m are ignored.
+__host__ __device__ inline bool mask_format_ok(int fmt, int max_inst) {
+  return fmt == 0 || (fmt == 1 && max_inst <= 8) || (fmt == 2 && max_inst <= 16) || fmt == 4;
+}
+__device__ __forceinline__ uint32_t mask_bits_at(const void *masks, int fmt, int v, int max_inst, int m,
+                                                 int HW, int pix) {
+  if (fmt == 0) {
+    const uint8_t *mb = (const uint8_t *)masks + (size_t)v * max_inst * HW + pix;
+    uint32_t bits = 0u;
+    for (int j = 0; j < m; j++) bits |= (mb[(size_t)j * HW] > 0) ? (1u << j) : 0u;
+    return bits;
+  }
+  const size_t o = (size_t)v * HW + pix;
+  const uint32_t w = fmt == 1 ? (uint32_t)((const uint8_t *)masks)[o]
+                   : fmt == 2 ? (uint32_t)((const uint16_t *)masks)[o] : ((const uint32_t *)masks)[o];
+  return m >= 32 ? w : (w & ((1u << m) - 1u));
 }
 
 // monotone map double -> uint64 (total order; -0.0 canonicalised by caller)

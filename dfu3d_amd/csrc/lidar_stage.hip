@@ -359,25 +359,46 @@ __global__ __launch_bounds__(256) void k_label_rows(
     const float4 *__restrict__ pts, const int *__restrict__ pt_off,
     const int *__restrict__ view_frame, const int *__restrict__ ag_pt,
     const int *__restrict__ ib_pix, const int *__restrict__ Kin,
-    const uint8_t *__restrict__ masks, const int *__restrict__ n_inst, int max_inst,
+    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst,
     int HW, int capN, uint32_t *__restrict__ it_bits, double *__restrict__ it_x,
     double *__restrict__ it_y, double *__restrict__ it_z) {
   const int v = blockIdx.y;
   const int K = Kin[v];
   const int p0 = pt_off[view_frame[v]];
-  const int m = n_inst[v];
-  const uint8_t *mb = masks + (size_t)v * max_inst * HW;
+  const int m = min(max(n_inst[v], 0), max_inst);
   for (int t = blockIdx.x * 256 + threadIdx.x; t < K; t += gridDim.x * 256) {   // K is a few hundred rows
     const size_t o = (size_t)v * capN + t;
     const float4 p = pts[p0 + ag_pt[o]];
-    const int pix = ib_pix[o];
-    uint32_t bits = 0u;
-    for (int j = 0; j < m; j++)
-      bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
-    it_bits[o] = bits;
+    it_bits[o] = mask_bits_at(masks, mask_format, v, max_inst, m, HW, ib_pix[o]);
     it_x[o] = (double)p.x;
     it_y[o] = (double)p.y;
     it_z[o] = (double)p.z;
+  }
+}
+
+// uint8 planes (V, max_inst, H, W) -> one word per pixel (V, H, W), bit j = plane j > 0 for j < n_inst[v]
+template <typename WordT>
+__global__ __launch_bounds__(256) void k_pack_masks(const uint8_t *__restrict__ masks,
+                                                    const int *__restrict__ n_inst, int max_inst,
+                                                    int HW, WordT *__restrict__ out) {
+  const int v = blockIdx.y;
+  const int m = min(max(n_inst[v], 0), max_inst);
+  const uint8_t *mb = masks + (size_t)v * max_inst * HW;
+  // 4 pixels per thread: one 32-bit load per plane
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < (HW + 3) / 4; q += gridDim.x * 256) {
+    const int pix = q * 4;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (pix + 4 <= HW && (HW & 3) == 0) {
+      for (int j = 0; j < m; j++) {
+        const uint32_t b4 = *(const uint32_t *)(mb + (size_t)j * HW + pix);
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] |= (((b4 >> (8 * k)) & 0xFFu) != 0u) ? (1u << j) : 0u;
+      }
+    } else {
+      for (int j = 0; j < m; j++)
+        for (int k = 0; k < 4 && pix + k < HW; k++) w[k] |= (mb[(size_t)j * HW + pix + k] > 0) ? (1u << j) : 0u;
+    }
+    for (int k = 0; k < 4 && pix + k < HW; k++) out[(size_t)v * HW + pix + k] = (WordT)w[k];
   }
 }
 
@@ -420,9 +441,9 @@ extern "C" int dfu3d_plane_ransac(const float *points, const int32_t *pt_off,
 extern "C" int dfu3d_project_label(
     const float *points, const int32_t *pt_off, const int32_t *view_frame,
     const float *calib, const double *plane, const int32_t *fov_idx,
-    const int32_t *n_fov, const uint8_t *masks, const int32_t *n_inst, int32_t V,
-    int32_t max_inst, int32_t H, int32_t W, int32_t cap_n, double plane_offset,
-    double xy_range, int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag, int32_t *K,
+    const int32_t *n_fov, const void *masks, int32_t mask_format, const int32_t *n_inst, int32_t V,
+    int32_t max_inst, int32_t H, int32_t W, int32_t bounds_h, int32_t bounds_w, int32_t cap_n,
+    double plane_offset, double xy_range, int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag, int32_t *K,
     uint32_t *it_bits, double *it_x, double *it_y, double *it_z, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!points || !pt_off || !view_frame || !calib || !plane || !fov_idx || !n_fov ||
@@ -430,17 +451,40 @@ extern "C" int dfu3d_project_label(
       !it_y || !it_z)
     return DFU3D_EINVAL;
   if (V <= 0 || cap_n <= 0 || H <= 0 || W <= 0 || max_inst <= 0) return DFU3D_EINVAL;
+  if (bounds_h <= 0 || bounds_w <= 0 || bounds_h > H || bounds_w > W) return DFU3D_EINVAL;
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  if (!mask_format_ok(mask_format, max_inst)) return DFU3D_EINVAL;
   hipLaunchKernelGGL(k_project_rows, dim3(V), dim3(NT), 0, (hipStream_t)stream,
                      (const float4 *)points, pt_off, view_frame,
                      (const ViewCalib *)calib, plane, fov_idx, n_fov, cap_n,
-                     (float)H, (float)W, W, plane_offset, (float)xy_range, ag_pt,
+                     (float)bounds_h, (float)bounds_w, W, plane_offset, (float)xy_range, ag_pt,
                      ib_pix, n_ag, K);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_label_rows, dim3((cap_n + 255) / 256 < 8 ? (cap_n + 255) / 256 : 8, V), dim3(256), 0,
                      (hipStream_t)stream, (const float4 *)points, pt_off, view_frame,
-                     ag_pt, ib_pix, K, masks, n_inst, max_inst, H * W, cap_n, it_bits,
+                     ag_pt, ib_pix, K, masks, mask_format, n_inst, max_inst, H * W, cap_n, it_bits,
                      it_x, it_y, it_z);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_pack_masks(const uint8_t *masks, const int32_t *n_inst, int32_t V, int32_t max_inst,
+                                int32_t H, int32_t W, void *out, int32_t word_bytes, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!masks || !n_inst || !out) return DFU3D_EINVAL;
+  if (V <= 0 || H <= 0 || W <= 0 || max_inst <= 0) return DFU3D_EINVAL;
+  if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  if (word_bytes == 0 || !mask_format_ok(word_bytes, max_inst)) return DFU3D_EINVAL;
+  const int HW = H * W;
+  const int gx = ((HW + 3) / 4 + 255) / 256;
+  const dim3 grid(gx < 2048 ? gx : 2048, V);
+  hipStream_t st = (hipStream_t)stream;
+  if (word_bytes == 1)
+    hipLaunchKernelGGL(k_pack_masks<uint8_t>, grid, dim3(256), 0, st, masks, n_inst, max_inst, HW, (uint8_t *)out);
+  else if (word_bytes == 2)
+    hipLaunchKernelGGL(k_pack_masks<uint16_t>, grid, dim3(256), 0, st, masks, n_inst, max_inst, HW, (uint16_t *)out);
+  else
+    hipLaunchKernelGGL(k_pack_masks<uint32_t>, grid, dim3(256), 0, st, masks, n_inst, max_inst, HW, (uint32_t *)out);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }

@@ -12,23 +12,29 @@
 // are the 100 smallest pixel indices.  Per view a direct-addressed table over
 // the reachable (theta,phi) bins holds {min key, min (key',pixel), count, first
 // pixel, rep pixel}:
-//   P1  per pixel: back-project, bin, store bin id; atomics: count++,
-//       first=min(pix), kmin=min(key), combo=min(key' | pix) where key' is the
-//       order-preserving key cut to its top 64-b bits and b = bits of a pixel
-//       index                                    (100-cap assumed not to bind)
-//   O*  bins whose count exceeded the cap are listed by the 101st arrival and
-//       repaired exactly: their pixel lists are gathered, the 100th smallest
-//       pixel index T is radix-selected, kmin and the representative recomputed
-//       over pix <= T
-//   P3  ONE pass over the bin ids: per 1024-pixel block the pixels that are the
-//       first of their bin, chained over the blocks of a view by a decoupled
-//       look-back scan -> ordered voxel list
-//   P4  per voxel: the representative is the pixel p* of combo if its exact key
-//       equals kmin (p* is the smallest pixel among those whose cut key is
-//       minimal, a superset of the exact arg-mins); otherwise two keys of the
-//       bin differ only below the cut -- the bin's pixels are then scanned
-//       (practically never).  Then xyz + instance bits; table entry reset.
-// P1 streams the (V,H,W) float32 depth with float4 loads, P3 the bin ids.
+//   P1  per pixel: back-project, bin; atomics: count++, first=min(pix),
+//       kmin=min(key), combo=min(key' | pix) where key' is the order-preserving
+//       key cut to its top 64-b bits and b = bits of a pixel index.  The update
+//       that finds first == NOBIN is the bin's first toucher and appends the bin
+//       to the view's (unordered) list of touched bins.  Nothing is written per
+//       pixel: the depth map is the only O(pixels) stream of the stage.
+//   P2  per touched bin: set bit first[bin] in a 1-bit-per-pixel map; check the
+//       representative: the pixel p* of combo is the smallest pixel among those
+//       whose CUT key is minimal, a superset of the exact arg-mins, so it is the
+//       representative iff its exact key equals kmin.  Bins where that fails
+//       (two keys differ only below the cut: practically never) and bins that
+//       saw more than max_points pixels are queued for the exact repair
+//   O*  repair (no-op kernels when the queue is empty): the views concerned are
+//       classified once more in fp64 with the bin id stored per pixel, the
+//       queued bins' pixel lists are gathered, the max_points-th smallest pixel
+//       index T is radix-selected, kmin and the representative recomputed over
+//       pix <= T
+//   P3  one workgroup per view scans the bit map: exclusive popcount prefix per
+//       32-pixel word -> the rank of any first-pixel = the voxel's position in
+//       first-seen order
+//   P4  per touched bin: rank, representative, xyz, instance bits (ONE gather
+//       from a bit-packed mask plane, or max_inst byte gathers), outputs written
+//       at the rank; table entry reset.
 #include "common.hpp"
 
 namespace {
@@ -128,21 +134,24 @@ __device__ __forceinline__ void load4(const float *p, int base, int n, float d[P
 }
 
 // ---- P1 ---------------------------------------------------------------------
-// table update shared by the two classification kernels
+// per-view counters (int32 each, V of every kind, zeroed at the start of a pass together with the bit map)
+struct Counters {
+  unsigned long long *amb_new;   // low 32 bits: undecided pixels listed, high 32 bits: touched bins listed
+  int *n_q, *q_cursor;           // repair queue length, pixel-list cursor of the repair
+};
+
+// table update of the exact (tier-2) classification; the update that finds the bin untouched lists it
 __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key,
-                                             uint32_t b, int v, int max_points, int cap_ovf,
-                                             uint32_t *ovf_bins, int *n_ovf, int pix_bits) {
-#ifdef DFU3D_DBG_NOATOMIC
-  if (pix == -12345) T.cnt[e] = 1;   // experiment: classification cost without table atomics
-  return;
-#endif
-  const uint32_t old = atomicAdd(&T.cnt[e], 1u);
-  atomicMin(&T.first[e], (uint32_t)pix);
+                                             uint32_t b, int v, int cap_vox, uint32_t *touched,
+                                             unsigned long long *amb_new, int pix_bits) {
+  atomicAdd(&T.cnt[e], 1u);
+  const uint32_t oldf = atomicMin(&T.first[e], (uint32_t)pix);
   atomicMin(&T.kmin[e], ordered_key(key));
   atomicMin(&T.combo[e], combo_word(ordered_key(key), (uint32_t)pix, pix_bits));
-  if (old == (uint32_t)max_points) {               // the (cap+1)-th arrival
-    const int slot = atomicAdd(&n_ovf[v], 1);
-    if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
+  if (oldf == NOBIN) {                             // first toucher of the bin
+    const unsigned long long o = atomicAdd(&amb_new[v], 1ull << 32);
+    const uint32_t slot = (uint32_t)(o >> 32);
+    if (slot < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + slot] = b;
   }
 }
 
@@ -203,21 +212,12 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
                                                    int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
   double x, y, z;
-#ifdef DFU3D_DBG_NOBACKPROJ
-  x = (double)d * 0.9; y = (double)(col - 800) * (double)d * 1e-3; z = -1.5 + (double)(450 - row) * (double)d * 1e-3;
-#else
   pixel_to_lidar(c, rc, col, row, d, x, y, z);
-#endif
   if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
   key = (key_axis == 2) ? z : y;
   if (key == 0.0) key = 0.0;
   float rf, th, eps_t, ph, eps_p;
-#ifdef DFU3D_DBG_NOANGLE
-  rf = 10.f; th = 1.6f + 1.3e-4f * (float)row; ph = -0.5f + 7.7e-4f * (float)col; eps_t = 3e-6f; eps_p = 3e-6f;
-  if (x == 1234.5) return AMBIG;
-#else
   if (!angle_estimate(x, y, z, rf, th, eps_t, ph, eps_p)) return AMBIG;
-#endif
   // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
   if (!(rf > fg.r_lo && rf < fg.r_hi)) return AMBIG;
   if (th < fg.theta_min - eps_t) return NOBIN;                    // certainly theta <= theta_min
@@ -241,16 +241,19 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 constexpr int TILE_W = 64, TILE_H = 16;            // 1024 pixels, 256 threads x 4
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
+constexpr int NEW_CAP = WIN_T * WIN_P + PBLK;      // new bins one tile can list: its window + every direct update
+
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     dfu3d_bin_geom g, FastGeom fg, int W, int H, int tiles_x, int key_axis,
-    int64_t E_view, void *table, int64_t E_total, uint32_t *__restrict__ pix_bin, int cap_ovf,
-    uint32_t *__restrict__ ovf_bins, int *__restrict__ n_ovf, uint32_t *__restrict__ amb_list,
-    int *__restrict__ n_amb, int pix_bits) {
+    int64_t E_view, void *table, int64_t E_total, int cap_vox, uint32_t *__restrict__ touched,
+    unsigned long long *__restrict__ amb_new, uint32_t *__restrict__ amb_list, int pix_bits) {
   __shared__ uint32_t s_amb[PBLK];
+  __shared__ uint32_t s_new[NEW_CAP];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
-  __shared__ int s_namb, s_base, s_t0, s_p0;
+  __shared__ int s_namb, s_nnew, s_t0, s_p0;
+  __shared__ unsigned long long s_base;
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int row = ty * TILE_H + (threadIdx.x >> 4);
   const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
-  if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
+  if (threadIdx.x == 0) { s_namb = 0; s_nnew = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
   uint32_t bins[PPT];
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     for (int k = 0; k < PPT; k++) {
       bins[k] = NOBIN;
       keys[k] = 0.0;
+      its[k] = 0; ips[k] = 0;
       if (col + k < W) {
-        its[k] = 0; ips[k] = 0;
         const uint32_t b = pixel_bin_fast(c, rc, g, fg, row, col + k, d[k], key_axis, keys[k],
                                           its[k], ips[k]);
         if (b == AMBIG) {
@@ -288,12 +291,6 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
           if (b != NOBIN) { tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]); }
         }
       }
-    }
-    if (col + PPT <= W) {
-      *(uint4 *)(pix_bin + (size_t)v * HW + base) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
-    } else {
-      for (int k = 0; k < PPT; k++)
-        if (col + k < W) pix_bin[(size_t)v * HW + base + k] = bins[k];
     }
   }
   // window origin: wave minimum first (all lanes), then one LDS atomic per wave -- 256 lanes on two
@@ -306,90 +303,80 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
-#ifdef DFU3D_DBG_BP_NOAGG
-  if (t0 == -12345)
-#endif
   if (inside) {
     // runs of equal bins among the thread's four consecutive pixels are merged first
-    auto commit = [&](uint32_t b, int it, int ip, uint32_t c, uint32_t f, unsigned long long ok,
+    auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
                       unsigned long long cm) {
       const int lt = it - t0, lp = ip - p0;
       if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
         const int w = lt * WIN_P + lp;
-        atomicAdd(&s_cnt[w], c);
+        atomicAdd(&s_cnt[w], cn);
         atomicMin(&s_first[w], f);
         atomicMin(&s_kmin[w], ok);
         atomicMin(&s_combo[w], cm);
       } else {                                                    // outside the window: direct
         const int64_t e = tb0 + b;
-        const uint32_t old = atomicAdd(&T.cnt[e], c);
-        atomicMin(&T.first[e], f);
+        atomicAdd(&T.cnt[e], cn);
+        const uint32_t oldf = atomicMin(&T.first[e], f);
         atomicMin(&T.kmin[e], ok);
         atomicMin(&T.combo[e], cm);
-        const uint32_t mx = (uint32_t)g.max_points_per_voxel;
-        if (old <= mx && old + c > mx) {                          // this add crossed the cap
-          const int slot = atomicAdd(&n_ovf[v], 1);
-          if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
-        }
+        if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;      // first toucher lists the bin
       }
     };
-    uint32_t rb = NOBIN, rc = 0u, rfirst = 0u;
+    uint32_t rb = NOBIN, rcn = 0u, rfirst = 0u;
     unsigned long long rk = ~0ull, rcm = ~0ull;
     int rit = 0, rip = 0;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = bins[k];
       if (b != rb) {
-        if (rb != NOBIN) commit(rb, rit, rip, rc, rfirst, rk, rcm);
-        rb = b; rc = 0u; rk = ~0ull; rcm = ~0ull;
+        if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
+        rb = b; rcn = 0u; rk = ~0ull; rcm = ~0ull;
         rfirst = (uint32_t)(base + k); rit = its[k]; rip = ips[k];
       }
       if (b != NOBIN) {
         const unsigned long long ok = ordered_key(keys[k]);
         const unsigned long long cm = combo_word(ok, (uint32_t)(base + k), pix_bits);
-        rc++;
+        rcn++;
         rk = ok < rk ? ok : rk;
         rcm = cm < rcm ? cm : rcm;
       }
     }
-    if (rb != NOBIN) commit(rb, rit, rip, rc, rfirst, rk, rcm);
+    if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
   }
   __syncthreads();
   // flush the window: one set of global atomics per touched bin
-#ifdef DFU3D_DBG_BP_NOFLUSH
-  if (t0 == -12345)
-#endif
   for (int w = threadIdx.x; w < WIN_T * WIN_P; w += PB) {
     const uint32_t cw = s_cnt[w];
     if (cw == 0u) continue;
     const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
     const int64_t e = tb0 + b;
-    const uint32_t old = atomicAdd(&T.cnt[e], cw);
-    atomicMin(&T.first[e], s_first[w]);
+    atomicAdd(&T.cnt[e], cw);
+    const uint32_t oldf = atomicMin(&T.first[e], s_first[w]);
     atomicMin(&T.kmin[e], s_kmin[w]);
     atomicMin(&T.combo[e], s_combo[w]);
-    const uint32_t mx = (uint32_t)g.max_points_per_voxel;
-    if (old <= mx && old + cw > mx) {                             // this add crossed the cap
-      const int slot = atomicAdd(&n_ovf[v], 1);
-      if (slot < cap_ovf) ovf_bins[(size_t)v * cap_ovf + slot] = b;
-    }
+    if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;
   }
-  const int na = s_namb;
-  if (na == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
   __syncthreads();
-  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + s_base + i] = s_amb[i];
+  const int na = s_namb, nn = s_nnew;
+  if (na == 0 && nn == 0) return;
+  if (threadIdx.x == 0)                                           // one global atomic per block, both lists
+    s_base = atomicAdd(&amb_new[v], (unsigned long long)(uint32_t)na | ((unsigned long long)(uint32_t)nn << 32));
+  __syncthreads();
+  const uint32_t ba = (uint32_t)(s_base & 0xFFFFFFFFull), bn = (uint32_t)(s_base >> 32);
+  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + ba + i] = s_amb[i];
+  for (int i = threadIdx.x; i < nn; i += PB)
+    if (bn + (uint32_t)i < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + bn + i] = s_new[i];
 }
 
 // Tier 2: the undecided pixels, full fp64 classification (pixel_bin).
 __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
-    int HW, int key_axis, int64_t E_view, void *table, int64_t E_total,
-    uint32_t *__restrict__ pix_bin, int cap_ovf, uint32_t *__restrict__ ovf_bins,
-    int *__restrict__ n_ovf, const uint32_t *__restrict__ amb_list, const int *__restrict__ n_amb,
-    uint32_t *__restrict__ status, int pix_bits) {
+    int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, int cap_vox,
+    uint32_t *__restrict__ touched, unsigned long long *__restrict__ amb_new,
+    const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits) {
   const int v = blockIdx.y;
-  const int na = n_amb[v];
+  const int na = (int)(__hip_atomic_load(&amb_new[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull);
   const ViewCalib c = calib[v];
   const Recip rc = make_recip(c);
   const Table T = table_view(table, E_total);
@@ -399,40 +386,158 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const int pix = (int)amb_list[(size_t)v * HW + e];
     double key;
     const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
-    pix_bin[(size_t)v * HW + pix] = b;
-    if (b != NOBIN)
-      commit_pixel(T, tb0 + b, pix, key, b, v, g.max_points_per_voxel, cap_ovf, ovf_bins, n_ovf, pix_bits);
+    if (b != NOBIN) commit_pixel(T, tb0 + b, pix, key, b, v, cap_vox, touched, amb_new, pix_bits);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
 
-// ---- O2: allocate a pixel list per overflow bin ------------------------------
-// rep[e] <- list base, cnt[e] <- OVF_FLAG | 0 (fill cursor), ovf_cnt <- count
-__global__ void k_ovf_alloc(void *table, int64_t E_total, int64_t E_view, int cap_ovf,
-                            const uint32_t *__restrict__ ovf_bins,
-                            const int *__restrict__ n_ovf, int *__restrict__ ovf_cnt,
-                            int *__restrict__ ovf_cursor, int HW,
-                            uint32_t *__restrict__ status) {
+// ---- P2: first-pixel bit map ---------------------------------------------------
+constexpr int MKB = 256;
+__global__ __launch_bounds__(MKB) void k_bp_mark(
+    int64_t E_view, void *table, int64_t E_total, int cap_vox, const uint32_t *__restrict__ touched,
+    const unsigned long long *__restrict__ amb_new, int BW, uint32_t *__restrict__ bitmap,
+    uint32_t *__restrict__ status) {
   const int v = blockIdx.y;
-  const int no = min(n_ovf[v], cap_ovf);
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= no) return;
+  const uint32_t nt_all = (uint32_t)(amb_new[v] >> 32);
+  if (nt_all > (uint32_t)cap_vox && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+  const int nt = (int)min(nt_all, (uint32_t)cap_vox);
   const Table T = table_view(table, E_total);
-  const int64_t e = (int64_t)v * E_view + ovf_bins[(size_t)v * cap_ovf + s];
-  const int c = (int)T.cnt[e];
-  const int off = atomicAdd(&ovf_cursor[v], c);
-  if (off + c > HW) atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);   // cannot happen
-  ovf_cnt[(size_t)v * cap_ovf + s] = c;
-  T.rep[e] = (uint32_t)off;
-  T.cnt[e] = OVF_FLAG;
+  for (int i = blockIdx.x * MKB + threadIdx.x; i < nt; i += gridDim.x * MKB) {
+    const uint32_t f = T.first[(int64_t)v * E_view + touched[(size_t)v * cap_vox + i]];
+    atomicOr(&bitmap[(size_t)v * BW + (f >> 5)], 1u << (f & 31u));
+  }
 }
 
-// ---- O3: gather the pixel indices of overflow bins ---------------------------
+// ---- P3: exclusive popcount prefix of the bit map (one workgroup per view) ------
+constexpr int SCB = 1024;
+__global__ __launch_bounds__(SCB) void k_bp_scan(int BW, const uint32_t *__restrict__ bitmap,
+                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox) {
+  __shared__ int s_w[SCB / 64];
+  const int v = blockIdx.x;
+  int running = 0;
+  for (int w0 = 0; w0 < BW; w0 += SCB) {
+    const int w = w0 + threadIdx.x;
+    const int c = (w < BW) ? __popc(bitmap[(size_t)v * BW + w]) : 0;
+    int tot;
+    const int ex = block_excl_scan<SCB / 64>(c, s_w, tot);
+    if (w < BW) wpre[(size_t)v * BW + w] = (uint32_t)(running + ex);
+    running += tot;
+  }
+  if (threadIdx.x == 0) n_vox[v] = running;                 // bins listed (clamped by k_bp_finalize)
+}
+
+// rank of first-pixel f among the first-pixels of view v = the voxel's place in first-seen order
+__device__ __forceinline__ int first_rank(const uint32_t *bitmap, const uint32_t *wpre, size_t vb, uint32_t f) {
+  return (int)(wpre[vb + (f >> 5)] + (uint32_t)__popc(bitmap[vb + (f >> 5)] & ((1u << (f & 31u)) - 1u)));
+}
+
+struct VoxOut {
+  uint32_t *vox_pix, *it_bits;
+  double *it_x, *it_y, *it_z;
+};
+
+__device__ __forceinline__ void emit_voxel(const VoxOut &o, size_t at, const ViewCalib &c, const Recip &rc,
+                                           const float *depth_v, int W, uint32_t pix, const void *masks,
+                                           int mask_format, int m, int max_inst, int HW, int v) {
+  const int row = (int)pix / W, col = (int)pix - row * W;
+  double x, y, z;
+  pixel_to_lidar(c, rc, col, row, depth_v[pix], x, y, z);
+  o.vox_pix[at] = pix;
+  o.it_bits[at] = masks ? mask_bits_at(masks, mask_format, v, max_inst, m, HW, (int)pix) : 0u;
+  o.it_x[at] = x;
+  o.it_y[at] = y;
+  o.it_z[at] = z;
+}
+
+// ---- P4: per touched bin: rank, representative, outputs, table reset -------------
+constexpr int VXB = 256;
+__global__ __launch_bounds__(VXB) void k_bp_vox(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
+    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
+    int HW, int max_voxels, int max_points, int64_t E_view, void *table, int64_t E_total, int cap_vox,
+    const uint32_t *__restrict__ touched, const unsigned long long *__restrict__ amb_new, int BW,
+    const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ wpre, VoxOut out, int key_axis,
+    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ n_q,
+    uint32_t *__restrict__ status) {
+  const int v = blockIdx.y;
+  const int nt = (int)min((uint32_t)(amb_new[v] >> 32), (uint32_t)cap_vox);
+  if (blockIdx.x * VXB >= nt) return;
+  const Table T = table_view(table, E_total);
+  const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
+  const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
+  const float *dv = depth + (size_t)v * HW;
+  const size_t vb = (size_t)v * BW;
+  for (int i = blockIdx.x * VXB + threadIdx.x; i < nt; i += gridDim.x * VXB) {
+    const uint32_t b = touched[(size_t)v * cap_vox + i];
+    const int64_t e = (int64_t)v * E_view + b;
+    const uint32_t cw = T.cnt[e];
+    const uint32_t pix = (uint32_t)(T.combo[e] & ((1ull << pix_bits) - 1ull));
+    bool repair = cw > (uint32_t)max_points;       // the cap binds: "first max_points pixels" must be found
+    if (!repair) {
+      const int row = (int)pix / W, col = (int)pix - row * W;
+      double key = pixel_to_lidar_axis(c, rc, col, row, dv[pix], key_axis);
+      if (key == 0.0) key = 0.0;
+      repair = ordered_key(key) != T.kmin[e];      // two keys agree in their top bits but not exactly
+    }
+    if (repair) {                                  // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
+      const int slot = atomicAdd(&n_q[v], 1);
+      if (slot < cap_q) q_bins[(size_t)v * cap_q + slot] = b;
+      else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
+      continue;
+    }
+    const int k = first_rank(bitmap, wpre, vb, T.first[e]);
+    if (k < max_voxels) emit_voxel(out, (size_t)v * cap_vox + k, c, rc, dv, W, pix, masks, mask_format, m, max_inst, HW, v);
+    // leave the table clean for the next pass (rep is only ever written by the repair)
+    T.kmin[e] = ~0ull;
+    T.combo[e] = ~0ull;
+    T.cnt[e] = 0u;
+    T.first[e] = NOBIN;
+  }
+}
+
+// ---- O1: bin id per pixel, exact classification, only for views with a repair queue ----
+__global__ __launch_bounds__(PB) void k_bp_rebin(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W, int HW,
+    int key_axis, const int *__restrict__ n_q, uint32_t *__restrict__ pix_bin) {
+  const int v = blockIdx.y;
+  if (n_q[v] == 0) return;                           // the usual case
+  const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
+  bool rerr = false;
+  for (int pix = blockIdx.x * PB + threadIdx.x; pix < HW; pix += gridDim.x * PB) {
+    double key;
+    pix_bin[(size_t)v * HW + pix] = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
+  }
+}
+
+// ---- O2: allocate a pixel list per queued bin ----------------------------------
+// rep[e] <- list base, cnt[e] <- OVF_FLAG | 0 (fill cursor), q_cnt <- count
+__global__ void k_ovf_alloc(void *table, int64_t E_total, int64_t E_view, int cap_q,
+                            const uint32_t *__restrict__ q_bins,
+                            const int *__restrict__ n_q, int *__restrict__ q_cnt,
+                            int *__restrict__ q_cursor, int HW,
+                            uint32_t *__restrict__ status) {
+  const int v = blockIdx.y;
+  const int no = min(n_q[v], cap_q);
+  const Table T = table_view(table, E_total);
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < no; s += gridDim.x * blockDim.x) {
+    const int64_t e = (int64_t)v * E_view + q_bins[(size_t)v * cap_q + s];
+    const int c = (int)T.cnt[e];
+    const int off = atomicAdd(&q_cursor[v], c);
+    if (off + c > HW) atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);   // cannot happen
+    q_cnt[(size_t)v * cap_q + s] = c;
+    T.rep[e] = (uint32_t)off;
+    T.cnt[e] = OVF_FLAG;
+  }
+}
+
+// ---- O3: gather the pixel indices of queued bins -------------------------------
 __global__ __launch_bounds__(PB) void k_ovf_gather(
     const uint32_t *__restrict__ pix_bin, void *table, int64_t E_total, int64_t E_view,
-    int HW, const int *__restrict__ n_ovf, uint32_t *__restrict__ ovf_list) {
+    int HW, const int *__restrict__ n_q, uint32_t *__restrict__ q_list) {
   const int v = blockIdx.y;
-  if (n_ovf[v] == 0) return;                       // the usual case: a few workgroups per view leave at once
+  if (n_q[v] == 0) return;                         // the usual case: a few workgroups per view leave at once
   const Table T = table_view(table, E_total);
   for (int base = blockIdx.x * PBLK + threadIdx.x * PPT; base < HW; base += gridDim.x * PBLK) {
     for (int k = 0; k < PPT; k++) {
@@ -443,7 +548,7 @@ __global__ __launch_bounds__(PB) void k_ovf_gather(
       const int64_t e = (int64_t)v * E_view + b;
       if (T.cnt[e] & OVF_FLAG) {
         const uint32_t pos = atomicAdd(&T.cnt[e], 1u) & ~OVF_FLAG;
-        ovf_list[(size_t)v * HW + T.rep[e] + pos] = (uint32_t)pix;
+        q_list[(size_t)v * HW + T.rep[e] + pos] = (uint32_t)pix;
       }
     }
   }
@@ -538,156 +643,26 @@ __global__ __launch_bounds__(256) void k_ovf_select(
   }
 }
 
-// ---- P3: ordered voxel list in one pass ----------------------------------------
-// lb[v*nblk + b] = flag << 62 | value: flag 1 = the block's own count, 2 = inclusive
-// prefix (decoupled look-back; blocks of a view are dispatched in order of b).
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
-
-constexpr int EPB = 512;                      // threads per P3 workgroup
-constexpr int EPT = 16;                       // pixels per thread in P3 (four uint4 loads)
-constexpr int EBLK = EPB * EPT;                 // 8192 pixels per block: few look-backs per view
-
-__global__ __launch_bounds__(EPB) void k_bp_emit(
-    int HW, int64_t E_view, void *table, int64_t E_total,
-    const uint32_t *__restrict__ pix_bin, int nblk, unsigned long long *__restrict__ lb,
-    int cap_vox, uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
-    uint32_t *__restrict__ status) {
-  __shared__ int s_w[EPB / 64];
-  __shared__ int s_excl;
-  const int v = blockIdx.y, bk = blockIdx.x;
-  const Table T = table_view(table, E_total);
-  const int64_t tb0 = (int64_t)v * E_view;
-  const int base = bk * EBLK + threadIdx.x * EPT;
-  uint32_t bins[EPT];
-  if (base + EPT <= HW) {
-#pragma unroll
-    for (int g = 0; g < EPT / 4; g++) {
-      const uint4 q = *(const uint4 *)(pix_bin + (size_t)v * HW + base + 4 * g);
-      bins[4 * g] = q.x; bins[4 * g + 1] = q.y; bins[4 * g + 2] = q.z; bins[4 * g + 3] = q.w;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < EPT; k++) bins[k] = (base + k < HW) ? pix_bin[(size_t)v * HW + base + k] : NOBIN;
-  }
-  uint32_t isf = 0u;                            // bit k: pixel base+k is the first of its bin
-#pragma unroll
-  for (int k = 0; k < EPT; k++)
-    if ((bins[k] != NOBIN) && (T.first[tb0 + bins[k]] == (uint32_t)(base + k))) isf |= 1u << k;
-  const int mine = __popc(isf);
-  int tot;
-  const int r_in = block_excl_scan<EPB / 64>(mine, s_w, tot);
-  unsigned long long *my = lb + (size_t)v * nblk;
-  if (threadIdx.x < 64) {                       // first wave: publish, look back, publish
-    const int lane = threadIdx.x;
-    if (lane == 0)
-      __hip_atomic_store(&my[bk], (bk == 0 ? LB_INC : LB_AGG) | (unsigned long long)tot,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    long long excl = 0;
-    int hi = bk - 1;                            // nearest predecessor not yet accounted for
-    while (hi >= 0) {
-      const int j = hi - lane;
-      unsigned long long w = LB_INC;            // lanes before block 0: neutral "inclusive 0"
-      if (j >= 0) {
-        do {
-          w = __hip_atomic_load(&my[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((w >> 62) == 0ull);
-      }
-      const unsigned long long inc = __ballot((w >> 62) == 2ull);
-      const int stop = inc ? (__ffsll((long long)inc) - 1) : 64;      // nearest inclusive prefix
-      long long part = (lane <= stop) ? (long long)(w & LB_VAL) : 0ll;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const int lo = __shfl_xor((int)(part & 0xFFFFFFFFll), m, 64);
-        const int hi32 = __shfl_xor((int)(part >> 32), m, 64);
-        part += ((long long)hi32 << 32) | (unsigned int)lo;
-      }
-      excl += part;
-      if (inc) break;
-      hi -= 64;
-    }
-    if (lane == 0) {
-      if (bk > 0)
-        __hip_atomic_store(&my[bk], LB_INC | (unsigned long long)(excl + tot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      s_excl = (int)excl;
-      if (bk == nblk - 1) {
-        const long long total = excl + tot;
-        n_vox[v] = (int)total;               // all touched bins (clamped in P4)
-        if (total > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
-      }
-    }
-  }
-  __syncthreads();
-  int r = s_excl + r_in;
-#pragma unroll
-  for (int k = 0; k < EPT; k++)
-    if (isf & (1u << k)) {
-      if (r < cap_vox) vox_bin[(size_t)v * cap_vox + r] = bins[k];
-      r++;
-    }
-}
-
-// ---- P4: per voxel output + table reset --------------------------------------
-constexpr int VXB = 1024;                     // threads per P4 workgroup
-constexpr int VXG = 65535;                      // workgroups per view (grid-stride over the voxels)
-__global__ __launch_bounds__(VXB) void k_bp_vox(
+// ---- O5: outputs of the repaired bins ---------------------------------------------
+__global__ __launch_bounds__(256) void k_bp_fix(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
-    const uint8_t *__restrict__ masks, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox,
-    const uint32_t *__restrict__ vox_bin, int *__restrict__ n_vox,
-    uint32_t *__restrict__ vox_pix, uint32_t *__restrict__ it_bits,
-    double *__restrict__ it_x, double *__restrict__ it_y, double *__restrict__ it_z,
-    const uint32_t *__restrict__ pix_bin, int key_axis, int pix_bits) {
+    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
+    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox, int BW,
+    const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ wpre, VoxOut out, int cap_q,
+    const uint32_t *__restrict__ q_bins, const int *__restrict__ n_q) {
   const int v = blockIdx.y;
-  const int ntouched = min(n_vox[v], cap_vox);
-  const int nout = min(ntouched, max_voxels);
-  for (int k = blockIdx.x * VXB + threadIdx.x; k < ntouched; k += gridDim.x * VXB) {
-    const Table T = table_view(table, E_total);
-    const size_t o = (size_t)v * cap_vox + k;
-    const int64_t e = (int64_t)v * E_view + vox_bin[o];
-    if (k < nout) {
-      const ViewCalib c = calib[v];
-      const Recip rc = make_recip(c);
-      const uint32_t cw = T.cnt[e];
-      uint32_t pix = (cw & OVF_FLAG) ? T.rep[e]
-                                     : (uint32_t)(T.combo[e] & ((1ull << pix_bits) - 1ull));
-      int row = (int)pix / W, col = (int)pix - row * W;
-      double x, y, z;
-      pixel_to_lidar(c, rc, col, row, depth[(size_t)v * HW + pix], x, y, z);
-      if (!(cw & OVF_FLAG)) {
-        double key = (key_axis == 2) ? z : y;
-        if (key == 0.0) key = 0.0;
-        if (ordered_key(key) != T.kmin[e]) {
-          // two keys of this bin agree in their top bits but not exactly: find the first
-          // arg-min among the bin's pixels the long way (one thread, practically never)
-          const uint32_t b = vox_bin[o];
-          const unsigned long long km = T.kmin[e];
-          const uint32_t *pb = pix_bin + (size_t)v * HW;
-          for (int p2 = 0; p2 < HW; p2++) {
-            if (pb[p2] != b) continue;
-            if (ordered_key(pixel_key(c, rc, W, p2, depth[(size_t)v * HW + p2], key_axis)) == km) {
-              pix = (uint32_t)p2;
-              break;
-            }
-          }
-          row = (int)pix / W; col = (int)pix - row * W;
-          pixel_to_lidar(c, rc, col, row, depth[(size_t)v * HW + pix], x, y, z);
-        }
-      }
-      uint32_t bits = 0u;
-      if (masks) {
-        const int m = n_inst[v];
-        const uint8_t *mb = masks + (size_t)v * max_inst * HW;
-        for (int j = 0; j < m; j++)
-          bits |= (mb[(size_t)j * HW + pix] > 0) ? (1u << j) : 0u;
-      }
-      vox_pix[o] = pix;
-      it_bits[o] = bits;
-      it_x[o] = x;
-      it_y[o] = y;
-      it_z[o] = z;
-    }
-    // leave the table clean for the next launch
+  const int no = min(n_q[v], cap_q);
+  if (blockIdx.x * 256 >= no) return;
+  const Table T = table_view(table, E_total);
+  const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
+  const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < no; s += gridDim.x * 256) {
+    const int64_t e = (int64_t)v * E_view + q_bins[(size_t)v * cap_q + s];
+    const int k = first_rank(bitmap, wpre, (size_t)v * BW, T.first[e]);
+    if (k < max_voxels)
+      emit_voxel(out, (size_t)v * cap_vox + k, c, rc, depth + (size_t)v * HW, W, T.rep[e], masks, mask_format, m,
+                 max_inst, HW, v);
     T.kmin[e] = ~0ull;
     T.combo[e] = ~0ull;
     T.cnt[e] = 0u;
@@ -696,14 +671,10 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   }
 }
 
-__global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restrict__ n_vox,
-                              int *__restrict__ n_ovf, int *__restrict__ ovf_cursor) {
+__global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restrict__ n_vox) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  const int n = n_vox[v];
-  n_vox[v] = min(min(n, cap_vox), max_voxels);
-  n_ovf[v] = 0;
-  ovf_cursor[v] = 0;
+  n_vox[v] = min(min(n_vox[v], cap_vox), max_voxels);
 }
 
 // max over n pseudo-random points of |fp32 estimate - fp64 value| / bound, for theta and phi
@@ -784,25 +755,37 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
   return DFU3D_OK;
 }
 
-// Scratch carve-up of blk_cnt (int32):
-//   [0, 2*V*(nblk+1))                     look-back words of k_bp_emit (uint64 per block)
-//   then n_ovf[V], ovf_cursor[V], n_amb[V], ovf_cnt[V*cap_ovf], ovf_bins[V*cap_ovf]
-// and of pix_bin (uint32): [0, V*HW) bin ids, [V*HW, 2*V*HW) overflow pixel
-// lists, [2*V*HW, 2*V*HW + V*cap_vox) voxel bin list.
+// Scratch carve-up.
+// blk_cnt (int32 words): amb_new[V] (uint64: undecided pixels | touched bins), n_q[V], q_cursor[V],
+//   bitmap[V*BW] -- everything up to here is zeroed at the start of a pass --, wpre[V*BW],
+//   q_cnt[V*cap_q], q_bins[V*cap_q]                      (BW = ceil(H*W/32), cap_q: queue_cap)
+// pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
+//   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair,
+//   [2*V*HW, 2*V*HW + V*cap_vox) touched bins.
+static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
+#ifdef DFU3D_DBG_COMBO_KEYBITS
+  (void)HW; (void)max_points;
+  return cap_vox;                          // test builds provoke the repair for a large share of the bins
+#else
+  const int64_t q = HW / (max_points + 1) + 1 + 4096;     // bins over the cap + room for key collisions
+  return (int)(q < cap_vox ? q : cap_vox);
+#endif
+}
+
 extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
                                                    int32_t cap_vox, int32_t max_points,
                                                    int64_t *pix_words, int64_t *blk_words) {
   if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1) return DFU3D_EINVAL;
   const int64_t HW = (int64_t)H * W;
-  const int64_t nblk = (HW + PBLK - 1) / PBLK;
-  const int64_t cap_ovf = HW / (max_points + 1) + 1;
+  const int64_t BW = (HW + 31) / 32;
+  const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
-  if (blk_words) *blk_words = 2 * V * (nblk + 1) + 3 * (int64_t)V + 2 * V * cap_ovf;
+  if (blk_words) *blk_words = 4 * (int64_t)V + 2 * V * BW + 2 * V * cap_q + 8;
   return 0;
 }
 
 extern "C" int dfu3d_backproject_bin(
-    const float *depth, const float *calib, const uint8_t *masks, const int32_t *n_inst,
+    const float *depth, const float *calib, const void *masks, int32_t mask_format, const int32_t *n_inst,
     int32_t V, int32_t max_inst, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
     int32_t key_axis, void *table, uint32_t *pix_bin, int32_t *blk_cnt, int32_t cap_vox,
     int32_t *n_vox, uint32_t *vox_pix, uint32_t *it_bits, double *it_x, double *it_y,
@@ -815,73 +798,85 @@ extern "C" int dfu3d_backproject_bin(
   if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0) return DFU3D_EINVAL;
   if (key_axis != 1 && key_axis != 2) return DFU3D_EINVAL;
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
+  if (masks && !mask_format_ok(mask_format, max_inst)) return DFU3D_EINVAL;
   const int64_t HW64 = (int64_t)H * W;
   if (HW64 >= (1ll << 24)) return DFU3D_ERANGE;     // 24-bit pixel radix select
   if (W % 4) return DFU3D_EINVAL;                    // float4 row loads
   if (geom->max_points_per_voxel < 1) return DFU3D_EINVAL;
+  if (((uintptr_t)blk_cnt & 7u) != 0) return DFU3D_EINVAL;   // 64-bit counters in front
   const int HW = (int)HW64;
-  const int nblk = (HW + PBLK - 1) / PBLK;
-  const int cap_ovf = HW / (geom->max_points_per_voxel + 1) + 1;
+  const int BW = (HW + 31) / 32;
+  const int cap_q = queue_cap(HW64, geom->max_points_per_voxel, cap_vox);
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long *lb = (unsigned long long *)blk_cnt;
-  int *n_ovf = blk_cnt + 2 * (size_t)V * (nblk + 1);
+  unsigned long long *amb_new = (unsigned long long *)blk_cnt;
+  int *n_q = blk_cnt + 2 * (size_t)V;
+  int *q_cursor = n_q + V;
+  uint32_t *bitmap = (uint32_t *)(q_cursor + V);
+  uint32_t *wpre = bitmap + (size_t)V * BW;
+  int *q_cnt = (int *)(wpre + (size_t)V * BW);
+  uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int pix_bits = 1;
   while ((1ll << pix_bits) < HW64) pix_bits++;
-  int *ovf_cursor = n_ovf + V;
-  int *n_amb = ovf_cursor + V;
-  int *ovf_cnt = n_amb + V;
-  uint32_t *ovf_bins = (uint32_t *)(ovf_cnt + (size_t)V * cap_ovf);
-  uint32_t *ovf_list = pix_bin + (size_t)V * HW;
-  uint32_t *vox_bin = pix_bin + 2 * (size_t)V * HW;
+  uint32_t *q_list = pix_bin + (size_t)V * HW;       // undecided pixels first, repair lists later
+  uint32_t *touched = pix_bin + 2 * (size_t)V * HW;
   const ViewCalib *cal = (const ViewCalib *)calib;
+  const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
 
   if (phases & DFU3D_BP_BIN) {
-  // n_ovf | ovf_cursor | n_amb  (3 x V ints); the undecided-pixel lists share the
-  // overflow pixel-list plane (consumed before k_ovf_gather fills it)
-  if (hipMemsetAsync(n_ovf, 0, sizeof(int) * 3 * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
-  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-  hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
-                     make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view,
-                     table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf, ovf_list, n_amb, pix_bits);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
-                     key_axis, E_view, table, E_total, pix_bin, cap_ovf, ovf_bins, n_ovf,
-                     ovf_list, n_amb, status, pix_bits);
-  DFU3D_LAUNCH_CHECK();
+    if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
+                       make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view, table, E_total, cap_vox, touched,
+                       amb_new, q_list, pix_bits);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
+                       key_axis, E_view, table, E_total, cap_vox, touched, amb_new, q_list, status, pix_bits);
+    DFU3D_LAUNCH_CHECK();
   }
-  if (phases & DFU3D_BP_REPAIR) {
-  // exact repair of bins that saw more than max_points points (no-ops otherwise)
-  hipLaunchKernelGGL(k_ovf_alloc, dim3((cap_ovf + 255) / 256, V), dim3(256), 0, st, table,
-                     E_total, E_view, cap_ovf, ovf_bins, n_ovf, ovf_cnt, ovf_cursor, HW,
-                     status);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ovf_gather, dim3(nblk < 128 ? nblk : 128, V), dim3(PB), 0, st, pix_bin, table, E_total,
-                     E_view, HW, n_ovf, ovf_list);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ovf_select, dim3(cap_ovf < 32 ? cap_ovf : 32, V), dim3(256), 0, st, depth, cal, W, HW,
-                     key_axis, geom->max_points_per_voxel, table, E_total, E_view, cap_ovf,
-                     ovf_bins, n_ovf, ovf_cnt, ovf_list);
-  DFU3D_LAUNCH_CHECK();
-  }
-  // DFU3D_BP_REP: nothing to do any more (the representative is resolved per voxel in P4)
-  if (phases & DFU3D_BP_EMIT) {
-  const int nblk_e = (HW + EBLK - 1) / EBLK;
-  if (hipMemsetAsync(lb, 0, sizeof(unsigned long long) * (size_t)V * nblk_e, st) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_bp_emit, dim3(nblk_e, V), dim3(EPB), 0, st, HW, E_view, table, E_total,
-                     pix_bin, nblk_e, lb, cap_vox, vox_bin, n_vox, status);
-  DFU3D_LAUNCH_CHECK();
+  if (phases & DFU3D_BP_MARK) {
+    const int gm = (cap_vox + MKB - 1) / MKB;
+    hipLaunchKernelGGL(k_bp_mark, dim3(gm < 64 ? gm : 64, V), dim3(MKB), 0, st, E_view, table, E_total, cap_vox,
+                       touched, amb_new, BW, bitmap, status);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, bitmap, wpre, n_vox);
+    DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-  hipLaunchKernelGGL(k_bp_vox, dim3((cap_vox + VXB - 1) / VXB < VXG ? (cap_vox + VXB - 1) / VXB : VXG, V), dim3(VXB), 0, st, depth, cal,
-                     masks, n_inst, max_inst, W, HW, geom->max_voxels, E_view, table,
-                     E_total, cap_vox, vox_bin, n_vox, vox_pix, it_bits, it_x, it_y, it_z, pix_bin,
-                     key_axis, pix_bits);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V,
-                     geom->max_voxels, cap_vox, n_vox, n_ovf, ovf_cursor);
-  DFU3D_LAUNCH_CHECK();
+    int gx = (cap_vox + VXB - 1) / VXB;
+    const int gmax = V >= 16 ? 128 : 2048 / V;
+    if (gx > gmax) gx = gmax;
+    hipLaunchKernelGGL(k_bp_vox, dim3(gx, V), dim3(VXB), 0, st, depth, cal, masks, mask_format, n_inst, max_inst, W,
+                       HW, geom->max_voxels, geom->max_points_per_voxel, E_view, table, E_total, cap_vox, touched,
+                       amb_new, BW, bitmap, wpre, out, key_axis, pix_bits, cap_q, q_bins, n_q, status);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_REPAIR) {
+    // exact repair of the queued bins (more than max_points pixels, or a key collision below the cut of the
+    // packed word); every kernel leaves at once for a view whose queue is empty
+    const int nblk = (HW + PB - 1) / PB;
+    hipLaunchKernelGGL(k_bp_rebin, dim3(nblk < 512 ? nblk : 512, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
+                       key_axis, n_q, pix_bin);
+    DFU3D_LAUNCH_CHECK();
+    const int ga = (cap_q + 255) / 256;
+    hipLaunchKernelGGL(k_ovf_alloc, dim3(ga < 16 ? ga : 16, V), dim3(256), 0, st, table, E_total, E_view, cap_q,
+                       q_bins, n_q, q_cnt, q_cursor, HW, status);
+    DFU3D_LAUNCH_CHECK();
+    const int nblk4 = (HW + PBLK - 1) / PBLK;
+    hipLaunchKernelGGL(k_ovf_gather, dim3(nblk4 < 128 ? nblk4 : 128, V), dim3(PB), 0, st, pix_bin, table, E_total,
+                       E_view, HW, n_q, q_list);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ovf_select, dim3(cap_q < 32 ? cap_q : 32, V), dim3(256), 0, st, depth, cal, W, HW,
+                       key_axis, geom->max_points_per_voxel, table, E_total, E_view, cap_q,
+                       q_bins, n_q, q_cnt, q_list);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_fix, dim3(ga < 16 ? ga : 16, V), dim3(256), 0, st, depth, cal, masks, mask_format, n_inst,
+                       max_inst, W, HW, geom->max_voxels, E_view, table, E_total, cap_vox, BW, bitmap, wpre, out, cap_q,
+                       q_bins, n_q);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V, geom->max_voxels, cap_vox, n_vox);
+    DFU3D_LAUNCH_CHECK();
   }
   return DFU3D_OK;
 }

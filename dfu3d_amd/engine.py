@@ -31,7 +31,7 @@ class ViewBatch:
     pt_off: torch.Tensor        # (F+1,) i32
     view_frame: torch.Tensor    # (V,) i32
     calib: torch.Tensor         # (V,48) f32  (Calibration.record())
-    masks: torch.Tensor         # (V,M,H,W) u8
+    masks: torch.Tensor         # (V,M,H,W) u8 planes, or (V,H,W) packed words when mask_format is 1/2/4
     n_inst: torch.Tensor        # (V,) i32
     inst_class: torch.Tensor    # (V,M) i32  index into the 10 nuScenes names
     inst_is_car: torch.Tensor   # (V,M) i32  SEEM name == "Car" (my_loader.py:651)
@@ -44,6 +44,21 @@ class ViewBatch:
     host_view_frame: np.ndarray
     depth: Optional[torch.Tensor] = None   # (V,H,W) f32; None = sparse mode (H20)
     plane: Optional[torch.Tensor] = None   # (V,4) f64; None = fit with RANSAC
+    mask_format: int = 0                   # stages.MASK_BYTES, or the packed word size in bytes (1 / 2 / 4)
+    # identity of every view for the gathered rows: global frame index and camera;
+    # None = frame index inside this batch, camera = view position inside its frame
+    frame_ids: Optional[np.ndarray] = None     # (F,) int64 global index of the batch's frames
+    view_cam: Optional[np.ndarray] = None      # (V,) int   camera of every view
+
+    def pack_masks(self, word_bytes=None):
+        """Replace the uint8 mask planes by ONE packed word per pixel (dfu3d_pack_masks): 1/8 of the
+        bytes, one gather per looked-up pixel.  No-op when already packed."""
+        if self.mask_format != st.MASK_BYTES:
+            return self
+        V, M, H, W = self.masks.shape
+        self.masks = st.pack_masks(self.masks.contiguous(), self.n_inst.contiguous(), V, M, H, W, word_bytes=word_bytes)
+        self.mask_format = self.masks.element_size()
+        return self
 
 
 class PseudoBoxEngine:
@@ -54,9 +69,11 @@ class PseudoBoxEngine:
                  chain: bool = False):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
-        if tuple(params.bounds_hw) != (int(H), int(W)):
-            raise Dfu3dError("params.bounds_hw %s must equal the mask/depth size (%d,%d) "
-                             "(hazard H11: canonical nuScenes = 900x1600 everywhere)"
+        # H, W: the canvas of the masks and the depth maps.  The in-bounds test of my_loader.py:526 is
+        # hard-coded to 1600x900 in the reference whatever the image size (hazard H11); here it is
+        # params.bounds_hw and only has to fit on the canvas.
+        if params.bounds_hw[0] > int(H) or params.bounds_hw[1] > int(W) or min(params.bounds_hw) < 1:
+            raise Dfu3dError("params.bounds_hw %s does not fit on the %dx%d mask / depth canvas"
                              % (tuple(params.bounds_hw), H, W))
         self.p = params
         self.apply_fov = bool(apply_fov)   # False: the caller already FOV-filtered (vis_utils.py:152-154)
@@ -146,6 +163,7 @@ class PseudoBoxEngine:
                 c.V, c.H, c.W, c.max_inst, c.cap_n, c.cap_vox, c.cap_rows = (V, self.H, self.W, self.M, cap_n,
                                                                             self.cap_vox, self.cap_rows)
                 c.dense, c.apply_fov, c.fov_h, c.fov_w = int(self.dense), int(self.apply_fov), int(p.fov_hw[0]), int(p.fov_hw[1])
+                c.bounds_h, c.bounds_w, c.mask_format = int(p.bounds_hw[0]), int(p.bounds_hw[1]), st.MASK_BYTES
                 c.stat_filter, c.pool_cap = int(p.stat_filter), self.pool_cap
                 c.plane_max_hs, c.plane_range, c.plane_offset = p.plane_max_hs, p.plane_range, p.plane_offset
                 c.ransac_trials, c.nb_points = int(p.ransac_trials), int(p.nb_points)
@@ -182,15 +200,15 @@ class PseudoBoxEngine:
         e1.record()
         self._events.append((name, e0, e1))
 
-    def _phased(self, prefix, fn, phases, *a):
+    def _phased(self, prefix, fn, phases, *a, **kw):
         """Issue a multi-kernel stage phase by phase so each kernel is bracketed."""
         if not self.timing:
             allbits = 0
             for _, bit in phases:
                 allbits |= bit
-            return fn(*a, phases=allbits)
+            return fn(*a, phases=allbits, **kw)
         for tag, bit in phases:
-            self._run(prefix + tag, fn, *a, phases=bit)
+            self._run(prefix + tag, fn, *a, phases=bit, **kw)
 
     def timing_summary(self):
         """-> {name: (total_ms, launches)}; synchronises."""
@@ -211,19 +229,39 @@ class PseudoBoxEngine:
 
     # ------------------------------------------------------------------
     def _chunk_chain(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
-        """One dfu3d_pseudo_boxes call for the chunk [v0, v1)."""
-        V = v1 - v0
+        """One dfu3d_pseudo_boxes call for the chunk [v0, v1).  Every operand goes through the same
+        dtype / device / size check as on the stage-by-stage path (a kernel must never see a foreign buffer)."""
+        V, M = v1 - v0, self.M
+        S = V * M
         st._check_frames(b.points, b.pt_off, b.view_frame[v0:v1], V, self.cap_n, b.host_pt_off,
                          b.host_view_frame[v0:v1])
-        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         c = lambda t: t.contiguous()
         f = lambda t: c(t[v0:v1].reshape(-1))
-        keep = [c(b.points), c(b.pt_off), c(b.view_frame[v0:v1]), c(b.calib[v0:v1]), c(b.masks[v0:v1]),
-                c(b.n_inst[v0:v1]), None if b.depth is None or not self.dense else c(b.depth[v0:v1]),
-                c(b.view_key[v0:v1]), None if b.plane is None else c(b.plane[v0:v1]), f(b.inst_class),
-                f(b.inst_is_car), f(b.inst_r_lidar), f(b.inst_r_pseudo), f(b.inst_box), f(b.inst_score)]
-        rc = st._lib.lib().dfu3d_pseudo_boxes(self.chain_cfg, *[ptr(t) for t in keep], ptr(self.chain_ws), ptr(rows),
-                                              ptr(n_rows), ptr(status), st._stream())
+        dense = self.dense and b.depth is not None
+        if self.dense and b.depth is None:
+            raise Dfu3dError("chain=True with a dense engine needs depth (build the engine with dense=False)")
+        F = b.pt_off.numel() - 1
+        T = torch
+        args = [
+            st._chk(c(b.points), "points", T.float32), st._chk(c(b.pt_off), "pt_off", T.int32, numel=F + 1),
+            st._chk(c(b.view_frame[v0:v1]), "view_frame", T.int32, numel=V),
+            st._chk(c(b.calib[v0:v1]), "calib", T.float32, numel=V * st.CALIB_FLOATS),
+            st._chk_masks(c(b.masks[v0:v1]), b.mask_format, V, M, self.H, self.W),
+            st._chk(c(b.n_inst[v0:v1]), "n_inst", T.int32, numel=V),
+            st._chk(c(b.depth[v0:v1]), "depth", T.float32, numel=V * self.H * self.W) if dense else None,
+            st._chk(c(b.view_key[v0:v1]), "view_key", T.int64, numel=V),
+            None if b.plane is None else st._chk(c(b.plane[v0:v1]), "plane", T.float64, numel=V * 4),
+            st._chk(f(b.inst_class), "inst_class", T.int32, numel=S),
+            st._chk(f(b.inst_is_car), "inst_is_car", T.int32, numel=S),
+            st._chk(f(b.inst_r_lidar), "inst_r_lidar", T.float64, numel=S),
+            st._chk(f(b.inst_r_pseudo), "inst_r_pseudo", T.float64, numel=S),
+            st._chk(f(b.inst_box), "inst_box", T.float32, numel=S * 4),
+            st._chk(f(b.inst_score), "inst_score", T.float32, numel=S),
+            st._chk(self.chain_ws, "workspace", T.uint8),
+            st._chk(rows, "rows", T.float64, numel=self.cap_rows * st.ROW_DOUBLES),
+            st._chk(n_rows, "n_rows", T.int32, numel=1), st._chk(status, "status", T.int32, numel=1)]
+        self.chain_cfg.mask_format = int(b.mask_format)
+        rc = st._lib.lib().dfu3d_pseudo_boxes(self.chain_cfg, *args, st._stream())
         st._lib.check(rc, "dfu3d_pseudo_boxes")
 
     def _chunk(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
@@ -255,17 +293,16 @@ class PseudoBoxEngine:
         else:
             plane = b.plane[v0:v1].reshape(-1)
         R("project_label", st.project_label, b.points, b.pt_off, vf, calib, plane, self.fov_idx, self.n_fov, masks,
-                         n_inst, V, M, p.bounds_hw[0], p.bounds_hw[1], cap_n, p.plane_offset,
+                         n_inst, V, M, H, W, cap_n, p.plane_offset,
                          p.plane_range, self.ag_pt, self.ib_pix, self.n_ag, self.K, self.a_bits,
-                         self.a_x, self.a_y, self.a_z)
+                         self.a_x, self.a_y, self.a_z, mask_format=b.mask_format, bounds_hw=p.bounds_hw)
         if self.dense and b.depth is not None:
             self._phased("bp_", st.backproject_bin,
-                         (("bin", st.BP_BIN), ("repair", st.BP_REPAIR),
-                          ("emit", st.BP_EMIT), ("vox", st.BP_VOX)),
+                         (("bin", st.BP_BIN), ("mark", st.BP_MARK), ("vox", st.BP_VOX), ("repair", st.BP_REPAIR)),
                          b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
                          self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
                          self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
-                         self.b_z, status)
+                         self.b_z, status, mask_format=b.mask_format)
         else:
             self.n_vox.zero_()
         self.pool_cursor.zero_()
@@ -322,8 +359,9 @@ class PseudoBoxEngine:
         if V % self.Vc:
             raise Dfu3dError("number of views (%d) must be a multiple of views_per_chunk (%d)"
                              % (V, self.Vc))
-        if tuple(b.masks.shape) != (V, self.M, self.H, self.W):
-            raise Dfu3dError("masks: expected shape %s" % ((V, self.M, self.H, self.W),))
+        want = (V, self.M, self.H, self.W) if b.mask_format == st.MASK_BYTES else (V, self.H, self.W)
+        if tuple(b.masks.shape) != want:
+            raise Dfu3dError("masks: expected shape %s for mask_format %d" % (want, b.mask_format))
         if b.depth is not None and tuple(b.depth.shape) != (V, self.H, self.W):
             raise Dfu3dError("depth: expected shape %s" % ((V, self.H, self.W),))
         nch = V // self.Vc
@@ -412,9 +450,12 @@ class PseudoBoxEngine:
         counts = n_rows.cpu().numpy()                   # the one host sync
         stw = int(np.bitwise_or.reduce(status.cpu().numpy().astype(np.int64)))
         if self.dense and (stw & st.ST_VOX_OVERFLOW):   # a pass that overflowed left its bin table dirty
-            for L in self.lanes:
+            for L in self.lanes:                         # (the chain keeps its own table inside its workspace)
                 with torch.cuda.stream(L.stream):
                     st.bin_table_init(L.table, self.Vc * L.E)
+                    if self.chain:
+                        st._lib.check(st._lib.lib().dfu3d_chain_workspace_init(
+                            L.chain_cfg, L.chain_ws.data_ptr(), st._stream()), "dfu3d_chain_workspace_init")
             torch.cuda.synchronize()
         parts = []
         for c, n in enumerate(counts):

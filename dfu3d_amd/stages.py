@@ -18,7 +18,8 @@ CALIB_FLOATS = 48
 ROW_DOUBLES = 24
 MAX_INST = 32
 
-BP_BIN, BP_REPAIR, BP_REP, BP_EMIT, BP_VOX, BP_ALL = 1, 2, 4, 8, 16, 31
+BP_BIN, BP_MARK, BP_VOX, BP_REPAIR, BP_ALL = 1, 2, 4, 8, 15
+MASK_BYTES = 0
 RF_TILES, RF_FLAGS, RF_COMPACT, RF_RESOLVE, RF_ALL = 1, 2, 4, 8, 15
 
 ST_POOL_OVERFLOW = 1
@@ -133,11 +134,46 @@ def plane_ransac(points, pt_off, view_frame, fov_idx, n_fov, V, cap_n, max_hs, x
     _lib.check(rc, "dfu3d_plane_ransac")
 
 
-def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, masks, n_inst, V,
-                  max_inst, H, W, cap_n, plane_offset, xy_range, ag_pt, ib_pix, n_ag, K,
-                  it_bits, it_x, it_y, it_z):
+def mask_word_bytes(max_inst):
+    """Smallest packed mask word (bytes) that holds max_inst instance bits."""
+    return 1 if max_inst <= 8 else (2 if max_inst <= 16 else 4)
+
+
+_WORD_DTYPE = {1: torch.uint8, 2: torch.int16, 4: torch.int32}
+
+
+def _chk_masks(masks, mask_format, V, max_inst, H, W):
+    """masks: uint8 planes (V,max_inst,H,W) for MASK_BYTES, else packed words (V,H,W) of mask_format bytes."""
     if max_inst < 1 or max_inst > MAX_INST:
         raise Dfu3dError("max_inst must be in [1, %d]" % MAX_INST)
+    if mask_format == MASK_BYTES:
+        return _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W)
+    if mask_format not in _WORD_DTYPE or mask_word_bytes(max_inst) > mask_format:
+        raise Dfu3dError("mask_format %r cannot hold %d instance bits" % (mask_format, max_inst))
+    if masks.data_ptr() % mask_format:
+        raise Dfu3dError("masks: misaligned for %d-byte words" % mask_format)
+    return _chk(masks, "masks (packed)", _WORD_DTYPE[mask_format], numel=V * H * W)
+
+
+def pack_masks(masks, n_inst, V, max_inst, H, W, out=None, word_bytes=None):
+    """uint8 planes (V,max_inst,H,W) -> packed words (V,H,W), bit j = plane j > 0 (dfu3d_pack_masks)."""
+    wb = word_bytes or mask_word_bytes(max_inst)
+    if out is None:
+        out = torch.empty((V, H, W), dtype=_WORD_DTYPE[wb], device=masks.device)
+    rc = _lib.lib().dfu3d_pack_masks(_chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W),
+                                     _chk(n_inst, "n_inst", torch.int32, numel=V), V, max_inst, H, W,
+                                     _chk(out, "out", _WORD_DTYPE[wb], numel=V * H * W), wb, _stream())
+    _lib.check(rc, "dfu3d_pack_masks")
+    return out
+
+
+def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, masks, n_inst, V,
+                  max_inst, H, W, cap_n, plane_offset, xy_range, ag_pt, ib_pix, n_ag, K,
+                  it_bits, it_x, it_y, it_z, mask_format=MASK_BYTES, bounds_hw=None):
+    """H, W: mask canvas; bounds_hw: the in-bounds test of my_loader.py:526 (default: the canvas)."""
+    bh, bw = (H, W) if bounds_hw is None else (int(bounds_hw[0]), int(bounds_hw[1]))
+    if bh > H or bw > W or bh < 1 or bw < 1:
+        raise Dfu3dError("bounds %s must lie inside the mask canvas (%d,%d)" % ((bh, bw), H, W))
     rc = _lib.lib().dfu3d_project_label(
         _chk(points, "points", torch.float32), _chk(pt_off, "pt_off", torch.int32, min_numel=2),
         _chk(view_frame, "view_frame", torch.int32, numel=V),
@@ -145,8 +181,8 @@ def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, mask
         _chk(plane, "plane", torch.float64, numel=V * 4),
         _chk(fov_idx, "fov_idx", torch.int32, numel=V * cap_n),
         _chk(n_fov, "n_fov", torch.int32, numel=V),
-        _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W),
-        _chk(n_inst, "n_inst", torch.int32, numel=V), V, max_inst, H, W, cap_n,
+        _chk_masks(masks, mask_format, V, max_inst, H, W), int(mask_format),
+        _chk(n_inst, "n_inst", torch.int32, numel=V), V, max_inst, H, W, bh, bw, cap_n,
         float(plane_offset), float(xy_range),
         _chk(ag_pt, "ag_pt", torch.int32, numel=V * cap_n),
         _chk(ib_pix, "ib_pix", torch.int32, numel=V * cap_n),
@@ -160,19 +196,19 @@ def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, mask
 
 def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_entries,
                     key_axis, table, pix_bin, blk_cnt, cap_vox, n_vox, vox_pix, it_bits, it_x,
-                    it_y, it_z, status, phases=BP_ALL):
+                    it_y, it_z, status, phases=BP_ALL, mask_format=MASK_BYTES):
     pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel)
-    if table.data_ptr() % 8:
-        raise Dfu3dError("table: must be 8-byte aligned")
-    if pix_bin.data_ptr() % 16 or depth.data_ptr() % 16:
-        raise Dfu3dError("depth / pix_bin: must be 16-byte aligned")
+    if table.data_ptr() % 8 or blk_cnt.data_ptr() % 8:
+        raise Dfu3dError("table / blk_cnt: must be 8-byte aligned")
+    if depth.data_ptr() % 16:
+        raise Dfu3dError("depth: must be 16-byte aligned")
     if W % 4:
         raise Dfu3dError("W must be a multiple of 4 (float4 depth loads)")
-    mp = _chk(masks, "masks", torch.uint8, numel=V * max_inst * H * W) if masks is not None else None
+    mp = _chk_masks(masks, mask_format, V, max_inst, H, W) if masks is not None else None
     ni = _chk(n_inst, "n_inst", torch.int32, numel=V) if n_inst is not None else None
     rc = _lib.lib().dfu3d_backproject_bin(
         _chk(depth, "depth", torch.float32, numel=V * H * W),
-        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS), mp, ni, V, max_inst, H, W,
+        _chk(calib, "calib", torch.float32, numel=V * CALIB_FLOATS), mp, int(mask_format), ni, V, max_inst, H, W,
         ctypes.byref(geom), int(key_axis),
         _chk(table, "table", torch.uint8, min_numel=V * table_entries * TABLE_ENTRY_BYTES),
         _chk(pix_bin, "pix_bin", torch.int32, min_numel=pw),

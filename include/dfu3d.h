@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 100          /* 0.1.0 */
+#define DFU3D_VERSION 110          /* 0.1.1 */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -96,21 +96,33 @@ int dfu3d_plane_ransac(const float *points, const int32_t *pt_off,
                        uint64_t seed, const int64_t *key, int32_t *cand_idx,
                        double *plane, void *stream);
 
+/* Instance masks come in one of two layouts (`mask_format`):
+ *   DFU3D_MASK_BYTES (0): uint8 planes (V, max_inst, H, W) -- np.uint8(mask_image) of
+ *     my_loader.py:523-525, one byte gather per instance and looked-up pixel;
+ *   1 / 2 / 4: ONE word of that many bytes per pixel, (V, H, W), bit j = instance j
+ *     (max_inst <= 8 / 16 / 32) -- one gather per looked-up pixel and 1/8 of the bytes in
+ *     HBM and over PCIe; dfu3d_pack_masks converts, a mask provider can deliver it directly. */
+#define DFU3D_MASK_BYTES 0
+int dfu3d_pack_masks(const uint8_t *masks, const int32_t *n_inst, int32_t V, int32_t max_inst,
+                     int32_t H, int32_t W, void *out, int32_t word_bytes, void *stream);
+
 /* ---- a5/a6: above_plane + point->pixel label inheritance
  * (my_loader.py:471-477, 517-530; hazard H3) ---------------------------------
  * For view v: rows t < K[v] are the first K above-plane FOV points; row t gets
  * the instance bits of the t-th IN-BOUNDS rounded pixel.  Outputs per row:
  * it_bits (bit j = uint8 mask_j > 0), it_x/y/z (fp64 coordinates of the row's
  * point), all at [v*cap_n + t]; n_ag[v], K[v].
- * masks: uint8 (V, max_inst, H, W); n_inst[v] <= max_inst <= 32.
+ * masks: (H, W) images per view in `mask_format`; n_inst[v] <= max_inst <= 32.
+ * bounds_h / bounds_w: the in-bounds test of my_loader.py:526 (hard-coded 900 / 1600 there;
+ * <= H, W -- hazard H11: the mask canvas may be larger than the bounds).
  * ag_pt / ib_pix: int32 scratch (V*cap_n each). */
 int dfu3d_project_label(const float *points, const int32_t *pt_off,
                         const int32_t *view_frame, const float *calib,
                         const double *plane, const int32_t *fov_idx,
-                        const int32_t *n_fov, const uint8_t *masks,
+                        const int32_t *n_fov, const void *masks, int32_t mask_format,
                         const int32_t *n_inst, int32_t V, int32_t max_inst,
-                        int32_t H, int32_t W, int32_t cap_n,
-                        double plane_offset, double xy_range,
+                        int32_t H, int32_t W, int32_t bounds_h, int32_t bounds_w,
+                        int32_t cap_n, double plane_offset, double xy_range,
                         int32_t *ag_pt, int32_t *ib_pix, int32_t *n_ag,
                         int32_t *K, uint32_t *it_bits, double *it_x,
                         double *it_y, double *it_z, void *stream);
@@ -126,17 +138,18 @@ int dfu3d_project_label(const float *points, const int32_t *pt_off,
  * the representative), it_x/y/z (its fp64 LiDAR coordinates), it_bits
  * (instance bits at that pixel; masks may be NULL -> 0).
  * `geom` is a HOST pointer (read at call time).
- * Scratch: pix_bin (uint32 words) and blk_cnt (int32 words) sized by
+ * Scratch: pix_bin (uint32 words) and blk_cnt (int32 words, 8-byte aligned) sized by
  * dfu3d_backproject_scratch_words; table: V*table_entries entries of
  * DFU3D_TABLE_ENTRY_BYTES (uint64 min-key and min-(key|pixel) planes, then
  * uint32 count / first-pixel / representative planes), initialised once with dfu3d_bin_table_init and left clean by every
- * call that returns without DFU3D_ST_VOX_OVERFLOW. */
+ * call that returns without DFU3D_ST_VOX_OVERFLOW.  The depth map is the only
+ * per-pixel stream of the stage: nothing is written per pixel. */
 int dfu3d_bin_table_init(void *table, int64_t table_entries_total, void *stream);
 int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
                                         int32_t cap_vox, int32_t max_points,
                                         int64_t *pix_words, int64_t *blk_words);
 int dfu3d_backproject_bin(const float *depth, const float *calib,
-                          const uint8_t *masks, const int32_t *n_inst,
+                          const void *masks, int32_t mask_format, const int32_t *n_inst,
                           int32_t V, int32_t max_inst, int32_t H, int32_t W,
                           const dfu3d_bin_geom *geom, int32_t key_axis,
                           void *table, uint32_t *pix_bin, int32_t *blk_cnt,
@@ -145,14 +158,13 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
                           double *it_z, uint32_t *status, int32_t phases,
                           void *stream);
 /* `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
- * production; single phases let a caller bracket one kernel with HIP events
+ * production; single phases let a caller bracket one kernel group with HIP events
  * on its stream).  The phases of one pass must be issued in this order. */
-#define DFU3D_BP_BIN 1     /* k_bp_bin: back-project + bin + table atomics      */
-#define DFU3D_BP_REPAIR 2  /* overflow-bin repair (no-op kernels when unused)   */
-#define DFU3D_BP_REP 4     /* reserved (no kernel since 0.1.1)                  */
-#define DFU3D_BP_EMIT 8    /* k_bp_emit: ordered voxel list (one pass)          */
-#define DFU3D_BP_VOX 16    /* k_bp_vox + finalize: outputs, table reset         */
-#define DFU3D_BP_ALL 31
+#define DFU3D_BP_BIN 1     /* k_bp_bin (+ _amb): back-project, bin, table atomics, touched-bin list */
+#define DFU3D_BP_MARK 2    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix   */
+#define DFU3D_BP_VOX 4     /* k_bp_vox: rank, representative, outputs, table reset                 */
+#define DFU3D_BP_REPAIR 8  /* exact repair of bins over the cap / key collisions (no-ops when none) */
+#define DFU3D_BP_ALL 15
 
 /* ---- per-instance point sets (my_loader.py:547-565) ------------------------
  * Builds, for every segment s = v*max_inst + j, the ordered list of LiDAR rows
@@ -324,6 +336,8 @@ int dfu3d_lshape_fit(const double *px, const double *py, const double *pz,
 typedef struct dfu3d_chain_cfg {
   int32_t V, H, W, max_inst, cap_n, cap_vox, cap_rows;
   int32_t dense, apply_fov, fov_h, fov_w, stat_filter;
+  int32_t bounds_h, bounds_w;       /* my_loader.py:526 (<= H, W)           */
+  int32_t mask_format, reserved0;   /* DFU3D_MASK_BYTES or 1 / 2 / 4        */
   int64_t pool_cap;
   double plane_max_hs, plane_range, plane_offset;
   int32_t ransac_trials, nb_points;
@@ -337,7 +351,7 @@ int64_t dfu3d_chain_workspace_bytes(const dfu3d_chain_cfg *cfg);
 int dfu3d_chain_workspace_init(const dfu3d_chain_cfg *cfg, void *workspace, void *stream);
 int dfu3d_pseudo_boxes(const dfu3d_chain_cfg *cfg, const float *points,
                        const int32_t *pt_off, const int32_t *view_frame,
-                       const float *calib, const uint8_t *masks,
+                       const float *calib, const void *masks,
                        const int32_t *n_inst, const float *depth,
                        const int64_t *view_key, const double *plane_in,
                        const int32_t *inst_class, const int32_t *inst_is_car,

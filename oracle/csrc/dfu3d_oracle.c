@@ -56,6 +56,26 @@ void orc_rect_to_img_f32(const float *rect, const float *P2, float *uv,
   }
 }
 
+/* ---- a3/a7: float64 points through a float32-valued (4,m) matrix -----------
+ * calibration_kitti.py:89-102 rect_to_lidar and the float64 path of :104-112:
+ * np.dot([xyz,1] float64, M) is a dgemm; measured here (numpy 2.2 / OpenBLAS
+ * 0.3.29) it is the same sequential-k FMA chain as the sgemm, bit for bit
+ * (tests/test_oracle_golden.py::test_fp64_chain_matches_numpy_dgemm).
+ * M: (4,ld) row-major float32, the first m columns are used.                   */
+void orc_hom_dot_f64(const double *xyz, const float *M, int64_t ld, int64_t m,
+                     double *out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    const double x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    for (int64_t j = 0; j < m; j++) {
+      double acc = x * (double)M[0 * ld + j];
+      acc = fma(y, (double)M[1 * ld + j], acc);
+      acc = fma(z, (double)M[2 * ld + j], acc);
+      acc = fma(1.0, (double)M[3 * ld + j], acc);
+      out[i * m + j] = acc;
+    }
+  }
+}
+
 /* (4,3) = V2C^T (4,3... as (4,3)x(3,3)) product, sequential-k FMA chain, the
  * arithmetic numpy's sgemm performs for np.dot(V2C.T, R0.T)
  * (calibration_kitti.py:110).  V2C is (3,4) row-major, R0 (3,3) row-major.   */

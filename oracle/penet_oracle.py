@@ -158,9 +158,18 @@ class Calibration:
                                          _p(self.M43), _p(out),
                                          ctypes.c_int64(n))
             return out
-        p = pts_lidar.astype(np.float64)
-        M = self.M43.astype(np.float64)
-        return ((p[:, 0:1] * M[0] + p[:, 1:2] * M[1]) + p[:, 2:3] * M[2]) + M[3]
+        return self._hom_dot_f64(pts_lidar, self.M43, 3)
+
+    @staticmethod
+    def _hom_dot_f64(pts, M, m):
+        """[xyz,1] float64 @ float32 (4,ld) matrix, first m columns: the sequential-k
+        FMA chain numpy's dgemm performs (pinned bit-exactly by golden G1)."""
+        p = np.ascontiguousarray(np.asarray(pts, np.float64)[:, :3])
+        M = np.ascontiguousarray(M, np.float32)
+        out = np.empty((p.shape[0], m), np.float64)
+        _lib().orc_hom_dot_f64(_p(p), _p(M), ctypes.c_int64(M.shape[1]), ctypes.c_int64(m), _p(out),
+                               ctypes.c_int64(p.shape[0]))
+        return out
 
     def rect_to_img(self, pts_rect):
         """calibration_kitti.py:114-123 (float32 path)."""
@@ -184,11 +193,8 @@ class Calibration:
                                depth_rect.reshape(-1, 1)), axis=1)
 
     def rect_to_lidar(self, pts_rect):
-        """calibration_kitti.py:89-102 (fp64 points x float32 inverse)."""
-        p = np.asarray(pts_rect, np.float64)
-        M = self.Minv.astype(np.float64)
-        return (((p[:, 0:1] * M[0, :3] + p[:, 1:2] * M[1, :3])
-                 + p[:, 2:3] * M[2, :3]) + M[3, :3])
+        """calibration_kitti.py:89-102 (fp64 points x float32 inverse; dgemm == FMA chain)."""
+        return self._hom_dot_f64(pts_rect, self.Minv, 3)
 
 
 # --------------------------------------------------------------------------

@@ -47,12 +47,12 @@ def test_g1_calibration(golden_dir, tmp_path, tag):
     # fp64 paths
     r64 = c.lidar_to_rect(g[tag + "_pts64"])
     assert r64.dtype == np.float64
-    np.testing.assert_allclose(r64, g[tag + "_rect64"], rtol=1e-13, atol=1e-12)
+    assert np.array_equal(r64, g[tag + "_rect64"])      # dgemm == fp64 FMA chain, bit-exact
     prect = c.img_to_rect(g[tag + "_u"], g[tag + "_v"], g[tag + "_d"])
     assert prect.dtype == np.float64
     assert np.array_equal(prect, g[tag + "_prect"])     # elementwise IEEE ops
     plid = c.rect_to_lidar(prect)
-    np.testing.assert_allclose(plid, g[tag + "_plid"], rtol=1e-13, atol=1e-12)
+    assert np.array_equal(plid, g[tag + "_plid"])       # back-projection bit-exact with the reference
 
 
 def test_fp32_chain_matches_numpy_sgemm():
@@ -73,6 +73,19 @@ def test_fp32_chain_matches_numpy_sgemm():
     with np.errstate(all="ignore"):
         assert np.array_equal(img, (h[:, 0:2].T / hom2[:, 2]).T, equal_nan=True)
     assert np.array_equal(dep, h[:, 2] - P2.T[3, 2])
+
+
+def test_fp64_chain_matches_numpy_dgemm():
+    """[xyz,1] float64 @ float32 matrix: np.dot (dgemm) is the sequential-k FMA chain too."""
+    rng = np.random.default_rng(6)
+    V2C = np.hstack([np.linalg.qr(rng.normal(0, 1, (3, 3)))[0], rng.normal(0, 1, (3, 1))]).astype(np.float32)
+    R0 = (np.eye(3) + rng.normal(0, 0.01, (3, 3))).astype(np.float32)
+    P2 = rng.normal(0, 500, (3, 4)).astype(np.float32)
+    c = O.Calibration({"P2": P2, "R0": R0, "Tr_velo2cam": V2C})
+    pts = rng.normal(0, 40, (20000, 3))
+    hom = np.hstack((pts, np.ones((pts.shape[0], 1), dtype=np.float32)))
+    assert np.array_equal(c.rect_to_lidar(pts), np.dot(hom, c.Minv)[:, 0:3])
+    assert np.array_equal(c.lidar_to_rect(pts), np.dot(hom, np.dot(V2C.T, R0.T)))
 
 
 # ---------------------------------------------------------------- G2
