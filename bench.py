@@ -27,8 +27,7 @@ from dfu3d_amd import synth                # noqa: E402
 from dfu3d_amd.engine import PseudoBoxEngine  # noqa: E402
 from dfu3d_amd.params import Params        # noqa: E402
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-HBM_COPY_GBS = 6290.0        # what a float4 device copy reaches on this part (MI355X_MICROARCH.md: 79 % of the spec peak)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy rate of THIS box is measured below
 H, W, CAMS, MAX_INST, N_PTS = 900, 1600, 6, 8, 34720
 
 
@@ -36,31 +35,82 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_batch(frames, seed0, device, dense, k_boxes):
-    scenes = [synth.make_scene(seed0 + f, H=H, W=W, M=MAX_INST, cams=CAMS, dense=dense,
-                               device=device, k_min=k_boxes[0], k_max=k_boxes[1])
-              for f in range(frames)]
-    # masks/depth are produced on the device already; keep only what the engine needs
-    return scenes
+# engine stage (as bracketed with HIP events) -> the kernels rocprofv3 lists for it
+STAGE_KERNELS = {
+    "fov_filter": ["k_fov_filter"], "plane_ransac": ["k_plane_ransac"],
+    "project_label": ["k_project_rows", "k_label_rows"],
+    "bp_bin": ["k_bp_bin"], "bp_amb": ["k_bp_bin_amb"], "bp_mark": ["k_bp_scan"],
+    "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
+                                          "k_bp_finalize"],
+    "segments_build": ["k_seg_count", "k_seg_alloc", "k_seg_write"],
+    "rf_flags": ["k_radius_flags"], "rf_resolve": ["k_radius_resolve"], "rf_compact": ["k_seg_compact_short"],
+    "ballquery_fuse": ["k_tile_scan", "k_ball_flags", "k_seg_compact"],
+    "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],
+    "lshape_fit": ["k_fit_gather", "k_fit_tiny", "k_fit_medium", "k_fit_big_cost", "k_fit_big_box"],
+}
+RF_STAGE = ("rf_flags", "rf_resolve", "rf_compact")
 
 
-PMC_NAMES = {"bp_bin": "k_bp_bin", "bp_emit": "k_bp_emit", "rf_flags": "k_radius_flags",
-             "fov_filter": "k_fov_filter", "project_label": "k_project_rows"}
+def algorithmic_bytes(c, views, max_inst, mask_word):
+    """Compulsory HBM bytes of every stage for the bracketed passes (SURVEY.md 8d / DESIGN.md 5), from the
+    device-side counts `c` of those passes: per unit figure x units."""
+    px = views * H * W
+    return {
+        "fov_filter": 16 * views * N_PTS + 4 * c["fov_points"],                 # the sweep per view, index list out
+        "plane_ransac": 20 * c["fov_points"] + 32 * views,                     # FOV points once, plane out
+        "project_label": 20 * c["fov_points"] + (28 + (mask_word or max_inst)) * c["label_rows"],
+        "bp_bin": 4 * px,                                                      # the depth map, once
+        "bp_amb": 4 * c.get("amb_pixels", 0),
+        "bp_mark": (4 * 32 * ((W + 63) // 64) * ((H + 15) // 16) + 4 * H * ((W + 63) // 64)) * views,   # bit map in, prefix out
+        "bp_vox": (24 + 4 + (mask_word or max_inst) + 28) * c.get("voxels", 0),     # table entry, depth, mask, voxel record
+        "bp_repair": 0,
+        "segments_build": 4 * (c["label_rows"] + c.get("voxels", 0)) + (24 + 24) * c["pool_points"],
+        "rf_stage": 21 * c["pool_points"],                                     # 16 coords + 4 segment + 1 flag
+        "ballquery_fuse": 12 * c["ball_points"] + c["ball_points"],            # 8d S5: 12(p+l) + p (p+l counted)
+        "range_cluster": 12 * c["instance_points"],                            # 8d S6: 8n + 4n
+        "lshape_fit": 16 * c["instance_points"] + 72 * c["rows"],              # 8d S7
+    }
 
 
-def pmc_traffic(kernel, views_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), scaled
-    linearly when this run's launch covers a different number of views; None if unknown."""
+def measure_copy_rate(dev, nbytes=1 << 30, reps=8):
+    """float4 device-to-device copy on THIS GPU -> GB/s of (read + write) bytes (confirm the peak on the box)."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def pmc_traffic(kernels):
+    """HBM bytes per launch of the given kernels from the newest committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), summed; None if unknown.
+    Valid for the launch geometry named in that file (bench default)."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        with open(files[-1]) as f:
             pm = json.load(f)
-        k = pm["kernels"][PMC_NAMES[kernel]]
-        if k["fetch_bytes"] is None or k["write_bytes"] is None:
-            return None
-        return int((k["fetch_bytes"] + k["write_bytes"]) * views_per_launch / pm["views_per_launch"])
+        tot = 0
+        for k in kernels:
+            hit = [v for name, v in pm["kernels"].items() if name == k or name.startswith(k + "<")]
+            if not hit:
+                continue
+            for v in hit:
+                if v["fetch_bytes"] is None or v["write_bytes"] is None:
+                    return None, None
+                tot += (v["fetch_bytes"] + v["write_bytes"]) * v.get("launches_per_pass", 1)
+        return int(tot), {"file": os.path.basename(files[-1]), "views_per_launch": pm.get("views_per_launch")}
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(scenes_cpu, params, dense, max_seconds=18.0):
@@ -177,36 +227,55 @@ def cpu_all_cores_cancel(st):
         p_.join(timeout=5)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run
+    (the parent has not touched the GPU and never will) and leave with their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] WORLD_SIZE unset: launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--chunk-frames", type=int, default=16, help="frames per kernel-launch chunk")
-    ap.add_argument("--lanes", type=int, default=4, help="concurrent HIP streams (one chunk each)")
+    ap.add_argument("--chunk-frames", type=int, default=0, help="frames per kernel-launch chunk (0 = all frames of the step)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="concurrent HIP streams, one chunk each (default 1: every kernel has the GPU to itself, so the "
+                         "HIP-event durations of the kernel table equal what rocprofv3 reports for the same command)")
     ap.add_argument("--sparse", action="store_true", help="depth off (hazard H20 extension)")
+    ap.add_argument("--byte-masks", action="store_true",
+                    help="instance masks as uint8 planes (V,M,H,W) -- the reference's np.uint8(mask) -- instead of one "
+                         "bit-packed word per pixel (SURVEY.md 8d: 'M/8 mask-bits')")
     ap.add_argument("--boxes", type=int, nargs=2, default=[30, 40], help="objects per scene (min max)")
     ap.add_argument("--no-chain", action="store_true",
                     help="sequence the stage entry points from Python on every step (default: every chunk is ONE C call, "
-                         "dfu3d_pseudo_boxes, except on the kernel-timing steps; same kernels, same results)")
+                         "dfu3d_pseudo_boxes; same kernels, same results)")
     ap.add_argument("--graphs", action="store_true",
-                    help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2: 3.7k vs 4.7k frames/s)")
+                    help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=16,
-                    help="host processes of the all-cores CPU figure (0 = skip; forked before the GPU is initialised)")
+                    help="host processes of the 16-process CPU figure (0 = skip; forked before the GPU is initialised)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="after the timed region, time the same kernels once more with nothing else on the GPU (one stream, "
-                         "all frames in one launch chain) and report them under \"single_stream\"")
     ap.add_argument("--timing-steps", type=int, default=3,
-                    help="steps of the timed region whose kernels are bracketed with HIP events (the brackets "
-                         "split multi-kernel stages into separate calls and cost a few percent)")
-    ap.add_argument("--dump", type=str, default="", help="write per-kernel timing JSON here")
+                    help="extra passes AFTER the timed region in which every stage is bracketed with HIP events on the "
+                         "launch stream (one stream, one chunk)")
+    ap.add_argument("--dump", type=str, default="", help="write the JSON here as well")
     ap.add_argument("--dist-backend", default=None, help="nccl (default on GPUs) | gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # before anything touches the GPU
 
     cpu_pool = None
     under_profiler = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
@@ -216,7 +285,7 @@ def main():
         try:
             cpu_pool = cpu_all_cores_start(min(args.cpu_procs, os.cpu_count() or 1))
         except Exception as e:                       # the single-thread baseline below does not depend on it
-            log("all-cores CPU baseline disabled: %s" % e)
+            log("16-process CPU baseline disabled: %s" % e)
 
     if args.single_device:
         os.environ["LOCAL_RANK_OVERRIDE"] = "0"
@@ -224,14 +293,17 @@ def main():
     if args.single_device:
         local = 0
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+        raise SystemExit("bench.py --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if world > 1 and torch.distributed.get_world_size() != args.gpus:
+        raise SystemExit("process group has %d ranks, expected %d" % (torch.distributed.get_world_size(), args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     dense = not args.sparse
     params = Params()
     frames = args.frames
-    if frames % args.chunk_frames:
+    chunk_frames = args.chunk_frames or frames
+    if frames % chunk_frames:
         raise SystemExit("--frames must be a multiple of --chunk-frames")
 
     t0 = time.time()
@@ -240,7 +312,11 @@ def main():
     my_frames = D.shard_frames(world * frames, rank, world)
     scenes = [synth.make_scene(fid, H=H, W=W, M=MAX_INST, cams=CAMS, dense=dense, device=dev,
                                k_min=args.boxes[0], k_max=args.boxes[1]) for fid in my_frames]
-    batch = synth.to_view_batch(scenes, params, dev, dense=dense)
+    batch = synth.to_view_batch(scenes, params, dev, dense=dense, frame_ids=my_frames)
+    mask_word = 0
+    if not args.byte_masks:
+        batch.pack_masks()                   # the resident input format: one word per pixel, bit j = instance j
+        mask_word = batch.mask_format
     cpu_scenes = None
     if rank == 0 and not args.no_cpu_baseline:
         keep = scenes[:10]
@@ -248,18 +324,24 @@ def main():
                                   s.inst_class, s.inst_box, s.inst_score, s.boxes3d) for s in keep]
     del scenes
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     log("[rank %d] %d frames generated in %.1fs" % (rank, frames, time.time() - t0))
 
-    eng = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=args.chunk_frames * CAMS,
-                          dense=dense, cap_vox=1 << 18, pool_per_view=1 << 17, device=dev,
-                          lanes=args.lanes, graphs=args.graphs, chain=not args.no_chain)
+    views = chunk_frames * CAMS
+
+    def make_engine(lanes, vpc):
+        return PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=vpc, dense=dense, cap_vox=1 << 18,
+                               pool_per_view=1 << 17, device=dev, lanes=lanes, graphs=args.graphs,
+                               chain=not args.no_chain)
+
+    eng = make_engine(args.lanes, views)
 
     def step():
         rows, status = eng.run(batch)
         if status:
             from dfu3d_amd.stages import status_message
             raise SystemExit("device status: " + status_message(status))
-        return D.allgather_rows(rows)
+        return D.allgather_rows(eng.gather_layout(rows, batch))
 
     def barrier():
         if world > 1:
@@ -268,11 +350,9 @@ def main():
 
     for _ in range(args.warmup):
         rows = step()
-    eng.reset_timing()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.timing = (not args.no_kernel_timing) and i < args.timing_steps
         rows = step()
     barrier()
     dt = time.perf_counter() - t0
@@ -282,8 +362,30 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     n_boxes = int(rows.shape[0])
+    if world > 1:                              # every gathered row belongs to a frame of the global batch
+        fr = rows[:, 0].long()
+        assert int(fr.min()) >= 0 and int(fr.max()) < world * frames, "gathered rows carry foreign frame ids"
+        assert torch.unique(fr % world).numel() == world or n_boxes < world, "rows of some rank are missing"
 
-    kern = eng.timing_summary() if not args.no_kernel_timing else {}
+    # ---- kernel table: extra passes after the timed region, one stream, one chunk, every stage bracketed ----
+    kern, counts, tsteps = {}, {}, 0
+    if rank == 0 and not args.no_kernel_timing and args.timing_steps > 0:
+        if args.lanes != 1 or chunk_frames != frames:
+            del eng
+            torch.cuda.empty_cache()
+            eng = make_engine(1, frames * CAMS)
+            eng.run(batch)
+        tsteps = args.timing_steps
+        eng.reset_timing()
+        eng.timing = True
+        for _ in range(tsteps):
+            r_, st_ = eng.run(batch)
+            eng._count("rows", r_.shape[0])
+        eng.timing = False
+        kern = eng.timing_summary()
+        counts = eng.counters()
+    copy_rate = measure_copy_rate(dev) if rank == 0 else None
+
     if rank == 0:
         total_frames = args.steps * frames * world
         value = total_frames / dt
@@ -293,87 +395,73 @@ def main():
             "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1] with depth back-projection %s: %d synthetic frames/GPU/step, "
-                                   "%d-pt sweep, %d cams x %dx%d depth + %d instance masks, %d-%d objects/scene"
-                                   % ("on (dense)" if dense else "off (sparse)", frames, N_PTS, CAMS, W, H,
-                                      MAX_INST, args.boxes[0], args.boxes[1]),
-                       "frames_per_gpu_per_step": frames, "views_per_launch_chunk": args.chunk_frames * CAMS,
-                       "streams": args.lanes,
+                                   "%d-pt sweep, %d cams x %dx%d depth + %d instance masks (%s), %d-%d objects/scene"
+                                   % ("on (dense)" if dense else "off (sparse)", frames, N_PTS, CAMS, W, H, MAX_INST,
+                                      "one bit-packed %d-byte word per pixel" % mask_word if mask_word else "uint8 planes",
+                                      args.boxes[0], args.boxes[1]),
+                       "frames_per_gpu_per_step": frames, "views_per_launch_chunk": views, "streams": args.lanes,
                        "boxes_per_step_all_ranks": n_boxes, "parallelism": "frames sharded x%d" % world},
+            "hbm_copy_GBs_measured": round(copy_rate, 1),
         }
         if kern:
-            # algorithmic bytes per launch (DESIGN.md §kernels / SURVEY.md §8d)
-            views_per_launch = args.chunk_frames * CAMS
-            rf_pts = eng.rf_points_total()
-            n_rf_launch = kern.get("rf_flags", (0, 1))[1]
-            alg = {
-                "bp_bin": views_per_launch * H * W * 4,                  # depth read
-                "bp_emit": views_per_launch * H * W * 4,                 # bin-id read
-                "rf_flags": 21.0 * rf_pts / max(n_rf_launch, 1),          # 16n + 4n + 1n
-                "fov_filter": views_per_launch * N_PTS * 16,
-                "project_label": views_per_launch * N_PTS * 16,
-            }
+            V1 = frames * CAMS                         # views per launch of the bracketed passes
+            c1 = {k: v / tsteps for k, v in counts.items()}      # per pass
+            for k in ("fov_points", "label_rows", "pool_points", "ball_points", "instance_points", "rows"):
+                c1.setdefault(k, 0)
+            alg = algorithmic_bytes(c1, V1, MAX_INST, mask_word)
             table = []
             for name, (ms, n) in sorted(kern.items(), key=lambda kv: -kv[1][0]):
                 avg = ms / n
-                row = {"kernel": name, "total_ms": round(ms, 3), "launches": n, "avg_ms": round(avg, 4)}
-                if name in alg:
+                row = {"stage": name, "kernels": STAGE_KERNELS.get(name, [name]), "total_ms": round(ms, 3),
+                       "launches": n, "avg_ms": round(avg, 4)}
+                if alg.get(name):
                     row["alg_bytes_per_launch"] = int(alg[name])
                     row["achieved_GBs"] = round(alg[name] / (avg * 1e-3) / 1e9, 2)
+                    row["frac_of_peak"] = round(alg[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 table.append(row)
             out["kernels"] = table
-            dom = next((r for r in table if "achieved_GBs" in r), None)
-            if dom is not None:
-                out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["kernel_timing"] = {"how": "HIP events on the launch stream around every stage, %d passes after the timed "
+                                           "region, one stream, %d views per launch" % (tsteps, V1),
+                                    "sum_ms_per_pass": round(sum(ms for ms, _ in kern.values()) / tsteps, 3),
+                                    "counts_per_pass": {k: int(v) for k, v in c1.items()}}
+            dom = table[0]                              # the dominant kernel of the pass
+            if "achieved_GBs" in dom:
+                traffic, tsrc = pmc_traffic(dom["kernels"])
+                out["roofline"] = {"bound": "hbm", "kernel": dom["kernels"][0], "stage": dom["stage"],
+                                   "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
-                                   "frac_of_copy_peak": round(dom["achieved_GBs"] / HBM_COPY_GBS, 5),
-                                   "traffic": pmc_traffic(dom["kernel"], views_per_launch)}
-            rf = next((r for r in table if r["kernel"] == "rf_flags"), None)
-            if rf is not None:
-                out["radius_filter_roofline"] = {"achieved": rf["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                                                 "unit": "GB/s", "frac": round(rf["achieved_GBs"] / HBM_PEAK_GBS, 6),
-                                                 "frac_of_copy_peak": round(rf["achieved_GBs"] / HBM_COPY_GBS, 6),
-                                                 "points_per_launch": int(rf_pts / max(n_rf_launch, 1))}
-        if kern and world == 1 and args.single_stream:
-            # the same kernels with nothing else on the GPU: one stream, all frames in one launch chain.
-            # (Informational, outside the timed region: with several streams the durations above include the
-            # contention that buys the overlap of the single-workgroup tails.)
-            del eng
-            torch.cuda.empty_cache()
-            eng1 = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=frames * CAMS, dense=dense,
-                                   cap_vox=1 << 18, pool_per_view=1 << 17, device=dev, lanes=1)
-            eng1.run(batch)
-            eng1.timing = True
-            eng1.reset_timing()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                eng1.run(batch)
-            torch.cuda.synchronize()
-            ms1 = (time.perf_counter() - t1) / 3 * 1e3
-            k1 = eng1.timing_summary()
-            v1 = frames * CAMS
-            pts1 = eng1.rf_points_total() / max(k1.get("rf_flags", (0, 1))[1], 1)
-            ss = {"ms_per_step": round(ms1, 3), "frames_per_s": round(frames / (ms1 * 1e-3), 1)}
-            for name, byts in (("bp_bin", v1 * H * W * 4), ("bp_emit", v1 * H * W * 4), ("rf_flags", 21.0 * pts1)):
-                if name in k1:
-                    avg = k1[name][0] / k1[name][1]
-                    ss[name] = {"avg_ms": round(avg, 4), "achieved_GBs": round(byts / (avg * 1e-3) / 1e9, 1),
-                                "frac": round(byts / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            out["single_stream"] = ss
-            del eng1
+                                   "frac_of_measured_copy": round(dom["achieved_GBs"] / copy_rate, 5),
+                                   "avg_ms": dom["avg_ms"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                                   "traffic": traffic, "traffic_source": tsrc}
+            rf = [r for r in table if r["stage"] in RF_STAGE]
+            if rf:
+                ms_stage = sum(r["avg_ms"] for r in rf)
+                gbs = alg["rf_stage"] / (ms_stage * 1e-3) / 1e9
+                fl = next((r for r in rf if r["stage"] == "rf_flags"), None)
+                traffic, tsrc = pmc_traffic([k for r in rf for k in r["kernels"]])
+                out["radius_filter_roofline"] = {
+                    "stage": {"kernels": [k for r in rf for k in r["kernels"]], "avg_ms": round(ms_stage, 4),
+                              "alg_bytes_per_launch": int(alg["rf_stage"]), "achieved": round(gbs, 2),
+                              "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / copy_rate, 5),
+                              "traffic": traffic},
+                    "k_radius_flags": None if fl is None else {
+                        "avg_ms": fl["avg_ms"], "achieved": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9, 2),
+                        "frac": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "points_per_launch": int(c1["pool_points"]),
+                    "undecided_after_phase_A": int(c1.get("rf_undecided", 0))}
         if cpu_scenes is not None and world == 1:
             fps, nf, secs = cpu_baseline(cpu_scenes, params, dense)
             if cpu_pool is not None:
                 try:
                     fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)
-                    out["cpu_baseline_all_cores"] = {
+                    out["cpu_baseline_16proc"] = {
                         "value": round(fps_all, 3), "unit": "frames/s", "cores": cpu_pool["n"], "kind": "port",
-                        "sample": "%d processes, each the same synthetic frame (6 cams) through the oracle at the same time; "
-                                  "slowest %.1fs" % (cpu_pool["n"], t_all)}
+                        "sample": "%d processes (the box's CPU share, not all %d host cores), each the same synthetic frame "
+                                  "(6 cams) through the oracle at the same time; slowest %.1fs"
+                                  % (cpu_pool["n"], os.cpu_count(), t_all)}
                     cpu_pool = None
                 except Exception as e:
-                    log("all-cores CPU baseline failed: %s" % e)
+                    log("16-process CPU baseline failed: %s" % e)
             out["cpu_baseline"] = {"value": round(fps, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d of the same synthetic frames (6 cams each) through oracle/penet_oracle.py "
                                              "(NumPy + C, 1 thread) in %.1fs; host has %d cores" % (nf, secs, os.cpu_count())}
@@ -383,6 +471,8 @@ def main():
             with open(args.dump, "w") as f:
                 json.dump(out, f, indent=1)
         print(json.dumps(out), flush=True)
+    elif cpu_pool is not None:
+        cpu_all_cores_cancel(cpu_pool)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

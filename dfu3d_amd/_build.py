@@ -46,5 +46,31 @@ def build(force=False, verbose=False):
     return OUT
 
 
+# Variant builds for tests: the same sources with a debug switch, next to the product library.
+VARIANTS = {
+    # packed min-(key|pixel) word with only 14 key bits: keys collide below the cut all the time, so the exact
+    # repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never taken in the product build) does the work
+    "keybits14": ["-DDFU3D_DBG_COMBO_KEYBITS=14"],
+}
+
+
+def variant_path(name):
+    return os.path.join(CSRC, "libdfu3d_hip_%s.so" % name)
+
+
+def build_variant(name, force=False, verbose=False):
+    out = variant_path(name)
+    deps = (sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
+            + [os.path.join(INCLUDE, "dfu3d.h")])
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + VARIANTS[name] + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -31,6 +31,15 @@ class BinGeom(ctypes.Structure):
     ]
 
 
+class Sizes(ctypes.Structure):
+    """dfu3d_sizes (include/dfu3d.h)."""
+    _fields_ = [
+        ("V", c_i32), ("H", c_i32), ("W", c_i32), ("max_inst", c_i32),
+        ("cap_n", c_i32), ("cap_vox", c_i32), ("cap_rows", c_i32), ("max_points_per_voxel", c_i32),
+        ("pool_cap", c_i64), ("table_entries", c_i64), ("dense", c_i32), ("stat_filter", c_i32),
+    ]
+
+
 class ChainCfg(ctypes.Structure):
     """dfu3d_chain_cfg (include/dfu3d.h)."""
     _fields_ = [
@@ -70,8 +79,8 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P, c_i32, _P]),
     "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,
                                      c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P]),
-    "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P]),
+    "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P, _P, _P,
                                     c_i32, _P]),
     "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,
                                   _P, _P, _P]),
@@ -85,6 +94,10 @@ SIGNATURES = {
     "dfu3d_gt_database": (c_i32, [_P, _P, _P, _P, c_i32, _P, _P, c_i64, _P, _P, _P, _P]),
     "dfu3d_boxes_bev": (c_i32, [_P, c_i32, _P, c_i32, _P, c_i32, _P]),
     "dfu3d_nms_bev": (c_i32, [_P, c_i32, ctypes.c_float, _P, _P, _P, _P]),
+    "dfu3d_nms_normal_bev": (c_i32, [_P, c_i32, ctypes.c_float, _P, _P, _P, _P]),
+    "dfu3d_boxes_bev_paired": (c_i32, [_P, _P, c_i32, _P, c_i32, _P]),
+    "dfu3d_rotate_iou_eval": (c_i32, [_P, c_i32, _P, c_i32, _P, c_i32, _P]),
+    "dfu3d_workspace_bytes": (c_i64, [c_i32, ctypes.POINTER(Sizes)]),
     "dfu3d_chain_workspace_bytes": (c_i64, [ctypes.POINTER(ChainCfg)]),
     "dfu3d_chain_workspace_init": (c_i32, [ctypes.POINTER(ChainCfg), _P, _P]),
     "dfu3d_pseudo_boxes": (c_i32, [ctypes.POINTER(ChainCfg)] + [_P] * 20),
@@ -119,11 +132,13 @@ def lib():
     # streams and device pointers are foreign to our launches: hipErrorInvalid*).
     import torch  # noqa: F401
     path = _build.OUT
-    if not os.path.exists(path):
-        try:
-            _build.build()
-        except Exception as e:  # no silent fallback
+    try:
+        _build.build()          # no-op when the library is newer than every source
+    except Exception as e:      # no silent fallback: a stale library must not be mistaken for the sources
+        if not os.path.exists(path):
             raise Dfu3dError("libdfu3d_hip.so is missing and could not be built: %r" % (e,))
+        if _build.needs_build():
+            raise Dfu3dError("libdfu3d_hip.so is older than its sources and could not be rebuilt: %r" % (e,))
     try:
         L = ctypes.CDLL(path)
     except OSError as e:
@@ -136,6 +151,20 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     _LIB = L
+    return L
+
+
+def load_variant(name):
+    """A test build of the library (dfu3d_amd/_build.py: VARIANTS) with the product's signatures."""
+    import torch  # noqa: F401
+    path = _build.variant_path(name)
+    if not os.path.exists(path):
+        _build.build_variant(name)
+    L = ctypes.CDLL(path)
+    for sym, (res, args) in SIGNATURES.items():
+        fn = getattr(L, sym)
+        fn.restype = res
+        fn.argtypes = args
     return L
 
 

@@ -25,6 +25,7 @@ struct ChainWs {
   int64_t *base_a, *base_b, *base_ab;
   int32_t *cnt_a, *cnt_b, *cnt_all, *cnt_ab, *tile_off, *queue, *stat_enable;
   double *rad_ab, *mean_d;
+  void *shadow;
   int64_t *pool_cursor;
   int64_t table_entries;
 };
@@ -66,7 +67,8 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
   t.base_a = (int64_t *)take(8 * S); t.base_b = (int64_t *)take(8 * S); t.base_ab = (int64_t *)take(8 * 2 * S);
   t.cnt_a = (int32_t *)take(4 * S); t.cnt_b = (int32_t *)take(4 * S); t.cnt_all = (int32_t *)take(4 * S);
   t.cnt_ab = (int32_t *)take(4 * 2 * S); t.tile_off = (int32_t *)take(4 * (2 * S + 1));
-  t.queue = (int32_t *)take(4 * (2 + 2 * P)); t.stat_enable = (int32_t *)take(4 * S);
+  t.queue = (int32_t *)take(4 * (2 + P)); t.stat_enable = (int32_t *)take(4 * S);
+  t.shadow = take(DFU3D_SHADOW_BYTES(P));
   t.rad_ab = (double *)take(8 * 2 * S);
   t.mean_d = c->stat_filter ? (double *)take(8 * P) : nullptr;
   t.pool_cursor = (int64_t *)take(8);
@@ -93,19 +95,6 @@ __global__ void k_all_points(const int *__restrict__ pt_off, const int *__restri
   if (blockIdx.x == 0 && threadIdx.x == 0) n_fov[v] = n;
 }
 
-// the 2S-segment view of (LiDAR lists | pseudo lists) for the joint radius-filter pass
-__global__ void k_join_segments(int S, const long long *__restrict__ base_a, const long long *__restrict__ base_b,
-                                const int *__restrict__ cnt_a, const int *__restrict__ cnt_b,
-                                const double *__restrict__ r_lidar, const double *__restrict__ r_pseudo,
-                                long long *__restrict__ base_ab, int *__restrict__ cnt_ab,
-                                double *__restrict__ rad_ab) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  base_ab[s] = base_a[s]; base_ab[S + s] = base_b[s];
-  cnt_ab[s] = cnt_a[s]; cnt_ab[S + s] = cnt_b[s];
-  rad_ab[s] = r_lidar[s]; rad_ab[S + s] = r_pseudo[s];
-}
-
 __global__ void k_sum_counts(int S, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < S) out[s] = a[s] + b[s];
@@ -121,6 +110,51 @@ __global__ void k_fill_i32(int n, int v, int *__restrict__ p) {
 extern "C" int64_t dfu3d_chain_workspace_bytes(const dfu3d_chain_cfg *cfg) {
   if (!cfg_ok(cfg)) return DFU3D_EINVAL;
   return carve(cfg, nullptr, nullptr);
+}
+
+extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
+  if (!z || z->V <= 0 || z->max_inst <= 0 || z->max_inst > DFU3D_MAX_INST) return DFU3D_EINVAL;
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  const int64_t V = z->V, S = V * z->max_inst, P = z->pool_cap, N = V * (int64_t)z->cap_n;
+  switch (stage) {
+    case DFU3D_STAGE_FOV_FILTER:
+    case DFU3D_STAGE_SEGMENTS_BUILD:
+      return 0;
+    case DFU3D_STAGE_PLANE_RANSAC:                       /* cand_idx */
+      return z->cap_n > 0 ? up(4 * N) : DFU3D_EINVAL;
+    case DFU3D_STAGE_PROJECT_LABEL:                      /* ag_pt, ib_pix */
+      return z->cap_n > 0 ? 2 * up(4 * N) : DFU3D_EINVAL;
+    case DFU3D_STAGE_BACKPROJECT_BIN: {                  /* table, pix_bin, blk_cnt */
+      int64_t pw = 0, bw = 0;
+      if (z->table_entries <= 0 ||
+          dfu3d_backproject_scratch_words(z->V, z->H, z->W, z->cap_vox, z->max_points_per_voxel, &pw, &bw))
+        return DFU3D_EINVAL;
+      return up(V * z->table_entries * DFU3D_TABLE_ENTRY_BYTES) + up(4 * pw) + up(4 * bw);
+    }
+    case DFU3D_STAGE_RADIUS_FILTER:                      /* shadow, tile_off, flags, queue (2S joint segments) */
+      return P > 0 ? up(DFU3D_SHADOW_BYTES(P)) + up(4 * (2 * S + 1)) + up(P) + up(4 * (2 + P)) : DFU3D_EINVAL;
+    case DFU3D_STAGE_STAT_FILTER:                        /* tile_off, flags, mean_d */
+      return P > 0 ? up(4 * (S + 1)) + up(P) + up(8 * P) : DFU3D_EINVAL;
+    case DFU3D_STAGE_BALLQUERY_FUSE:                     /* tile_off, flags */
+      return P > 0 ? up(4 * (S + 1)) + up(P) : DFU3D_EINVAL;
+    case DFU3D_STAGE_RANGE_CLUSTER:                      /* sx, sy, si */
+      return P > 0 ? 2 * up(8 * P) + up(12 * P) : DFU3D_EINVAL;
+    case DFU3D_STAGE_LSHAPE_FIT:                         /* sx, sy, sroot, fit_ws */
+      return (P > 0 && z->cap_rows > 0)
+                 ? 2 * up(8 * P) + up(4 * P) + up(8 * dfu3d_lshape_fit_ws_doubles(P, z->cap_rows)) : DFU3D_EINVAL;
+    case DFU3D_STAGE_PSEUDO_BOXES: {
+      dfu3d_chain_cfg c = {};
+      c.V = z->V; c.H = z->H; c.W = z->W; c.max_inst = z->max_inst; c.cap_n = z->cap_n; c.cap_vox = z->cap_vox;
+      c.cap_rows = z->cap_rows; c.dense = z->dense; c.stat_filter = z->stat_filter; c.pool_cap = z->pool_cap;
+      c.bounds_h = z->H; c.bounds_w = z->W; c.n_theta = 1;
+      c.geom.max_points_per_voxel = z->max_points_per_voxel;
+      c.geom.t_n = 1; c.geom.p_n = (int32_t)z->table_entries;       /* only the product enters the size */
+      if (z->dense && (z->table_entries <= 0 || z->table_entries > 0x7FFFFFFF)) return DFU3D_EINVAL;
+      return dfu3d_chain_workspace_bytes(&c);
+    }
+    default:
+      return DFU3D_EINVAL;
+  }
 }
 
 extern "C" int dfu3d_chain_workspace_init(const dfu3d_chain_cfg *cfg, void *workspace, void *stream) {
@@ -195,27 +229,31 @@ extern "C" int dfu3d_pseudo_boxes(
   } else {
     if (hipMemsetAsync(w.n_vox, 0, sizeof(int32_t) * V, st) != hipSuccess) return DFU3D_ELAUNCH;
   }
+  const bool joint = !cfg->stat_filter;   // one radius-filter pass over the LiDAR and pseudo lists together
   CHAIN_TRY(dfu3d_segments_build(w.a_bits, w.a_x, w.a_y, w.a_z, w.K, cap_n, w.b_bits, w.b_x, w.b_y, w.b_z,
                                  w.n_vox, cfg->cap_vox, V, M, cfg->pool_cap, w.pool_cursor, w.px, w.py, w.pz,
-                                 w.base_a, w.cnt_a, w.base_b, w.cnt_b, status, stream));
+                                 w.base_a, w.cnt_a, w.base_b, w.cnt_b, status, inst_r_lidar, inst_r_pseudo,
+                                 joint ? w.shadow : nullptr, joint ? w.base_ab : nullptr, w.cnt_ab, w.rad_ab,
+                                 stream));
   // a10 (+a11) + a12
-  if (!cfg->stat_filter) {
-    hipLaunchKernelGGL(k_join_segments, dim3((S + 255) / 256), dim3(256), 0, st, S, (const long long *)w.base_a,
-                       (const long long *)w.base_b, w.cnt_a, w.cnt_b, inst_r_lidar, inst_r_pseudo,
-                       (long long *)w.base_ab, w.cnt_ab, w.rad_ab);
-    DFU3D_LAUNCH_CHECK();
+  if (joint) {
+    // the shadow and the joint segment table come from the segment build; the LiDAR lists are compacted in
+    // place, the pseudo lists keep their flags for the masked fuse (one compaction for both filters)
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_ab, w.cnt_ab, w.rad_ab, cfg->nb_points, 2 * S,
-                                  cfg->pool_cap, w.tile_off, w.flags, w.queue,
-                                  DFU3D_RF_ALL & ~DFU3D_RF_COMPACT, stream));
+                                  cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
+                                  DFU3D_RF_FLAGS | DFU3D_RF_RESOLVE, stream));
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,
-                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_COMPACT, stream));
+                                  cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
+                                  DFU3D_RF_COMPACT | DFU3D_RF_SHORT_LISTS, stream));
     CHAIN_TRY(dfu3d_ballquery_fuse_masked(w.px, w.py, w.pz, w.base_a, w.cnt_a, w.base_b, w.cnt_b, cfg->fuse_C,
                                           S, cfg->pool_cap, w.tile_off, w.flags, stream));
   } else {
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,
-                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_ALL, stream));
+                                  cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
+                                  DFU3D_RF_ALL, stream));
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, inst_r_pseudo, cfg->nb_points, S,
-                                  cfg->pool_cap, w.tile_off, w.flags, w.queue, DFU3D_RF_ALL, stream));
+                                  cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
+                                  DFU3D_RF_ALL, stream));
     CHAIN_TRY(dfu3d_stat_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, w.stat_enable, cfg->stat_nb_neighbors,
                                 cfg->stat_std_ratio, S, cfg->pool_cap, w.tile_off, w.flags, w.mean_d, nullptr,
                                 stream));

@@ -1,70 +1,181 @@
-// iou_stage.hip -- SURVEY.md §8 row f-3: rotated BEV overlap / IoU and rotated NMS
-// (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu; host loop of iou3d_nms.cpp:139-177).
-// The per-pair arithmetic is iou_common.inc (float32, the reference's operation order).
+// iou_stage.hip -- SURVEY.md §8 row f-3: overlap of rotated rectangles in the ground plane (BEV),
+// the IoU criteria built on it, and rotated non-maximum suppression.
+//
+// What it stands in for in the reference: pcdet/ops/iou3d_nms (boxes_overlap / boxes_iou_bev /
+// nms kernels, iou3d_nms.cpp:120-177 host walk over the mask) and the AP evaluator's
+// rotate_iou_gpu_eval (pcdet/datasets/kitti/kitti_object_eval_python/rotate_iou.py:262-330, numba-CUDA,
+// no ROCm target).  This is NOT their algorithm (edge-pair intersections + corner-in-box tests with a
+// 1e-2 margin + angular sort of up to 16 vertices): the overlap here is the exact area of the
+// intersection polygon --
+//   * rectangle A is expressed in the frame of rectangle B, where B is the axis-aligned box
+//     |u| <= hu, |v| <= hv;
+//   * A's quadrilateral is clipped against B's four sides one after the other (Sutherland-Hodgman);
+//     a convex polygon stays convex and ordered under clipping, so there is nothing to sort;
+//   * the polygon (at most 8 vertices) lives in LDS as [vertex][thread], which makes a run-time
+//     vertex index free of register spills and of bank conflicts beyond 2-way;
+//   * pairs whose circumscribed circles do not meet leave at once (almost all pairs of an NMS).
+// Differences to the reference's numbers: its margin lets a corner that is up to 1 cm OUTSIDE the other
+// box count as a vertex, so it over-estimates the overlap by a thin sliver in those configurations; the
+// exact polygon never does.  Parity for this row is therefore against geometry (float64 clipper +
+// analytic cases), not against the reference's rounding -- stated in DESIGN.md.
 #include "common.hpp"
 
 namespace {
 
-#define IOU_FN __device__ __forceinline__
-#include "iou_common.inc"
+constexpr int IB = 256;                 // threads per workgroup in every kernel of this file
+constexpr int MAXV = 8;                 // a quadrilateral clipped by four half-planes has at most 8 vertices
 
-// (N, M) overlap areas (mode 0: boxes_overlap_kernel) or BEV IoUs (mode 1: boxes_iou_bev_kernel)
-__global__ __launch_bounds__(256) void k_boxes_bev(const float *__restrict__ a, int n,
-                                                   const float *__restrict__ b, int m,
-                                                   float *__restrict__ out, int mode) {
-  __shared__ float sb[16 * 7];
-  __shared__ float sa[16 * 7];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + tx, i = blockIdx.y * 16 + ty;
-  if (threadIdx.x < 16 * 7) {
-    const int bj = blockIdx.x * 16 + threadIdx.x / 7;
-    sb[threadIdx.x] = (bj < m) ? b[(size_t)blockIdx.x * 16 * 7 + threadIdx.x] : 0.f;
-    const int ai = blockIdx.y * 16 + threadIdx.x / 7;
-    sa[threadIdx.x] = (ai < n) ? a[(size_t)blockIdx.y * 16 * 7 + threadIdx.x] : 0.f;
+struct Rect {                           // centre, half extents along its own axes, first axis (unit vector)
+  float cx, cy, hu, hv, ax, ay;
+};
+
+// fmt 7: (x, y, z, dx, dy, dz, heading), heading turns the box counter-clockwise (iou3d_nms convention);
+// fmt 5: (cx, cy, w, h, angle) of rotate_iou.py, whose corner formula turns the box CLOCKWISE by `angle`
+__device__ __forceinline__ Rect make_rect(const float *b, int fmt) {
+  Rect r;
+  r.cx = b[0]; r.cy = b[1];
+  float s, c;
+  if (fmt == 7) {
+    r.hu = 0.5f * b[3]; r.hv = 0.5f * b[4];
+    sincosf(b[6], &s, &c);
+    r.ax = c; r.ay = s;
+  } else {
+    r.hu = 0.5f * b[2]; r.hv = 0.5f * b[3];
+    sincosf(b[4], &s, &c);
+    r.ax = c; r.ay = -s;
   }
-  __syncthreads();
-  if (i >= n || j >= m) return;
-  float ba[7], bb[7];
-#pragma unroll
-  for (int k = 0; k < 7; k++) { ba[k] = sa[ty * 7 + k]; bb[k] = sb[tx * 7 + k]; }
-  out[(size_t)i * m + j] = mode ? iou_bev(ba, bb) : iou_box_overlap(ba, bb);
+  return r;
 }
 
-// mask[i * col_blocks + c] bit t: iou_bev(box i, box 64c + t) > thresh, for 64c + t > i
-// (iou3d_nms_kernel.cu:295-339; column blocks left of the diagonal are never read by the
-// reduction and are not computed)
-__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
-                                                 unsigned long long *__restrict__ mask) {
-  const int row_start = blockIdx.y, col_start = blockIdx.x;
-  if (col_start < row_start) return;
-  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-  __shared__ float block_boxes[64 * 7];
-  if ((int)threadIdx.x < col_size) {
+__device__ __forceinline__ float rect_area(const Rect &r) { return 4.0f * r.hu * r.hv; }
+
+// Area of A n B.  pu / pv: this thread's column of the two [MAXV][IB] LDS planes (ping) and qu / qv (pong).
+__device__ float overlap_area(const Rect &A, const Rect &B, float *pu, float *pv, float *qu, float *qv) {
+  const float dx = A.cx - B.cx, dy = A.cy - B.cy;
+  const float ra2 = A.hu * A.hu + A.hv * A.hv, rb2 = B.hu * B.hu + B.hv * B.hv;
+  const float rr = ra2 + rb2 + 2.0f * sqrtf(ra2 * rb2);              // (ra + rb)^2
+  if (dx * dx + dy * dy > rr) return 0.0f;                            // circumscribed circles apart
+  // A's centre and axes in B's frame
+  const float cu = dx * B.ax + dy * B.ay, cv = -dx * B.ay + dy * B.ax;
+  const float eu = A.ax * B.ax + A.ay * B.ay, ev = -A.ax * B.ay + A.ay * B.ax;     // A's first axis
+  const float au = A.hu * eu, av = A.hu * ev, bu = -A.hv * ev, bv = A.hv * eu;      // half edges
+  // counter-clockwise corners
+  pu[0 * IB] = cu + au + bu; pv[0 * IB] = cv + av + bv;
+  pu[1 * IB] = cu - au + bu; pv[1 * IB] = cv - av + bv;
+  pu[2 * IB] = cu - au - bu; pv[2 * IB] = cv - av - bv;
+  pu[3 * IB] = cu + au - bu; pv[3 * IB] = cv + av - bv;
+  int n = 4;
+  // four half-planes g(p) >= 0:  hu - u,  hu + u,  hv - v,  hv + v
 #pragma unroll
-    for (int k = 0; k < 7; k++)
-      block_boxes[threadIdx.x * 7 + k] = boxes[(size_t)(64 * col_start + threadIdx.x) * 7 + k];
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < row_size) {
-    const int cur = 64 * row_start + threadIdx.x;
-    float cb[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) cb[k] = boxes[(size_t)cur * 7 + k];
-    unsigned long long t = 0;
-    const int start = (row_start == col_start) ? (int)threadIdx.x + 1 : 0;
-    for (int i = start; i < col_size; i++) {
-      float ob[7];
-#pragma unroll
-      for (int k = 0; k < 7; k++) ob[k] = block_boxes[i * 7 + k];
-      if (iou_bev(cb, ob) > thresh) t |= 1ULL << i;
+  for (int side = 0; side < 4; side++) {
+    const float lim = (side < 2) ? B.hu : B.hv;
+    const float sg = (side & 1) ? 1.0f : -1.0f;
+    const float *iu = (side & 1) ? qu : pu, *iv = (side & 1) ? qv : pv;
+    float *ou = (side & 1) ? pu : qu, *ov = (side & 1) ? pv : qv;
+    const float *ic = (side < 2) ? iu : iv;                            // the coordinate this side bounds
+    int m = 0;
+    float u0 = iu[0], v0 = iv[0];
+    float g0 = lim + sg * ic[0];
+    for (int k = 0; k < n; k++) {
+      const int kn = (k + 1 == n) ? 0 : k + 1;
+      const float u1 = iu[kn * IB], v1 = iv[kn * IB];
+      const float g1 = lim + sg * ic[kn * IB];
+      if (g0 >= 0.0f) { ou[m * IB] = u0; ov[m * IB] = v0; m++; }
+      if ((g0 >= 0.0f) != (g1 >= 0.0f)) {                             // the edge crosses the side
+        const float t = g0 / (g0 - g1);
+        ou[m * IB] = u0 + t * (u1 - u0);
+        ov[m * IB] = v0 + t * (v1 - v0);
+        m++;
+      }
+      u0 = u1; v0 = v1; g0 = g1;
     }
-    const int col_blocks = (n + 63) / 64;
-    mask[(size_t)cur * col_blocks + col_start] = t;
+    n = m;
+    if (n < 3) return 0.0f;
   }
+  // after four sides the polygon is back in (pu, pv); shoelace around its first vertex
+  const float ox = pu[0], oy = pv[0];
+  float twice = 0.0f;
+  float x0 = pu[1 * IB] - ox, y0 = pv[1 * IB] - oy;
+  for (int k = 2; k < n; k++) {
+    const float x1 = pu[k * IB] - ox, y1 = pv[k * IB] - oy;
+    twice += x0 * y1 - x1 * y0;
+    x0 = x1; y0 = y1;
+  }
+  return 0.5f * fabsf(twice);
 }
 
-// The reference copies the mask to the host and walks it there (iou3d_nms.cpp:158-172);
-// here one wave does the same walk on the device: lane l owns the `removed` words l, l+64, ...
+// what to make of the overlap: 0 overlap area, 1 IoU, 2 overlap / area(A), 3 overlap / area(B)
+__device__ __forceinline__ float criterion_value(float inter, const Rect &A, const Rect &B, int crit) {
+  if (crit == 0) return inter;
+  const float sa = rect_area(A), sb = rect_area(B);
+  if (crit == 1) return inter / fmaxf(sa + sb - inter, 1e-8f);
+  return inter / fmaxf(crit == 2 ? sa : sb, 1e-8f);
+}
+
+// (n, m) matrix: workgroup = 8 rows x 32 columns of pairs (128-byte output rows)
+__global__ __launch_bounds__(IB) void k_pair_matrix(const float *__restrict__ a, int n,
+                                                    const float *__restrict__ b, int m, int fmt,
+                                                    float *__restrict__ out, int crit) {
+  __shared__ float s_poly[4][MAXV * IB];
+  __shared__ Rect s_a[8], s_b[32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.y * 8, j0 = blockIdx.x * 32;
+  if (threadIdx.x < 8 && i0 + threadIdx.x < n) s_a[threadIdx.x] = make_rect(a + (size_t)(i0 + threadIdx.x) * fmt, fmt);
+  if (threadIdx.x >= 32 && threadIdx.x < 64 && j0 + threadIdx.x - 32 < m)
+    s_b[threadIdx.x - 32] = make_rect(b + (size_t)(j0 + threadIdx.x - 32) * fmt, fmt);
+  __syncthreads();
+  const int i = i0 + ty, j = j0 + tx;
+  if (i >= n || j >= m) return;
+  const Rect A = s_a[ty], B = s_b[tx];
+  const float inter = overlap_area(A, B, s_poly[0] + threadIdx.x, s_poly[1] + threadIdx.x, s_poly[2] + threadIdx.x,
+                                   s_poly[3] + threadIdx.x);
+  out[(size_t)i * m + j] = criterion_value(inter, A, B, crit);
+}
+
+// row i against row i of the other list ("aligned" / "paired" variants of the reference)
+__global__ __launch_bounds__(IB) void k_pair_list(const float *__restrict__ a, const float *__restrict__ b, int n,
+                                                  int fmt, float *__restrict__ out, int crit) {
+  __shared__ float s_poly[4][MAXV * IB];
+  const int i = blockIdx.x * IB + threadIdx.x;
+  if (i >= n) return;
+  const Rect A = make_rect(a + (size_t)i * fmt, fmt), B = make_rect(b + (size_t)i * fmt, fmt);
+  const float inter = overlap_area(A, B, s_poly[0] + threadIdx.x, s_poly[1] + threadIdx.x, s_poly[2] + threadIdx.x,
+                                   s_poly[3] + threadIdx.x);
+  out[i] = criterion_value(inter, A, B, crit);
+}
+
+// Suppression mask, one 64-bit word per (box i, block of 64 later boxes): ONE WAVE per word -- lane l tests box
+// 64*cb + l against box i and the wave's ballot IS the word.  Blocks that lie wholly before i are never read by
+// the walk below and are skipped.  normal != 0: axis-aligned IoU (the reference's nms_normal).
+__global__ __launch_bounds__(IB) void k_suppress_mask(const float *__restrict__ boxes, int n, float thresh,
+                                                      int normal, unsigned long long *__restrict__ mask) {
+  __shared__ float s_poly[4][MAXV * IB];
+  const int nblk = (n + 63) >> 6;
+  const int i = blockIdx.y * (IB / 64) + (threadIdx.x >> 6);
+  const int cb = blockIdx.x;
+  if (i >= n || cb * 64 + 63 <= i) return;                  // uniform per wave
+  const int lane = lane_id();
+  const int j = cb * 64 + lane;
+  bool over = false;
+  if (j < n && j > i) {
+    const Rect A = make_rect(boxes + (size_t)i * 7, 7), B = make_rect(boxes + (size_t)j * 7, 7);
+    float inter;
+    if (normal) {                                           // headings ignored
+      const float w = fminf(A.cx + A.hu, B.cx + B.hu) - fmaxf(A.cx - A.hu, B.cx - B.hu);
+      const float h = fminf(A.cy + A.hv, B.cy + B.hv) - fmaxf(A.cy - A.hv, B.cy - B.hv);
+      inter = fmaxf(w, 0.0f) * fmaxf(h, 0.0f);
+    } else {
+      inter = overlap_area(A, B, s_poly[0] + threadIdx.x, s_poly[1] + threadIdx.x, s_poly[2] + threadIdx.x,
+                           s_poly[3] + threadIdx.x);
+    }
+    over = criterion_value(inter, A, B, 1) > thresh;
+  }
+  const unsigned long long word = __ballot(over);
+  if (lane == 0) mask[(size_t)i * nblk + cb] = word;
+}
+
+// Greedy walk over the boxes in score order on the device (the reference copies the mask to the host,
+// iou3d_nms.cpp:158-172): one wave, lane l owns the words l, l+64, ... of the running "suppressed" set.
 __global__ __launch_bounds__(64) void k_nms_reduce(int n, const unsigned long long *__restrict__ mask,
                                                    long long *__restrict__ keep, int *__restrict__ num_keep) {
   const int col_blocks = (n + 63) / 64;
@@ -98,6 +209,13 @@ __global__ __launch_bounds__(64) void k_nms_reduce(int n, const unsigned long lo
   if (lane == 0) *num_keep = nk;
 }
 
+int launch_matrix(const float *a, int n, const float *b, int m, int fmt, float *out, int crit, hipStream_t st) {
+  if ((n + 7) / 8 > 65535) return DFU3D_ERANGE;
+  hipLaunchKernelGGL(k_pair_matrix, dim3((m + 31) / 32, (n + 7) / 8), dim3(IB), 0, st, a, n, b, m, fmt, out, crit);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
 }  // namespace
 
 extern "C" int dfu3d_boxes_bev(const float *boxes_a, int32_t n, const float *boxes_b, int32_t m,
@@ -106,15 +224,34 @@ extern "C" int dfu3d_boxes_bev(const float *boxes_a, int32_t n, const float *box
   if (!boxes_a || !boxes_b || !out) return DFU3D_EINVAL;
   if (n < 0 || m < 0 || (mode != 0 && mode != 1)) return DFU3D_EINVAL;
   if (n == 0 || m == 0) return DFU3D_OK;
-  if ((n + 15) / 16 > 65535) return DFU3D_ERANGE;
-  hipLaunchKernelGGL(k_boxes_bev, dim3((m + 15) / 16, (n + 15) / 16), dim3(256), 0,
-                     (hipStream_t)stream, boxes_a, n, boxes_b, m, out, mode);
+  return launch_matrix(boxes_a, n, boxes_b, m, 7, out, mode, (hipStream_t)stream);
+}
+
+extern "C" int dfu3d_boxes_bev_paired(const float *boxes_a, const float *boxes_b, int32_t n, float *out,
+                                      int32_t mode, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!boxes_a || !boxes_b || !out) return DFU3D_EINVAL;
+  if (n < 0 || (mode != 0 && mode != 1)) return DFU3D_EINVAL;
+  if (n == 0) return DFU3D_OK;
+  hipLaunchKernelGGL(k_pair_list, dim3((n + IB - 1) / IB), dim3(IB), 0, (hipStream_t)stream, boxes_a, boxes_b, n, 7, out,
+                     mode);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
 
-extern "C" int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
-                             int64_t *keep, int32_t *num_keep, void *stream) {
+extern "C" int dfu3d_rotate_iou_eval(const float *boxes, int32_t n, const float *query_boxes, int32_t k,
+                                     float *out, int32_t criterion, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!boxes || !query_boxes || !out) return DFU3D_EINVAL;
+  if (n < 0 || k < 0) return DFU3D_EINVAL;
+  if (n == 0 || k == 0) return DFU3D_OK;
+  // rotate_iou.py:247-255: -1 -> IoU, 0 -> / area(box), 1 -> / area(query box), anything else -> the overlap itself
+  const int crit = criterion == -1 ? 1 : (criterion == 0 ? 2 : (criterion == 1 ? 3 : 0));
+  return launch_matrix(boxes, n, query_boxes, k, 5, out, crit, (hipStream_t)stream);
+}
+
+static int nms_impl(const float *boxes, int32_t n, float thresh, int normal, uint64_t *mask, int64_t *keep,
+                    int32_t *num_keep, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!boxes || !mask || !keep || !num_keep) return DFU3D_EINVAL;
   if (n < 0) return DFU3D_EINVAL;
@@ -125,11 +262,21 @@ extern "C" int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64
     return DFU3D_OK;
   }
   const int cb = (n + 63) / 64;
-  hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, n, thresh, boxes,
-                     (unsigned long long *)mask);
+  hipLaunchKernelGGL(k_suppress_mask, dim3(cb, (n + IB / 64 - 1) / (IB / 64)), dim3(IB), 0, st, boxes, n, thresh,
+                     normal, (unsigned long long *)mask);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(64), 0, st, n, (const unsigned long long *)mask,
                      (long long *)keep, num_keep);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
+}
+
+extern "C" int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
+                             int64_t *keep, int32_t *num_keep, void *stream) {
+  return nms_impl(boxes, n, thresh, 0, mask, keep, num_keep, stream);
+}
+
+extern "C" int dfu3d_nms_normal_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
+                                    int64_t *keep, int32_t *num_keep, void *stream) {
+  return nms_impl(boxes, n, thresh, 1, mask, keep, num_keep, stream);
 }

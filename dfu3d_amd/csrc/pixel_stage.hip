@@ -18,23 +18,30 @@
 //       that finds first == NOBIN is the bin's first toucher and appends the bin
 //       to the view's (unordered) list of touched bins.  Nothing is written per
 //       pixel: the depth map is the only O(pixels) stream of the stage.
-//   P2  per touched bin: set bit first[bin] in a 1-bit-per-pixel map; check the
-//       representative: the pixel p* of combo is the smallest pixel among those
-//       whose CUT key is minimal, a superset of the exact arg-mins, so it is the
-//       representative iff its exact key equals kmin.  Bins where that fails
-//       (two keys differ only below the cut: practically never) and bins that
-//       saw more than max_points pixels are queued for the exact repair
+//       The same update maintains a 1-bit-per-pixel map of the CURRENT first
+//       pixels: whoever lowers first[bin] toggles the bit of its own pixel and the
+//       bit of the pixel it displaced (the old value atomicMin returns).  XOR
+//       commutes, every pixel wins at most once and is displaced at most once, so
+//       when the pass is over exactly the final first pixels are set -- whatever
+//       the order of the updates.  The map is stored tile by tile (128 B per
+//       64x16 tile), a tile collects its own bits in LDS and flushes them with one
+//       contiguous 128-byte wave atomic; workgroups are dispatched in raster order,
+//       so displacements (scattered atomics) are rare.
 //   O*  repair (no-op kernels when the queue is empty): the views concerned are
 //       classified once more in fp64 with the bin id stored per pixel, the
 //       queued bins' pixel lists are gathered, the max_points-th smallest pixel
 //       index T is radix-selected, kmin and the representative recomputed over
 //       pix <= T
-//   P3  one workgroup per view scans the bit map: exclusive popcount prefix per
-//       32-pixel word -> the rank of any first-pixel = the voxel's position in
-//       first-seen order
-//   P4  per touched bin: rank, representative, xyz, instance bits (ONE gather
-//       from a bit-packed mask plane, or max_inst byte gathers), outputs written
-//       at the rank; table entry reset.
+//   P3  one workgroup per view scans the bit map in raster order: exclusive
+//       popcount prefix per 64-pixel row piece -> the rank of any first-pixel = the
+//       voxel's position in first-seen order
+//   P4  per touched bin: rank, representative (the pixel p* of combo is the smallest
+//       pixel among those whose CUT key is minimal, a superset of the exact
+//       arg-mins, so it is the representative iff its exact key equals kmin), xyz,
+//       instance bits (ONE gather from a bit-packed mask plane, or max_inst byte
+//       gathers), outputs written at the rank; table entry reset.  Bins where the
+//       check fails (two keys differ only below the cut: practically never) and
+//       bins that saw more than max_points pixels are queued for the exact repair.
 #include "common.hpp"
 
 namespace {
@@ -140,18 +147,34 @@ struct Counters {
   int *n_q, *q_cursor;           // repair queue length, pixel-list cursor of the repair
 };
 
+// first-pixel bit map, tile-major: tile (64 wide x 16 high, the tiles of k_bp_bin) t owns words [32t, 32t+32),
+// pixel (row, col) is bit (row & 15) * 64 + (col & 63) of its tile
+constexpr int TILE_W = 64, TILE_H = 16;            // 1024 pixels, 256 threads x 4
+__device__ __forceinline__ void toggle_first_bit(uint32_t *bitmap_v, int W, int tiles_x, uint32_t pix) {
+  const int row = (int)pix / W, col = (int)pix - row * W;
+  const int tile = (row >> 4) * tiles_x + (col >> 6);
+  const int local = (row & 15) * TILE_W + (col & 63);
+  atomicXor(&bitmap_v[tile * 32 + (local >> 5)], 1u << (local & 31));
+}
+
 // table update of the exact (tier-2) classification; the update that finds the bin untouched lists it
 __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key,
                                              uint32_t b, int v, int cap_vox, uint32_t *touched,
-                                             unsigned long long *amb_new, int pix_bits) {
+                                             unsigned long long *amb_new, int pix_bits,
+                                             uint32_t *bitmap_v, int W, int tiles_x) {
   atomicAdd(&T.cnt[e], 1u);
   const uint32_t oldf = atomicMin(&T.first[e], (uint32_t)pix);
   atomicMin(&T.kmin[e], ordered_key(key));
   atomicMin(&T.combo[e], combo_word(ordered_key(key), (uint32_t)pix, pix_bits));
-  if (oldf == NOBIN) {                             // first toucher of the bin
-    const unsigned long long o = atomicAdd(&amb_new[v], 1ull << 32);
-    const uint32_t slot = (uint32_t)(o >> 32);
-    if (slot < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + slot] = b;
+  if (oldf > (uint32_t)pix) {                      // this pixel is the bin's first pixel now
+    toggle_first_bit(bitmap_v, W, tiles_x, (uint32_t)pix);
+    if (oldf == NOBIN) {                           // first toucher of the bin
+      const unsigned long long o = atomicAdd(&amb_new[v], 1ull << 32);
+      const uint32_t slot = (uint32_t)(o >> 32);
+      if (slot < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + slot] = b;
+    } else {
+      toggle_first_bit(bitmap_v, W, tiles_x, oldf);   // ... and the one it displaced no longer is
+    }
   }
 }
 
@@ -238,7 +261,6 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 // 0.002 rad bin), so the tile first aggregates count / first pixel / min key in
 // an LDS window over the bins it touches and then issues one set of global
 // atomics per touched bin instead of one per pixel (6x fewer for dense depth).
-constexpr int TILE_W = 64, TILE_H = 16;            // 1024 pixels, 256 threads x 4
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
 constexpr int NEW_CAP = WIN_T * WIN_P + PBLK;      // new bins one tile can list: its window + every direct update
@@ -247,7 +269,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     dfu3d_bin_geom g, FastGeom fg, int W, int H, int tiles_x, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int cap_vox, uint32_t *__restrict__ touched,
-    unsigned long long *__restrict__ amb_new, uint32_t *__restrict__ amb_list, int pix_bits) {
+    unsigned long long *__restrict__ amb_new, uint32_t *__restrict__ amb_list, int pix_bits,
+    uint32_t *__restrict__ bitmap, int BW) {
+  __shared__ uint32_t s_bits[32];                 // this tile's piece of the first-pixel bit map
   __shared__ uint32_t s_amb[PBLK];
   __shared__ uint32_t s_new[NEW_CAP];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
@@ -264,6 +288,16 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int row = ty * TILE_H + (threadIdx.x >> 4);
   const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
   if (threadIdx.x == 0) { s_namb = 0; s_nnew = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
+  if (threadIdx.x < 32) s_bits[threadIdx.x] = 0u;
+  uint32_t *bitmap_v = bitmap + (size_t)v * BW;
+  // pixel f of THIS tile became a bin's first pixel; oldf is what it displaced
+  auto new_first = [&](uint32_t f, uint32_t oldf, uint32_t b) {
+    const int fr = (int)f / W, fc = (int)f - fr * W;
+    const int local = (fr - ty * TILE_H) * TILE_W + (fc - tx * TILE_W);
+    atomicOr(&s_bits[local >> 5], 1u << (local & 31));
+    if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;          // first toucher lists the bin
+    else toggle_first_bit(bitmap_v, W, tiles_x, oldf);
+  };
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
   uint32_t bins[PPT];
@@ -320,7 +354,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         const uint32_t oldf = atomicMin(&T.first[e], f);
         atomicMin(&T.kmin[e], ok);
         atomicMin(&T.combo[e], cm);
-        if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;      // first toucher lists the bin
+        if (oldf > f) new_first(f, oldf, b);
       }
     };
     uint32_t rb = NOBIN, rcn = 0u, rfirst = 0u;
@@ -355,9 +389,11 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     const uint32_t oldf = atomicMin(&T.first[e], s_first[w]);
     atomicMin(&T.kmin[e], s_kmin[w]);
     atomicMin(&T.combo[e], s_combo[w]);
-    if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;
+    if (oldf > s_first[w]) new_first(s_first[w], oldf, b);
   }
   __syncthreads();
+  // the tile's own bits: one contiguous 128-byte wave atomic (XOR: other tiles may already have toggled here)
+  if (threadIdx.x < 32 && s_bits[threadIdx.x]) atomicXor(&bitmap_v[blockIdx.x * 32 + threadIdx.x], s_bits[threadIdx.x]);
   const int na = s_namb, nn = s_nnew;
   if (na == 0 && nn == 0) return;
   if (threadIdx.x == 0)                                           // one global atomic per block, both lists
@@ -374,7 +410,8 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
     int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, int cap_vox,
     uint32_t *__restrict__ touched, unsigned long long *__restrict__ amb_new,
-    const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits) {
+    const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits,
+    uint32_t *__restrict__ bitmap, int BW, int tiles_x) {
   const int v = blockIdx.y;
   const int na = (int)(__hip_atomic_load(&amb_new[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull);
   const ViewCalib c = calib[v];
@@ -386,49 +423,54 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const int pix = (int)amb_list[(size_t)v * HW + e];
     double key;
     const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
-    if (b != NOBIN) commit_pixel(T, tb0 + b, pix, key, b, v, cap_vox, touched, amb_new, pix_bits);
+    if (b != NOBIN)
+      commit_pixel(T, tb0 + b, pix, key, b, v, cap_vox, touched, amb_new, pix_bits, bitmap + (size_t)v * BW, W, tiles_x);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
 
-// ---- P2: first-pixel bit map ---------------------------------------------------
-constexpr int MKB = 256;
-__global__ __launch_bounds__(MKB) void k_bp_mark(
-    int64_t E_view, void *table, int64_t E_total, int cap_vox, const uint32_t *__restrict__ touched,
-    const unsigned long long *__restrict__ amb_new, int BW, uint32_t *__restrict__ bitmap,
-    uint32_t *__restrict__ status) {
-  const int v = blockIdx.y;
-  const uint32_t nt_all = (uint32_t)(amb_new[v] >> 32);
-  if (nt_all > (uint32_t)cap_vox && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
-  const int nt = (int)min(nt_all, (uint32_t)cap_vox);
-  const Table T = table_view(table, E_total);
-  for (int i = blockIdx.x * MKB + threadIdx.x; i < nt; i += gridDim.x * MKB) {
-    const uint32_t f = T.first[(int64_t)v * E_view + touched[(size_t)v * cap_vox + i]];
-    atomicOr(&bitmap[(size_t)v * BW + (f >> 5)], 1u << (f & 31u));
-  }
-}
-
-// ---- P3: exclusive popcount prefix of the bit map (one workgroup per view) ------
+// ---- P3: exclusive popcount prefix of the bit map in raster order (one workgroup per view) ------
+// item j = y * tiles_x + tx: the 64 pixels of image row y inside tile column tx (two words of the tile-major map)
 constexpr int SCB = 1024;
-__global__ __launch_bounds__(SCB) void k_bp_scan(int BW, const uint32_t *__restrict__ bitmap,
-                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox) {
+__device__ __forceinline__ unsigned long long row_piece(const uint32_t *bitmap_v, int tiles_x, int y, int tx) {
+  return *(const unsigned long long *)(bitmap_v + ((size_t)(y >> 4) * tiles_x + tx) * 32 + (y & 15) * 2);
+}
+__global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, const uint32_t *__restrict__ bitmap,
+                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox,
+                                                 const unsigned long long *__restrict__ amb_new, int cap_vox,
+                                                 uint32_t *__restrict__ status) {
   __shared__ int s_w[SCB / 64];
   const int v = blockIdx.x;
+  const uint32_t *bv = bitmap + (size_t)v * BW;
   int running = 0;
-  for (int w0 = 0; w0 < BW; w0 += SCB) {
-    const int w = w0 + threadIdx.x;
-    const int c = (w < BW) ? __popc(bitmap[(size_t)v * BW + w]) : 0;
+  for (int j0 = 0; j0 < NJ; j0 += SCB) {
+    const int j = j0 + threadIdx.x;
+    int c = 0;
+    if (j < NJ) {
+      const int y = j / tiles_x, tx = j - y * tiles_x;
+      c = __popcll(row_piece(bv, tiles_x, y, tx));
+    }
     int tot;
     const int ex = block_excl_scan<SCB / 64>(c, s_w, tot);
-    if (w < BW) wpre[(size_t)v * BW + w] = (uint32_t)(running + ex);
+    if (j < NJ) wpre[(size_t)v * NJ + j] = (uint32_t)(running + ex);
     running += tot;
   }
-  if (threadIdx.x == 0) n_vox[v] = running;                 // bins listed (clamped by k_bp_finalize)
+  if (threadIdx.x == 0) {
+    n_vox[v] = running;                                   // touched bins (clamped by k_bp_finalize)
+    if ((uint32_t)(amb_new[v] >> 32) > (uint32_t)cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+  }
 }
 
 // rank of first-pixel f among the first-pixels of view v = the voxel's place in first-seen order
-__device__ __forceinline__ int first_rank(const uint32_t *bitmap, const uint32_t *wpre, size_t vb, uint32_t f) {
-  return (int)(wpre[vb + (f >> 5)] + (uint32_t)__popc(bitmap[vb + (f >> 5)] & ((1u << (f & 31u)) - 1u)));
+struct RankMap {
+  const uint32_t *bitmap, *wpre;
+  int BW, NJ, tiles_x, W;
+};
+__device__ __forceinline__ int first_rank(const RankMap &R, int v, uint32_t f) {
+  const int y = (int)f / R.W, x = (int)f - y * R.W;
+  const int tx = x >> 6;
+  const unsigned long long m = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
+  return (int)(R.wpre[(size_t)v * R.NJ + y * R.tiles_x + tx] + (uint32_t)__popcll(m & ((1ull << (x & 63)) - 1ull)));
 }
 
 struct VoxOut {
@@ -455,8 +497,8 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int max_voxels, int max_points, int64_t E_view, void *table, int64_t E_total, int cap_vox,
-    const uint32_t *__restrict__ touched, const unsigned long long *__restrict__ amb_new, int BW,
-    const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ wpre, VoxOut out, int key_axis,
+    const uint32_t *__restrict__ touched, const unsigned long long *__restrict__ amb_new, RankMap R,
+    VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ n_q,
     uint32_t *__restrict__ status) {
   const int v = blockIdx.y;
@@ -467,7 +509,6 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   const Recip rc = make_recip(c);
   const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
   const float *dv = depth + (size_t)v * HW;
-  const size_t vb = (size_t)v * BW;
   for (int i = blockIdx.x * VXB + threadIdx.x; i < nt; i += gridDim.x * VXB) {
     const uint32_t b = touched[(size_t)v * cap_vox + i];
     const int64_t e = (int64_t)v * E_view + b;
@@ -486,7 +527,7 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
       else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
       continue;
     }
-    const int k = first_rank(bitmap, wpre, vb, T.first[e]);
+    const int k = first_rank(R, v, T.first[e]);
     if (k < max_voxels) emit_voxel(out, (size_t)v * cap_vox + k, c, rc, dv, W, pix, masks, mask_format, m, max_inst, HW, v);
     // leave the table clean for the next pass (rep is only ever written by the repair)
     T.kmin[e] = ~0ull;
@@ -647,8 +688,7 @@ __global__ __launch_bounds__(256) void k_ovf_select(
 __global__ __launch_bounds__(256) void k_bp_fix(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox, int BW,
-    const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ wpre, VoxOut out, int cap_q,
+    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int cap_q,
     const uint32_t *__restrict__ q_bins, const int *__restrict__ n_q) {
   const int v = blockIdx.y;
   const int no = min(n_q[v], cap_q);
@@ -659,7 +699,7 @@ __global__ __launch_bounds__(256) void k_bp_fix(
   const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
   for (int s = blockIdx.x * 256 + threadIdx.x; s < no; s += gridDim.x * 256) {
     const int64_t e = (int64_t)v * E_view + q_bins[(size_t)v * cap_q + s];
-    const int k = first_rank(bitmap, wpre, (size_t)v * BW, T.first[e]);
+    const int k = first_rank(R, v, T.first[e]);
     if (k < max_voxels)
       emit_voxel(out, (size_t)v * cap_vox + k, c, rc, depth + (size_t)v * HW, W, T.rep[e], masks, mask_format, m,
                  max_inst, HW, v);
@@ -757,8 +797,8 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 
 // Scratch carve-up.
 // blk_cnt (int32 words): amb_new[V] (uint64: undecided pixels | touched bins), n_q[V], q_cursor[V],
-//   bitmap[V*BW] -- everything up to here is zeroed at the start of a pass --, wpre[V*BW],
-//   q_cnt[V*cap_q], q_bins[V*cap_q]                      (BW = ceil(H*W/32), cap_q: queue_cap)
+//   bitmap[V*BW] -- everything up to here is zeroed at the start of a pass --, wpre[V*NJ],
+//   q_cnt[V*cap_q], q_bins[V*cap_q]      (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair,
 //   [2*V*HW, 2*V*HW + V*cap_vox) touched bins.
@@ -777,10 +817,11 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
                                                    int64_t *pix_words, int64_t *blk_words) {
   if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1) return DFU3D_EINVAL;
   const int64_t HW = (int64_t)H * W;
-  const int64_t BW = (HW + 31) / 32;
+  const int64_t tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
-  if (blk_words) *blk_words = 4 * (int64_t)V + 2 * V * BW + 2 * V * cap_q + 8;
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 2 * V * cap_q + 8;
   return 0;
 }
 
@@ -805,7 +846,8 @@ extern "C" int dfu3d_backproject_bin(
   if (geom->max_points_per_voxel < 1) return DFU3D_EINVAL;
   if (((uintptr_t)blk_cnt & 7u) != 0) return DFU3D_EINVAL;   // 64-bit counters in front
   const int HW = (int)HW64;
-  const int BW = (HW + 31) / 32;
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  const int BW = tiles_x * tiles_y * 32, NJ = H * tiles_x;
   const int cap_q = queue_cap(HW64, geom->max_points_per_voxel, cap_vox);
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
@@ -815,7 +857,7 @@ extern "C" int dfu3d_backproject_bin(
   int *q_cursor = n_q + V;
   uint32_t *bitmap = (uint32_t *)(q_cursor + V);
   uint32_t *wpre = bitmap + (size_t)V * BW;
-  int *q_cnt = (int *)(wpre + (size_t)V * BW);
+  int *q_cnt = (int *)(wpre + (size_t)V * NJ);
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int pix_bits = 1;
   while ((1ll << pix_bits) < HW64) pix_bits++;
@@ -823,24 +865,24 @@ extern "C" int dfu3d_backproject_bin(
   uint32_t *touched = pix_bin + 2 * (size_t)V * HW;
   const ViewCalib *cal = (const ViewCalib *)calib;
   const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
+  const RankMap R = {bitmap, wpre, BW, NJ, tiles_x, W};
 
   if (phases & DFU3D_BP_BIN) {
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
                        make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view, table, E_total, cap_vox, touched,
-                       amb_new, q_list, pix_bits);
+                       amb_new, q_list, pix_bits, bitmap, BW);
     DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_AMB) {
     hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
-                       key_axis, E_view, table, E_total, cap_vox, touched, amb_new, q_list, status, pix_bits);
+                       key_axis, E_view, table, E_total, cap_vox, touched, amb_new, q_list, status, pix_bits, bitmap,
+                       BW, tiles_x);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_MARK) {
-    const int gm = (cap_vox + MKB - 1) / MKB;
-    hipLaunchKernelGGL(k_bp_mark, dim3(gm < 64 ? gm : 64, V), dim3(MKB), 0, st, E_view, table, E_total, cap_vox,
-                       touched, amb_new, BW, bitmap, status);
-    DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, bitmap, wpre, n_vox);
+    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, amb_new, cap_vox,
+                       status);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
@@ -849,7 +891,7 @@ extern "C" int dfu3d_backproject_bin(
     if (gx > gmax) gx = gmax;
     hipLaunchKernelGGL(k_bp_vox, dim3(gx, V), dim3(VXB), 0, st, depth, cal, masks, mask_format, n_inst, max_inst, W,
                        HW, geom->max_voxels, geom->max_points_per_voxel, E_view, table, E_total, cap_vox, touched,
-                       amb_new, BW, bitmap, wpre, out, key_axis, pix_bits, cap_q, q_bins, n_q, status);
+                       amb_new, R, out, key_axis, pix_bits, cap_q, q_bins, n_q, status);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {
@@ -872,7 +914,7 @@ extern "C" int dfu3d_backproject_bin(
                        q_bins, n_q, q_cnt, q_list);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_fix, dim3(ga < 16 ? ga : 16, V), dim3(256), 0, st, depth, cal, masks, mask_format, n_inst,
-                       max_inst, W, HW, geom->max_voxels, E_view, table, E_total, cap_vox, BW, bitmap, wpre, out, cap_q,
+                       max_inst, W, HW, geom->max_voxels, E_view, table, E_total, cap_vox, R, out, cap_q,
                        q_bins, n_q);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V, geom->max_voxels, cap_vox, n_vox);

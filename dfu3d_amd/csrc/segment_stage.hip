@@ -19,6 +19,20 @@ namespace {
 constexpr int QT = 256;    // queries per workgroup tile
 constexpr int PT = 1024;   // points per LDS tile
 
+// last word of a shadow entry (see the radius filter below): segment << 16 | radius as a bfloat16
+__device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
+  // radius as the top 16 bits of its float32 value rounded toward zero: r' <= r, so "certainly
+  // within r'" implies "within r".  r == 0 (no filter) stays 0; r < 0 (drop all) keeps its sign
+  // bit, NaN its pattern; a positive radius never becomes 0.
+  float rf = (float)radius;
+  if (radius > 0.0 && (double)rf > radius) rf = __uint_as_float(__float_as_uint(rf) - 1u);   // (float) rounded up
+  uint32_t hi = __float_as_uint(rf) >> 16;
+  if (radius > 0.0 && hi == 0u) hi = 1u;
+  if (radius != radius) hi = 0x7FC0u;
+  return ((uint32_t)seg << 16) | hi;
+}
+
+
 // ---------------------------------------------------------------- build
 __global__ __launch_bounds__(1024) void k_seg_count(const uint32_t *__restrict__ bits,
                                                    const int *__restrict__ n_item,
@@ -41,16 +55,27 @@ __global__ __launch_bounds__(1024) void k_seg_count(const uint32_t *__restrict__
   if (threadIdx.x < max_inst) cnt[v * max_inst + threadIdx.x] = s_c[threadIdx.x];
 }
 
+// joint view of the 2S lists for the one-pass radius filter: s < S the LiDAR lists, S + s the pseudo lists
+struct JointSegs {
+  long long *base;
+  int *cnt;
+  double *rad;
+  const double *rad_a, *rad_b;
+};
+
 __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt_a,
                                                     int *__restrict__ cnt_b,
                                                     long long *__restrict__ base_a,
                                                     long long *__restrict__ base_b,
                                                     long long pool_cap,
                                                     long long *__restrict__ cursor,
-                                                    uint32_t *__restrict__ status) {
+                                                    uint32_t *__restrict__ status, JointSegs J) {
   __shared__ int s_w[16];
+  __shared__ long long s_end;              // end of the last segment that fitted (the pool is dense up to there)
   long long running = *cursor;
   bool over = false;
+  if (threadIdx.x == 0) s_end = -1;
+  __syncthreads();
   for (int b0 = 0; b0 < S; b0 += 1024) {
     const int s = b0 + threadIdx.x;
     const int ca = (s < S) ? cnt_a[s] : 0, cb = (s < S) ? cnt_b[s] : 0;
@@ -63,17 +88,26 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt
         cnt_b[s] = 0;
         base_a[s] = 0;
         base_b[s] = 0;
-        over = over || (ca + cb > 0);
+        if (ca + cb > 0) {
+          over = true;
+          atomicMin((unsigned long long *)&s_end, (unsigned long long)b);     // -1 = "none" is the largest value
+        }
       } else {
         base_a[s] = b;
         base_b[s] = b + ca;
+      }
+      if (J.base) {
+        J.base[s] = base_a[s]; J.base[S + s] = base_b[s];
+        J.cnt[s] = cnt_a[s]; J.cnt[S + s] = cnt_b[s];
+        J.rad[s] = J.rad_a[s]; J.rad[S + s] = J.rad_b[s];
       }
     }
     running += tot;
   }
   if (over) atomicOr(status, DFU3D_ST_POOL_OVERFLOW);
   __syncthreads();
-  if (threadIdx.x == 0) *cursor = running < pool_cap ? running : pool_cap;
+  // segments are allocated in index order, so the ones that fit form a prefix: [0, cursor) is exactly covered
+  if (threadIdx.x == 0) *cursor = (s_end >= 0) ? s_end : (running < pool_cap ? running : pool_cap);
 }
 
 // One workgroup per VIEW writes the ordered lists of all its instances in a single sweep over the view's
@@ -85,7 +119,8 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
     const double *__restrict__ iy, const double *__restrict__ iz,
     const int *__restrict__ n_item, int cap_item, int max_inst,
     const long long *__restrict__ base, const int *__restrict__ cnt,
-    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz) {
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+    float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off) {
   __shared__ int s_wc[SWT / 64][DFU3D_MAX_INST];      // per wave: items of instance j in this step
   __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items written before this step
   const int v = blockIdx.x;
@@ -130,6 +165,9 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
         px[d] = x;
         py[d] = y;
         pz[d] = z;
+        if (pq)                                        // float32 shadow for the radius filter
+          pq[d] = make_float4((float)x, (float)y, (float)z,
+                              __uint_as_float(shadow_word(seg_off + v * max_inst + j, rad[v * max_inst + j])));
       }
     }
   }
@@ -162,251 +200,315 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 }
 
 // ---------------------------------------------------------------- a10 radius
-// Phase A (streaming, no LDS): a query is first tested against itself and its
-// two nearest list neighbours (lane^1, lane^2) -- the lists are in pixel / sweep
-// order, so list neighbours are spatial neighbours and nb_points = 1 is settled
-// right there for ~98 % of the points.  If a lane of the wave is still
-// undecided, eight of the wave's points are broadcast one by one (v_readlane,
-// scalar operands) until every lane has its nb_points+1 distinct hits.
-// Whatever is still undecided is collected in a workgroup-local LDS list and
-// appended with one global atomic to the queue of phase B, which sees the whole
-// segment.
-// Each workgroup walks RF_TPB consecutive query tiles: one binary search, then a
-// linear step from segment to segment.
-constexpr int RF_TPB = 8;
-constexpr int RF_LONG = 2048;      // phase B hands segments longer than this to a whole workgroup
+// The filter works on a float32 SHADOW of the pool: pq[i] = (x, y, z, seg << 16 | radius
+// as a truncated bfloat16) for pool position i -- one 16-byte load per point, the segment
+// travels with the coordinates (k_seg_write produces it together with the pool).  Every decision
+// taken from the shadow is a CERTAIN one: a neighbour is counted only when its float32 distance is
+// below the radius by more than a bound on everything float32 rounding (of the coordinates and of
+// the arithmetic) can do; whatever is not certain is decided from the fp64 pool with the
+// reference's predicate d2 < r2 (Open3D / nanoflann, self included).
+//
+// Phase A (k_radius_flags) streams the shadow linearly over the used part of the pool, 2048
+// positions per workgroup, all of a wave's loads issued up front.  A query is tested against
+// itself and its two list neighbours (lane^1, lane^2 -- the lists are in pixel / sweep order,
+// so list neighbours are spatial neighbours; this settles ~98 % for nb_points = 1), then, if a
+// lane of the wave is still undecided, against eight of the wave's points broadcast as scalar
+// operands (v_readlane).  What is still undecided is kept in an LDS list of the workgroup and
+// tried pairwise against the other undecided points of the workgroup (an outlier's neighbours
+// are usually other outliers a few dozen list positions away).  The rest -- isolated points and
+// the rare uncertain comparisons -- goes to phase B through one global atomic per workgroup.
+// Phase A also leaves, per 64-position chunk of the pool, two bounding boxes: one of the points it
+// decided and one of the points it could not decide (outliers: kept apart so that they do not blow up
+// the first).  Phase B (k_radius_resolve): one wave per queued query sweeps the BOXES of its segment
+// (64 chunks per step, a lane each) and tests the points of the few chunks whose boxes come within the
+// radius: float32 shadow with certain-hit / certain-miss bounds, fp64 for the pairs in between.
+// Every point of the segment lies in one of the two boxes of its chunk, so nothing is missed.
+constexpr int RFB = 256;           // threads per phase-A workgroup
+constexpr int RF_IT = 8;           // 64-point chunks per wave
+constexpr int RF_WG = RFB * RF_IT; // pool positions per workgroup
 constexpr int RF_STRIDE = 8;       // phase A tries lanes 0, 8, 16, ... of the wave
+constexpr int RF_LIST = 512;       // undecided points a workgroup tries pairwise in LDS
+constexpr uint32_t RF_NOSEG = 0xFFFFu;
 
-__device__ __forceinline__ double readlane_d(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
+// bound on |float32 distance - true distance| for a query at (x,y,z) and neighbours within ~r of it:
+// each coordinate of either point carries <= 2^-24 relative rounding, the differences, squares and
+// sums add a few ulp: 2^-20 * (|x|+|y|+|z| + 3r) is more than 10x that.
+__device__ __forceinline__ float rf_bound(float x, float y, float z, float r) {
+  return (fabsf(x) + fabsf(y) + fabsf(z) + 3.0f * r) * 9.5367431640625e-07f;
+}
+__device__ __forceinline__ float rf_certain_hit2(float x, float y, float z, float r) {
+  const float t = r - rf_bound(x, y, z, r) - r * 2.4e-7f;
+  return (t > 0.0f) ? t * t * 0.999999f : -1.0f;
 }
 
-__global__ __launch_bounds__(QT) void k_radius_flags(
-    const double *__restrict__ px, const double *__restrict__ py,
-    const double *__restrict__ pz, const long long *__restrict__ seg_base,
-    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S,
-    const int *__restrict__ tile_off, uint8_t *__restrict__ flags, int *__restrict__ queue) {
-  __shared__ int2 s_list[RF_TPB * QT];
-  __shared__ int s_n, s_base;
-  const int ntile = tile_off[S];
-  int t = blockIdx.x * RF_TPB;
-  if (t >= ntile) return;
-  if (threadIdx.x == 0) s_n = 0;
+// wave-wide min / max with DPP row operations (VALU, no LDS traffic); the result is valid in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min63(float v) {
+  v = fminf(v, dpp_f<0xB1, 0xF>(v, v));      // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_f<0x4E, 0xF>(v, v));      // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_f<0x141, 0xF>(v, v));     // row_half_mirror
+  v = fminf(v, dpp_f<0x140, 0xF>(v, v));     // row_mirror: every lane of a row holds the row's minimum
+  v = fminf(v, dpp_f<0x142, 0xA>(v, v));     // row_bcast15 into rows 1 and 3
+  v = fminf(v, dpp_f<0x143, 0xC>(v, v));     // row_bcast31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ float wave_max63(float v) {
+  v = fmaxf(v, dpp_f<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
+  return v;
+}
+constexpr int BOX_FLOATS = 12;               // per chunk: decided min xyz, max xyz | undecided min xyz, max xyz
+constexpr float BOX_EMPTY = 3.0e38f;
+
+__global__ __launch_bounds__(RFB) void k_radius_flags(
+    const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S,
+    uint8_t *__restrict__ flags, int *__restrict__ queue, float *__restrict__ boxes) {
+  __shared__ float4 s_pt[RF_LIST];
+  __shared__ int s_pos[RF_LIST], s_cnt[RF_LIST], s_q[RF_LIST];
+  __shared__ int s_n, s_nq, s_base;
+  long long n_used = n_max;
+  if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
+  const long long wg0 = (long long)blockIdx.x * RF_WG;
+  if (wg0 >= n_used) return;
+  if (threadIdx.x == 0) { s_n = 0; s_nq = 0; }
   __syncthreads();
-  const int t_end = min(t + RF_TPB, ntile);
-  int s = find_segment(tile_off, S, t);
   const int lane = lane_id();
-  const int w_in_tile = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
-  // segment facts stay in registers while consecutive tiles belong to the same segment
-  int t_first = tile_off[s], t_next = tile_off[s + 1];
-  int n = seg_cnt[s];
-  long long base = seg_base[s];
-  double r = radius[s];
-  for (; t < t_end; t++) {
-    if (t >= t_next) {
-      do { s++; t_first = t_next; t_next = tile_off[s + 1]; } while (t >= t_next);
-      n = seg_cnt[s];
-      base = seg_base[s];
-      r = radius[s];
-    }
-    const int w0 = (t - t_first) * QT + w_in_tile;         // first point of this wave (uniform)
-    if (w0 >= n) continue;
-    const int q = w0 + lane;
-    const bool valid = q < n;
-    if (!(r > 0.0)) {               // r == 0: no filter; r < 0 (or NaN): drop all
-      if (valid) flags[base + q] = (r == 0.0) ? 1 : 0;
-      continue;
-    }
-    const double r2 = r * r;
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
-    const int wn = min(64, n - w0);
-    // self + the two nearest list neighbours (quad permutes, no LDS traffic)
-    int cnt = 0;
+  const long long w0 = wg0 + (long long)(threadIdx.x >> 6) * (64 * RF_IT);
+  float4 p[RF_IT];
+#pragma unroll
+  for (int it = 0; it < RF_IT; it++) {
+    const long long i = w0 + it * 64 + lane;
+    p[it] = (i < n_used) ? pq[i] : make_float4(0.f, 0.f, 0.f, __uint_as_float(RF_NOSEG << 16));
+  }
+#pragma unroll
+  for (int it = 0; it < RF_IT; it++) {
+    const long long i = w0 + it * 64 + lane;
+    const float x = p[it].x, y = p[it].y, z = p[it].z;
+    const uint32_t wb = __float_as_uint(p[it].w);
+    const uint32_t seg = wb >> 16;
+    const float r = __uint_as_float(wb << 16);
+    const bool valid = seg < (uint32_t)S;           // "no segment" mark, or a slot nobody wrote: never a point
+    if (__ballot(valid) == 0ull) continue;
+    const bool active = valid && (r > 0.0f);
+    if (valid && !active) flags[i] = (r == 0.0f) ? 1 : 0;     // r == 0: no filter; r < 0 / NaN: drop all
+    const float thr2 = rf_certain_hit2(x, y, z, r);
+    int cnt = 1;                                    // the query itself (d = 0 < r^2)
     {
-      const int l1 = lane ^ 1, l2 = lane ^ 2;
-      const double x1 = shfl_xor_d(x, 1), y1 = shfl_xor_d(y, 1), z1 = shfl_xor_d(z, 1);
-      const double x2 = shfl_xor_d(x, 2), y2 = shfl_xor_d(y, 2), z2 = shfl_xor_d(z, 2);
-      double dx = x - x1, dy = y - y1, dz = z - z1;
-      double d = dx * dx;
-      d += dy * dy;
-      d += dz * dz;
-      cnt = 1 + ((l1 < wn && d < r2) ? 1 : 0);                 // self: d == 0 < r2
+      const float x1 = __shfl_xor(x, 1, 64), y1 = __shfl_xor(y, 1, 64), z1 = __shfl_xor(z, 1, 64);
+      const float x2 = __shfl_xor(x, 2, 64), y2 = __shfl_xor(y, 2, 64), z2 = __shfl_xor(z, 2, 64);
+      const uint32_t s1 = (uint32_t)__shfl_xor((int)seg, 1, 64), s2 = (uint32_t)__shfl_xor((int)seg, 2, 64);
+      float dx = x - x1, dy = y - y1, dz = z - z1;
+      cnt += (s1 == seg && dx * dx + dy * dy + dz * dz < thr2) ? 1 : 0;
       dx = x - x2; dy = y - y2; dz = z - z2;
-      d = dx * dx;
-      d += dy * dy;
-      d += dz * dz;
-      cnt += (l2 < wn && d < r2) ? 1 : 0;
+      cnt += (s2 == seg && dx * dx + dy * dy + dz * dz < thr2) ? 1 : 0;
     }
-    // undecided lanes: a few of the wave's points, broadcast as scalar operands
-    // (v_readlane), are tried by all of them at once; what is left after that is
-    // almost surely isolated and goes to phase B
-    if (__ballot(valid && cnt <= nb)) {
+    if (__ballot(active && cnt <= nb)) {
       const int l1 = lane ^ 1, l2 = lane ^ 2;
-      for (int j = 0; j < wn; j += RF_STRIDE) {
-        const double dx = x - readlane_d(x, j), dy = y - readlane_d(y, j), dz = z - readlane_d(z, j);
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        if (d < r2 && j != lane && j != l1 && j != l2) cnt++;   // never count a point twice
-        if (__ballot(valid && cnt <= nb) == 0ull) break;
+      for (int j = 0; j < 64; j += RF_STRIDE) {
+        const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+        const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), j));
+        const float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), j));
+        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)seg, j);
+        const float dx = x - xj, dy = y - yj, dz = z - zj;
+        if (sj == seg && dx * dx + dy * dy + dz * dz < thr2 && j != lane && j != l1 && j != l2) cnt++;
+        if (__ballot(active && cnt <= nb) == 0ull) break;
       }
     }
-    const bool pending = valid && cnt <= nb;       // a lower bound that did not reach nb_points + 1
-    if (valid && !pending) flags[base + q] = 1;
+    const bool pending = active && cnt <= nb;
+    if (active && !pending) flags[i] = 1;
+    {   // the chunk's two boxes: points decided here | points left undecided
+      const bool dk = valid && !pending;
+      float bx[BOX_FLOATS];
+      bx[0] = wave_min63(dk ? x : BOX_EMPTY);  bx[1] = wave_min63(dk ? y : BOX_EMPTY);  bx[2] = wave_min63(dk ? z : BOX_EMPTY);
+      bx[3] = wave_max63(dk ? x : -BOX_EMPTY); bx[4] = wave_max63(dk ? y : -BOX_EMPTY); bx[5] = wave_max63(dk ? z : -BOX_EMPTY);
+      bx[6] = wave_min63(pending ? x : BOX_EMPTY);  bx[7] = wave_min63(pending ? y : BOX_EMPTY);
+      bx[8] = wave_min63(pending ? z : BOX_EMPTY);  bx[9] = wave_max63(pending ? x : -BOX_EMPTY);
+      bx[10] = wave_max63(pending ? y : -BOX_EMPTY); bx[11] = wave_max63(pending ? z : -BOX_EMPTY);
+      if (lane == 63) {
+        float4 *o = (float4 *)(boxes + (size_t)((w0 + it * 64) >> 6) * BOX_FLOATS);
+        o[0] = make_float4(bx[0], bx[1], bx[2], bx[3]);
+        o[1] = make_float4(bx[4], bx[5], bx[6], bx[7]);
+        o[2] = make_float4(bx[8], bx[9], bx[10], bx[11]);
+      }
+    }
     const unsigned long long pm = __ballot(pending);
-    if (pm) {                       // block-local list (LDS), one LDS atomic per wave
+    if (pm) {                       // workgroup-local list (LDS), one LDS atomic per wave
       int slot0 = 0;
       if (lane == 0) slot0 = atomicAdd(&s_n, __popcll(pm));
       slot0 = __builtin_amdgcn_readfirstlane(slot0);
       if (pending) {
         const int slot = slot0 + __popcll(pm & ((1ull << lane) - 1ull));
-        s_list[slot] = make_int2(s, q);
+        if (slot < RF_LIST) {
+          s_pt[slot] = p[it];
+          s_pos[slot] = (int)(i - wg0);
+          s_cnt[slot] = cnt;
+        } else {                     // list full (a pathological tile): straight to phase B
+          const int g = atomicAdd(&queue[0], 1);
+          queue[2 + g] = (int)i;
+        }
       }
     }
   }
   __syncthreads();
-  const int np = s_n;
+  const int np = min(s_n, RF_LIST);
   if (np == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&queue[0], np);        // one global atomic per workgroup
+  // pairwise among the workgroup's undecided points.  A partner that phase A already looked at
+  // (same chunk: lane^1, lane^2 and the broadcast lanes 0, 8, ...) is skipped: counted or not, it
+  // must not be counted twice.
+  for (int a = threadIdx.x; a < np; a += RFB) {
+    const float4 q = s_pt[a];
+    const uint32_t wa = __float_as_uint(q.w);
+    const uint32_t seg = wa >> 16;
+    const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
+    int cnt = s_cnt[a];
+    const int pa = s_pos[a];
+    for (int b = 0; b < np && cnt <= nb; b++) {
+      const float4 o = s_pt[b];
+      if ((__float_as_uint(o.w) >> 16) != seg || b == a) continue;
+      const int pb = s_pos[b];
+      if ((pb >> 6) == (pa >> 6)) {
+        const int lb = pb & 63, la = pa & 63;
+        if (lb == (la ^ 1) || lb == (la ^ 2) || (lb & (RF_STRIDE - 1)) == 0) continue;
+      }
+      const float dx = q.x - o.x, dy = q.y - o.y, dz = q.z - o.z;
+      if (dx * dx + dy * dy + dz * dz < thr2) cnt++;
+    }
+    if (cnt > nb) flags[wg0 + pa] = 1;
+    else s_q[atomicAdd(&s_nq, 1)] = pa;
+  }
   __syncthreads();
-  int2 *out = (int2 *)(queue + 2) + s_base;
-  for (int i = threadIdx.x; i < np; i += QT) out[i] = s_list[i];
+  const int nq = s_nq;
+  if (nq == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&queue[0], nq);        // one global atomic per workgroup
+  __syncthreads();
+  for (int k = threadIdx.x; k < nq; k += RFB) queue[2 + s_base + k] = (int)(wg0 + s_q[k]);
 }
 
-// Phase B: one wave per undecided query; the 64 lanes stride the whole segment
-// (coalesced 8 B/lane loads) and leave together as soon as the count is reached.
+// squared distance from q to an axis-aligned box (0 inside)
+__device__ __forceinline__ float box_dist2(float qx, float qy, float qz, float lx, float ly, float lz,
+                                           float hx, float hy, float hz) {
+  const float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.0f), dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.0f),
+              dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.0f);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// Phase B: one wave per queued query.
 __global__ __launch_bounds__(256) void k_radius_resolve(
-    const double *__restrict__ px, const double *__restrict__ py,
-    const double *__restrict__ pz, const long long *__restrict__ seg_base,
-    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb,
-    uint8_t *__restrict__ flags, int *__restrict__ queue, long long pool_cap) {
-  const int nq = queue[0];
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    const float4 *__restrict__ pq, const float *__restrict__ boxes, const long long *__restrict__ seg_base,
+    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S, long long pool_cap,
+    uint8_t *__restrict__ flags, const int *__restrict__ queue) {
+  const int nq = (int)min((long long)queue[0], pool_cap);
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
   const int lane = lane_id();
   for (int e = wave; e < nq; e += nwaves) {
-    const int s = queue[2 + 2 * e], q = queue[3 + 2 * e];
-    const int n = seg_cnt[s];
-    const long long base = seg_base[s];
+    const long long i = queue[2 + e];
+    const float4 qf = pq[i];
+    const int s = (int)(__float_as_uint(qf.w) >> 16);     // < S: phase A queues nothing else
+    if (s >= S) continue;
+    const int n = max(seg_cnt[s], 0);
+    const long long base = seg_base[s], end = base + n;
+    if (i < base || i >= end) continue;                   // cannot happen for a shadow built from this table
     const double r = radius[s], r2 = r * r;
-    const double x = px[base + q], y = py[base + q], z = pz[base + q];
-    // own 64-point chunk first (list neighbours are near), then the rest of the
-    // segment RU chunks at a time so that the loads of one step overlap
+    const double x = px[i], y = py[i], z = pz[i];
+    // float32 screening: certainly inside below lo2, certainly outside above hi2, fp64 in between
+    const float rf = (float)r;
+    const float eb = rf_bound(qf.x, qf.y, qf.z, rf) + rf * 2.4e-7f;
+    const float tl = rf - eb, th = rf + eb;
+    const float lo2 = (tl > 0.0f) ? tl * tl * 0.999999f : -1.0f;
+    const float hi2 = th * th * 1.000001f;
     int cnt = 0;
-    const int c0 = q >> 6;
-    {
-      const int j = (c0 << 6) + lane;
+    // the points of chunk c (pool positions 64c .. 64c+63) that belong to the segment
+    auto test_chunk = [&](long long c) {
+      const long long g = (c << 6) + lane;
+      const bool in = (g >= base) && (g < end);
       bool hit = false;
-      if (j < n) {
-        const double dx = x - px[base + j], dy = y - py[base + j], dz = z - pz[base + j];
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        hit = d < r2;
-      }
-      cnt = __popcll(__ballot(hit));
-    }
-    constexpr int RU = 4;
-    // then outwards from the own chunk, RU chunks per step (their loads overlap).  A long
-    // segment that did not settle in the first step is swept by a whole workgroup
-    // (k_radius_resolve_long); its entry moves to the top end of the queue
-    bool handed = false;
-    const int nch = (n + 63) >> 6;
-    int lo = c0 - 1, hi = c0 + 1;
-    for (int step = 0; (lo >= 0 || hi < nch) && cnt <= nb; step++) {
-      if (step == 1 && n > RF_LONG) {
-        int h = 0;
-        if (lane == 0) h = atomicAdd(&queue[1], 1);
-        h = __builtin_amdgcn_readfirstlane(h);
-        if ((long long)nq + h + 1 <= pool_cap) {           // room left (always, in practice)
-          if (lane == 0) {
-            queue[2 + 2 * (pool_cap - 1 - h)] = s;
-            queue[3 + 2 * (pool_cap - 1 - h)] = q;
-          }
-          handed = true;
-          break;
+      if (in) {
+        const float4 o = pq[g];
+        const float dx = qf.x - o.x, dy = qf.y - o.y, dz = qf.z - o.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        hit = d2 < lo2;
+        if (!hit && !(d2 > hi2)) {                   // too close to call in float32
+          const double ex = x - px[g], ey = y - py[g], ez = z - pz[g];
+          double d = ex * ex;
+          d += ey * ey;
+          d += ez * ez;
+          hit = d < r2;
         }
       }
-      double cx[RU], cy[RU], cz[RU];
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        int c;                                            // uniform: next chunk above / below in turn
-        if (u & 1) c = (lo >= 0) ? lo-- : ((hi < nch) ? hi++ : -1);
-        else c = (hi < nch) ? hi++ : ((lo >= 0) ? lo-- : -1);
-        const int j = (c << 6) + lane;
-        const bool ok = (c >= 0) && (j < n);
-        cx[u] = ok ? px[base + j] : __builtin_nan("");
-        cy[u] = ok ? py[base + j] : 0.0;
-        cz[u] = ok ? pz[base + j] : 0.0;
+      cnt += __popcll(__ballot(hit));
+    };
+    const long long c_own = i >> 6;
+    test_chunk(c_own);                               // the query itself is counted here (d = 0 < r2)
+    const long long c_lo = base >> 6, c_hi = (end - 1) >> 6;
+    for (long long c0 = c_lo; c0 <= c_hi && cnt <= nb; c0 += 64) {
+      const long long c = c0 + lane;
+      bool cand = false;
+      if (c <= c_hi && c != c_own) {
+        const float4 *bp = (const float4 *)(boxes + (size_t)c * BOX_FLOATS);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        cand = box_dist2(qf.x, qf.y, qf.z, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y) <= hi2 ||
+               box_dist2(qf.x, qf.y, qf.z, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w) <= hi2;
       }
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        const double dx = x - cx[u], dy = y - cy[u], dz = z - cz[u];
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        cnt += __popcll(__ballot(d < r2));                 // NaN never compares below r2
+      unsigned long long m = __ballot(cand);
+      while (m && cnt <= nb) {                       // uniform: the candidate chunks of this step, one by one
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        test_chunk(c0 + k);
       }
     }
-    if (lane == 0 && !handed) flags[base + q] = (cnt > nb) ? 1 : 0;
+    if (lane == 0) flags[i] = (cnt > nb) ? 1 : 0;
   }
 }
 
-// Phase B': one workgroup per query that is (almost surely) isolated in a long
-// segment: 1024 candidates per step, leaves (all waves together) as soon as the
-// count is reached.
-__global__ __launch_bounds__(256) void k_radius_resolve_long(
-    const double *__restrict__ px, const double *__restrict__ py,
-    const double *__restrict__ pz, const long long *__restrict__ seg_base,
-    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb,
-    uint8_t *__restrict__ flags, const int *__restrict__ queue, long long pool_cap) {
-  __shared__ int s_cnt;
-  const int nq = queue[0];
-  long long nh = queue[1];
-  if (nh > pool_cap - nq) nh = pool_cap - nq;             // entries beyond that were resolved inline
-  const int lane = lane_id();
-  for (long long e = blockIdx.x; e < nh; e += gridDim.x) {
-    const int s = queue[2 + 2 * (pool_cap - 1 - e)], q = queue[3 + 2 * (pool_cap - 1 - e)];
-    const int n = seg_cnt[s];
-    const long long base = seg_base[s];
-    const double r = radius[s], r2 = r * r;
-    const double x = px[base + q], y = py[base + q], z = pz[base + q];
-    if (threadIdx.x == 0) s_cnt = 1;                      // the query itself (d = 0 < r2)
-    __syncthreads();
-    // outwards from the query: per step 512 list positions above and 512 below it
-    constexpr int RU = 4;
-    int c = 1;
-    const int reach = max(q, n - 1 - q);
-    for (int k0 = 0; k0 < reach && c <= nb; k0 += 512) {
-      double cx[RU], cy[RU], cz[RU];
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        const int off = k0 + 1 + (u >> 1) * 256 + (int)threadIdx.x;     // 1 .. 512 beyond k0
-        const int j = (u & 1) ? q - off : q + off;
-        const bool ok = (j >= 0) && (j < n);
-        cx[u] = ok ? px[base + j] : __builtin_nan("");
-        cy[u] = ok ? py[base + j] : 0.0;
-        cz[u] = ok ? pz[base + j] : 0.0;
-      }
-      int h = 0;
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        const double dx = x - cx[u], dy = y - cy[u], dz = z - cz[u];
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        h += __popcll(__ballot(d < r2));
-      }
-      if (lane == 0 && h) atomicAdd(&s_cnt, h);
-      __syncthreads();
-      c = s_cnt;                                         // the same value for every thread ...
-      __syncthreads();                                   // ... because nobody adds before all have read
-    }
-    if (threadIdx.x == 0) flags[base + q] = (c > nb) ? 1 : 0;
+// standalone use of the filter (no k_seg_write in front): float32 shadow of the given segments
+__global__ __launch_bounds__(QT) void k_shadow_build(
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt,
+    const double *__restrict__ radius, int S, const int *__restrict__ tile_off, float4 *__restrict__ pq) {
+  const int ntile = tile_off[S];
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int s = find_segment(tile_off, S, t);
+    const int q = (t - tile_off[s]) * QT + threadIdx.x;
+    if (q >= seg_cnt[s]) continue;
+    const long long i = seg_base[s] + q;
+    pq[i] = make_float4((float)px[i], (float)py[i], (float)pz[i], __uint_as_float(shadow_word(s, radius[s])));
   }
+}
+
+// in-place ordered compaction of SHORT lists (the per-instance LiDAR lists): one wave per segment
+__global__ __launch_bounds__(256) void k_seg_compact_short(
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+    const long long *__restrict__ seg_base, int *__restrict__ seg_cnt, const uint8_t *__restrict__ flags, int S) {
+  const int s = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (s >= S) return;
+  const int n = seg_cnt[s];
+  if (n == 0) return;
+  const long long base = seg_base[s];
+  const int lane = lane_id();
+  int running = 0;
+  for (int t0 = 0; t0 < n; t0 += 64) {
+    const int i = t0 + lane;
+    const bool f = (i < n) && flags[base + i];
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (f) { x = px[base + i]; y = py[base + i]; z = pz[base + i]; }
+    const unsigned long long m = __ballot(f);
+    if (f) {                                        // dst <= src of every lane: loads above come first
+      const long long d = base + running + __popcll(m & ((1ull << lane) - 1ull));
+      px[d] = x; py[d] = y; pz[d] = z;
+    }
+    running += __popcll(m);
+  }
+  if (lane == 0) seg_cnt[s] = running;
 }
 
 // ---------------------------------------------------------------- a12 ball query
@@ -734,67 +836,83 @@ extern "C" int dfu3d_segments_build(
     const double *b_y, const double *b_z, const int32_t *b_n, int32_t b_cap, int32_t V,
     int32_t max_inst, int64_t pool_cap, int64_t *pool_cursor, double *px, double *py,
     double *pz, int64_t *base_a, int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
-    uint32_t *status, void *stream) {
+    uint32_t *status, const double *rad_a, const double *rad_b, void *shadow, int64_t *base_ab,
+    int32_t *cnt_ab, double *rad_ab, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!a_bits || !a_x || !a_y || !a_z || !a_n || !b_bits || !b_x || !b_y || !b_z || !b_n ||
       !pool_cursor || !px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !status)
     return DFU3D_EINVAL;
   if (V <= 0 || max_inst <= 0 || a_cap <= 0 || b_cap <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
-  hipStream_t st = (hipStream_t)stream;
+  if ((shadow || base_ab) && (!rad_a || !rad_b)) return DFU3D_EINVAL;
+  if (base_ab && (!cnt_ab || !rad_ab)) return DFU3D_EINVAL;
   const int S = V * max_inst;
+  if (shadow && 2 * (int64_t)S >= (int64_t)RF_NOSEG) return DFU3D_ERANGE;   // 16-bit segment ids in the shadow
+  if (shadow && ((uintptr_t)shadow & 15u)) return DFU3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b);
   DFU3D_LAUNCH_CHECK();
+  const JointSegs J = {(long long *)base_ab, cnt_ab, rad_ab, rad_a, rad_b};
   hipLaunchKernelGGL(k_seg_alloc, dim3(1), dim3(1024), 0, st, S, cnt_a, cnt_b,
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
-                     (long long *)pool_cursor, status);
+                     (long long *)pool_cursor, status, J);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
-                     max_inst, (const long long *)base_a, cnt_a, px, py, pz);
+                     max_inst, (const long long *)base_a, cnt_a, px, py, pz, (float4 *)shadow, rad_a, 0);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
-                     max_inst, (const long long *)base_b, cnt_b, px, py, pz);
+                     max_inst, (const long long *)base_b, cnt_b, px, py, pz, (float4 *)shadow, rad_b, S);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
 
 extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int64_t *seg_base,
                                    int32_t *seg_cnt, const double *radius, int32_t nb_points,
-                                   int32_t S, int64_t pool_cap, int32_t *tile_off,
-                                   uint8_t *flags, int32_t *queue, int32_t phases,
+                                   int32_t S, int64_t pool_cap, const int64_t *n_used, void *shadow,
+                                   int32_t *tile_off, uint8_t *flags, int32_t *queue, int32_t phases,
                                    void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
-  if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags || !queue)
+  if (!px || !py || !pz || !seg_base || !seg_cnt || !radius || !tile_off || !flags || !queue || !shadow)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || nb_points < 0) return DFU3D_EINVAL;
+  if (pool_cap >= (1ll << 31) - 2) return DFU3D_ERANGE;            // queue entries are int32 positions
+  if ((int64_t)S >= (int64_t)RF_NOSEG) return DFU3D_ERANGE;         // 16-bit segment ids in the shadow
+  if ((uintptr_t)shadow & 15u) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (phases & DFU3D_RF_TILES) {
-    if (hipMemsetAsync(queue, 0, 2 * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
+  float4 *pq = (float4 *)shadow;
+  float *boxes = (float *)(pq + pool_cap);           // 12 floats per 64 pool slots, behind the shadow proper
+  if (phases & DFU3D_RF_SHADOW) {
+    // positions outside the given segments carry the "no segment" mark (all bits set)
+    if (hipMemsetAsync(pq, 0xFF, sizeof(float4) * (size_t)pool_cap, st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, QT);
+    DFU3D_LAUNCH_CHECK();
+    const int g = tile_grid(pool_cap, S);
+    hipLaunchKernelGGL(k_shadow_build, dim3(g < 4096 ? g : 4096), dim3(QT), 0, st, px, py, pz,
+                       (const long long *)seg_base, seg_cnt, radius, S, tile_off, pq);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_FLAGS) {
-    hipLaunchKernelGGL(k_radius_flags, dim3((tile_grid(pool_cap, S) + RF_TPB - 1) / RF_TPB), dim3(QT), 0, st, px, py, pz,
-                       (const long long *)seg_base, seg_cnt, radius, nb_points, S, tile_off, flags,
-                       queue);
+    if (hipMemsetAsync(queue, 0, 2 * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
+    hipLaunchKernelGGL(k_radius_flags, dim3((unsigned)((pool_cap + RF_WG - 1) / RF_WG)), dim3(RFB), 0, st, pq,
+                       (const long long *)n_used, (long long)pool_cap, nb_points, S, flags, queue, boxes);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
-    hipLaunchKernelGGL(k_radius_resolve, dim3(2048), dim3(256), 0, st, px, py, pz,
-                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue,
-                       (long long)pool_cap);
-    DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_radius_resolve_long, dim3(2048), dim3(256), 0, st, px, py, pz,
-                       (const long long *)seg_base, seg_cnt, radius, nb_points, flags, queue,
-                       (long long)pool_cap);
+    hipLaunchKernelGGL(k_radius_resolve, dim3(2048), dim3(256), 0, st, px, py, pz, pq, boxes,
+                       (const long long *)seg_base, seg_cnt, radius, nb_points, S, (long long)pool_cap, flags, queue);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {
-    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
-                       (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
-                       (const int *)nullptr);
+    if (phases & DFU3D_RF_SHORT_LISTS) {
+      hipLaunchKernelGGL(k_seg_compact_short, dim3((S + 3) / 4), dim3(256), 0, st, px, py, pz,
+                         (const long long *)seg_base, seg_cnt, flags, S);
+    } else {
+      hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
+                         (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
+                         (const int *)nullptr);
+    }
     DFU3D_LAUNCH_CHECK();
   }
   return DFU3D_OK;

@@ -11,6 +11,7 @@ RCCL all_gather over xGMI (backend "nccl" on ROCm) or gloo on CPU.
 import os
 from typing import List
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -37,7 +38,53 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def allgather_rows(rows: torch.Tensor, frame_of_view=None) -> torch.Tensor:
+GATHER_COLUMNS = ("frame_idx", "cam", "class", "inst", "cluster", "alpha", "x1", "y1", "x2", "y2",
+                  "h", "w", "l", "x", "y", "z", "ry", "score")
+
+
+def rows_for_gather(rows: torch.Tensor, view_frame, frame_ids, view_cam) -> torch.Tensor:
+    """Engine rows (n,24; column 0 = view index inside the rank's batch, include/dfu3d.h) -> the rows that
+    travel between ranks: (n,18) float64 in GATHER_COLUMNS order.  view_frame (V,) maps a view
+    to its frame inside the batch, frame_ids (F,) that frame to its GLOBAL index, view_cam (V,) to its camera;
+    afterwards a row can be attributed to its frame whatever rank produced it.  (The box numbers stay
+    float64 -- the label files print them at full precision -- instead of 8e's i32/f32 mix.)"""
+    d = rows.device
+    t = lambda a: torch.as_tensor(np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a), device=d)
+    vf, fid, cam = t(view_frame).long(), t(frame_ids).to(torch.float64), t(view_cam).to(torch.float64)
+    out = torch.empty((rows.shape[0], len(GATHER_COLUMNS)), dtype=torch.float64, device=d)
+    if rows.shape[0]:
+        v = rows[:, 0].long()
+        if int(v.min()) < 0 or int(v.max()) >= vf.numel():
+            raise ValueError("row with a view index outside the batch")
+        out[:, 0] = fid[vf[v]]
+        out[:, 1] = cam[v]
+        out[:, 2] = rows[:, 3]
+        out[:, 3] = rows[:, 1]
+        out[:, 4] = rows[:, 2]
+        out[:, 5:18] = rows[:, 4:17]
+    return out
+
+
+def write_manifest(path, gathered: torch.Tensor, n_frames_total: int, world: int, extra=None):
+    """Rank 0's summary of a sharded run: frames, boxes, boxes per rank (frame_idx % world == rank, the
+    interleave of shard_frames) and per class."""
+    import json
+    g = gathered.cpu().numpy() if isinstance(gathered, torch.Tensor) else np.asarray(gathered)
+    fr = g[:, 0].astype(np.int64) if g.shape[0] else np.zeros((0,), np.int64)
+    man = {"frames": int(n_frames_total), "world_size": int(world), "boxes": int(g.shape[0]),
+           "frames_with_boxes": int(np.unique(fr).size),
+           "boxes_per_rank": [int((fr % world == r).sum()) for r in range(world)],
+           "boxes_per_class": {str(int(c)): int(n) for c, n in zip(*np.unique(g[:, 2].astype(np.int64), return_counts=True))}
+           if g.shape[0] else {},
+           "columns": list(GATHER_COLUMNS)}
+    if extra:
+        man.update(extra)
+    with open(path, "w") as f:
+        json.dump(man, f, indent=1)
+    return man
+
+
+def allgather_rows(rows: torch.Tensor) -> torch.Tensor:
     """rows (n_r, C) on every rank -> (sum n_r, C) on every rank, rank-major.
 
     Two collectives: one all_gather of the int64 row count, one all_gather of

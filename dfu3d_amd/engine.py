@@ -105,6 +105,7 @@ class PseudoBoxEngine:
         # optional per-kernel timing with HIP events on the launch stream
         self.timing = False
         self._events = []
+        self._counts = {}
 
 
     class _Lane:
@@ -152,7 +153,8 @@ class PseudoBoxEngine:
             L.base_ab = torch.empty(2 * S, dtype=torch.int64, device=d)
             L.cnt_ab = i32(2 * S)
             L.rad_ab = f64(2 * S)
-            L.queue = i32(2 + 2 * pc)
+            L.queue = i32(2 + pc)
+            L.shadow = torch.empty(st.shadow_floats(pc), dtype=torch.float32, device=d)
             L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
             L.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
             L.rf_points = torch.zeros(1, dtype=torch.int64, device=d)   # timing mode only
@@ -221,11 +223,22 @@ class PseudoBoxEngine:
 
     def reset_timing(self):
         self._events = []
+        self._counts = {}
         for L in self.lanes:
             L.rf_points.zero_()
 
     def rf_points_total(self):
         return int(sum(int(L.rf_points.item()) for L in self.lanes))
+
+    def _count(self, name, t):
+        """timing mode: accumulate a device-side count (units of the algorithmic byte figures)."""
+        if self.timing:
+            v = t.sum().to(torch.int64) if isinstance(t, torch.Tensor) else torch.tensor(int(t), device=self.dev)
+            self._counts[name] = self._counts.get(name, 0) + v
+
+    def counters(self):
+        """-> {name: total over the bracketed passes}; synchronises."""
+        return {k: int(v.item()) if isinstance(v, torch.Tensor) else int(v) for k, v in getattr(self, "_counts", {}).items()}
 
     # ------------------------------------------------------------------
     def _chunk_chain(self, b: ViewBatch, v0: int, v1: int, rows, n_rows, status):
@@ -296,54 +309,64 @@ class PseudoBoxEngine:
                          n_inst, V, M, H, W, cap_n, p.plane_offset,
                          p.plane_range, self.ag_pt, self.ib_pix, self.n_ag, self.K, self.a_bits,
                          self.a_x, self.a_y, self.a_z, mask_format=b.mask_format, bounds_hw=p.bounds_hw)
+        self._count("fov_points", self.n_fov)
+        self._count("label_rows", self.K)
         if self.dense and b.depth is not None:
             self._phased("bp_", st.backproject_bin,
-                         (("bin", st.BP_BIN), ("mark", st.BP_MARK), ("vox", st.BP_VOX), ("repair", st.BP_REPAIR)),
+                         (("bin", st.BP_BIN), ("amb", st.BP_AMB), ("mark", st.BP_MARK), ("vox", st.BP_VOX),
+                          ("repair", st.BP_REPAIR)),
                          b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
                          self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
                          self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
                          self.b_z, status, mask_format=b.mask_format)
+            self._count("voxels", self.n_vox)
+            self._count("amb_pixels", self.blk_cnt[:2 * V].view(torch.int64) & 0xFFFFFFFF)
         else:
             self.n_vox.zero_()
         self.pool_cursor.zero_()
+        rl = b.inst_r_lidar[v0:v1].reshape(-1)
+        rp = b.inst_r_pseudo[v0:v1].reshape(-1)
+        fused = not p.stat_filter
         R("segments_build", st.segments_build, self.a_bits, self.a_x, self.a_y, self.a_z, self.K, cap_n, self.b_bits,
                           self.b_x, self.b_y, self.b_z, self.n_vox, self.cap_vox, V, M,
                           self.pool_cap, self.pool_cursor, self.px, self.py, self.pz,
-                          self.base_a, self.cnt_a, self.base_b, self.cnt_b, status)
-        rl = b.inst_r_lidar[v0:v1].reshape(-1)
-        rp = b.inst_r_pseudo[v0:v1].reshape(-1)
-        rf_ph = (("tiles", st.RF_TILES), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE),
-                 ("compact", st.RF_COMPACT))
+                          self.base_a, self.cnt_a, self.base_b, self.cnt_b, status,
+                          rad_a=rl.contiguous(), rad_b=rp.contiguous(), shadow=self.shadow if fused else None,
+                          base_ab=self.base_ab if fused else None, cnt_ab=self.cnt_ab, rad_ab=self.rad_ab)
         if self.timing:
             self.rf_points += self.cnt_a.sum() + self.cnt_b.sum()
-        fused = not p.stat_filter
+        self._count("pool_points", self.pool_cursor)
         if fused:
-            # ONE flag pass over the LiDAR and the pseudo lists of all instances (2S segments);
-            # the LiDAR lists are compacted in place, the pseudo lists stay as they are -- the
-            # fuse below compacts them once for both filters (dfu3d_ballquery_fuse_masked)
-            torch.cat((self.base_a, self.base_b), out=self.base_ab)
-            torch.cat((self.cnt_a, self.cnt_b), out=self.cnt_ab)
-            torch.cat((rl, rp), out=self.rad_ab)
-            self._phased("rf_", st.radius_filter, rf_ph[:3], self.px, self.py, self.pz, self.base_ab,
-                         self.cnt_ab, self.rad_ab, p.nb_points, 2 * S, self.pool_cap, self.tile_off,
-                         self.flags, self.queue)
+            # ONE pass over the LiDAR and the pseudo lists of all instances (2S segments) on the float32
+            # shadow written by the segment build; the LiDAR lists are compacted in place, the pseudo lists
+            # keep their flags -- the fuse below compacts them once for both filters
+            self._phased("rf_", st.radius_filter, (("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE)),
+                         self.px, self.py, self.pz, self.base_ab, self.cnt_ab, self.rad_ab, p.nb_points, 2 * S,
+                         self.pool_cap, self.tile_off, self.flags, self.queue, shadow=self.shadow,
+                         n_used=self.pool_cursor)
             self._run("rf_compact", st.radius_filter, self.px, self.py, self.pz, self.base_a, self.cnt_a,
                       rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags, self.queue,
-                      phases=st.RF_COMPACT)
+                      phases=st.RF_COMPACT | st.RF_SHORT_LISTS, shadow=self.shadow, n_used=self.pool_cursor)
         else:           # the (dormant) statistical filter sits in between and needs the filtered lists
+            rf_ph = (("shadow", st.RF_SHADOW), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE),
+                     ("compact", st.RF_COMPACT))
             self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_a,
                          self.cnt_a, rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
-                         self.queue)
+                         self.queue, shadow=self.shadow, n_used=self.pool_cursor)
             self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_b,
                          self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
-                         self.queue)
+                         self.queue, shadow=self.shadow, n_used=self.pool_cursor)
         if p.stat_filter:
             R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
                            self.tile_off, self.flags, self.mean_d)
+        self._count("rf_undecided", self.queue[0:1])
+        self._count("ball_points", self.cnt_a)
+        self._count("ball_points", self.cnt_b)
         R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
                           self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags, masked=fused)
         torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
+        self._count("instance_points", self.cnt_all)
         R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0,
           p.Rd, self.label, self.pool_cap, self.sx, self.sy, self.si3)
         R("lshape_fit", st.lshape_fit, self.px, self.py, self.pz, self.label, self.base_a, self.cnt_all, S, M,
@@ -444,6 +467,18 @@ class PseudoBoxEngine:
                            self.b_z, status)
         xyz = torch.stack([self.b_x, self.b_y, self.b_z], 1).view(V, self.cap_vox, 3)
         return self.n_vox.clone(), self.vox_pix.view(V, self.cap_vox).clone(), xyz, int(status.item())
+
+    def gather_layout(self, rows, b: ViewBatch):
+        """Engine rows (n,24) -> (n,18) rows carrying the GLOBAL frame index and the camera (dist.rows_for_gather)."""
+        from .dist import rows_for_gather
+        V = b.view_frame.numel()
+        fid = b.frame_ids if b.frame_ids is not None else np.arange(b.pt_off.numel() - 1)
+        if b.view_cam is not None:
+            cam = b.view_cam
+        else:                                   # position of the view among the views of its frame
+            vf = np.asarray(b.host_view_frame)
+            cam = np.array([int((vf[:i] == vf[i]).sum()) for i in range(V)], np.int64)
+        return rows_for_gather(rows, b.host_view_frame, fid, cam)
 
     def collect(self):
         rows, n_rows, status = self._last

@@ -72,8 +72,11 @@ def main(argv=None):
     depth_dir = args.depth_dir or os.path.join(args.detpath, 'depth_2')
     label_out = args.label_out or os.path.join(args.detpath, 'label_2')
     t0 = time.time()
+    n_assigned = len(mine)
     if args.skip_existing:
         mine = [s for s in mine if not os.path.exists(os.path.join(label_out, s + '.txt'))]
+    frame_index = {s: i for i, s in enumerate(frames)}     # global index of a frame = its place in the sorted list
+    rows_log = []                                           # (stem, engine rows) of every frame this rank labelled
     if args.batch_frames > 0:
         from ..pipeline import BatchedLabeler
         lab = BatchedLabeler(batch_frames=max(1, min(args.batch_frames, len(mine))), lanes=args.streams,
@@ -81,6 +84,7 @@ def main(argv=None):
                              device="cuda:%d" % (local if world > 1 else 0),
                              want_points=not args.no_virtual_points, reader_pool=rpool)
         stats = lab.run(args.detpath, mine, label_out, depth_dir, seg_dir=args.seg_dir)
+        rows_log += lab.rows_log
         lab.close()
         if rank == 0:
             dt = time.time() - t0
@@ -92,13 +96,42 @@ def main(argv=None):
             continue
         depth = np.load(os.path.join(depth_dir, idx + '.npy')).astype(np.float32)
         from .vis_utils import load_seg_npz
-        save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
-                             seg_provider=(lambda path, _i=idx: load_seg_npz(args.detpath, _i, args.seg_dir)),
-                             device="cuda:%d" % (local if world > 1 else 0))
+        _, r = save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
+                                    seg_provider=(lambda path, _i=idx: load_seg_npz(args.detpath, _i, args.seg_dir)),
+                                    device="cuda:%d" % (local if world > 1 else 0), return_rows=True)
+        rows_log.append((idx, r))
         if rank == 0 and (k + 1) % 10 == 0:
             print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))
     if rpool is not None:
         rpool.close()
+    # the one collective of the path: variable-length all-gather of the box rows, each carrying its
+    # global frame index; rank 0 writes the manifest of the run next to the label files
+    import torch
+    dev = torch.device("cuda:%d" % (local if world > 1 else 0)) if torch.cuda.is_available() else torch.device("cpu")
+    parts = []
+    for stem, r in rows_log:
+        r = np.asarray(r, np.float64).reshape(-1, 24)
+        if r.shape[0]:
+            loc = torch.as_tensor(r, device=dev).clone()
+            loc[:, 0] = 0
+            parts.append(D.rows_for_gather(loc, [0], [frame_index[stem]], [0]))
+    mine_rows = torch.cat(parts, 0) if parts else torch.zeros((0, len(D.GATHER_COLUMNS)), dtype=torch.float64, device=dev)
+    gathered = D.allgather_rows(mine_rows)
+    if world > 1:
+        import torch.distributed as dist
+        cnt = torch.tensor([len(rows_log), n_assigned], dtype=torch.int64,
+                           device=dev if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(cnt)
+        n_labelled, n_total = int(cnt[0]), int(cnt[1])
+    else:
+        n_labelled, n_total = len(rows_log), n_assigned
+    if rank == 0:
+        os.makedirs(label_out, exist_ok=True)
+        man = D.write_manifest(os.path.join(label_out, "manifest.json"), gathered, n_total, world,
+                               extra={"frames_labelled_this_run": n_labelled, "seconds": round(time.time() - t0, 3),
+                                      "detpath": os.path.abspath(args.detpath)})
+        print("manifest: %d frames (%d labelled now), %d boxes, per rank %s" % (
+            man["frames"], n_labelled, man["boxes"], man["boxes_per_rank"]))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

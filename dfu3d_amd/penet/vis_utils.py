@@ -39,7 +39,7 @@ def get_fov_flag_gpu(lidar, calib, img_shape, device="cuda:0"):
 
 
 def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=None, params=None,
-                         crop_hw=None, device="cuda:0"):
+                         crop_hw=None, device="cuda:0", return_rows=False):
     """vis_utils.py:136-166.  `idx` is the frame id (int -> zero-padded to 6, or a
     file stem); `crop_hw` reproduces the shipped [:352,:1216] crop (hazard H11),
     default: no crop (canonical nuScenes 900x1600)."""
@@ -56,18 +56,24 @@ def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=No
     seg = (seg_provider or (lambda path: load_seg_npz(root_path, file_idx)))(file_image_path)
     thing_classes, masks, classes, scores, boxes2D = seg              # :150
     H, W = image.shape[0], image.shape[1]
-    lidar = lidar[get_fov_flag_gpu(lidar, calib, (H, W), device)]     # :152-154
+    lidar = lidar[get_fov_flag_gpu(lidar, calib, (H, W), device)]     # :152-154: FOV test on the (cropped) image size
     paths = os.path.join(root_path, 'velodyne_depth')                 # :156-160
     os.makedirs(paths, exist_ok=True)
     out_path = os.path.join(paths, file_idx + '.npy')
     if isinstance(depth, torch.Tensor):
         depth = depth.detach().cpu().numpy()
     depth = np.ascontiguousarray(depth, np.float32).reshape(-1)[:H * W].reshape(H, W, 1)   # :161
-    if tuple(p.bounds_hw) != (H, W) or tuple(p.fov_hw) != (H, W):
-        p = Params(**{**p.__dict__, "bounds_hw": (H, W), "fov_hw": (H, W)})
-    final_points = depth2pointsrgbpm(depth, image, image1, calib, lidar, thing_classes,
-                                     np.asarray(masks)[:, :H, :W], classes, scores, boxes2D, None,
-                                     file_idx, label_root=label_root or os.path.join(root_path, 'label_2'),
-                                     params=p, device=device)       # :163
+    if crop_hw is None:
+        # canonical nuScenes (hazard H11): every size is the image size
+        if tuple(p.bounds_hw) != (H, W) or tuple(p.fov_hw) != (H, W):
+            p = Params(**{**p.__dict__, "bounds_hw": (H, W), "fov_hw": (H, W)})
+    else:
+        # the shipped mix: FOV filter and depth on the crop, masks at their own size, bounds as in `params`
+        # (my_loader.py:526 hard-codes 1600x900)
+        p = Params(**{**p.__dict__, "fov_hw": (H, W)})
+    final_points, rows = depth2pointsrgbpm(depth, image, image1, calib, lidar, thing_classes,
+                                           np.asarray(masks), classes, scores, boxes2D, None,
+                                           file_idx, label_root=label_root or os.path.join(root_path, 'label_2'),
+                                           params=p, device=device, return_rows=True)       # :163
     np.save(out_path, final_points.astype(np.float16))                # :164-166
-    return out_path
+    return (out_path, rows) if return_rows else out_path

@@ -109,6 +109,7 @@ class BatchedLabeler:
         self._shm = {}
         self.seg_dir = None
         self.stats = {"frames": 0, "boxes": 0, "t_read": 0.0, "t_pack": 0.0, "t_wait": 0.0, "t_gpu": 0.0}
+        self.rows_log = []          # (stem, engine rows of that frame) for the run's manifest / row gather
 
     # ------------------------------------------------------------------
     def _engine(self, H, W, M):
@@ -410,6 +411,8 @@ class BatchedLabeler:
             pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp))
             self.stats["frames"] += len(frames)
             self.stats["boxes"] += int(rows_h.shape[0])
+            for i, f in enumerate(frames):
+                self.rows_log.append((f.stem, rows_h[rows_h[:, 0] == i]))
         for p_ in pending:
             p_.result()
         for ex in (pool, prep, writers):

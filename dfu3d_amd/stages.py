@@ -18,9 +18,9 @@ CALIB_FLOATS = 48
 ROW_DOUBLES = 24
 MAX_INST = 32
 
-BP_BIN, BP_MARK, BP_VOX, BP_REPAIR, BP_ALL = 1, 2, 4, 8, 15
+BP_BIN, BP_AMB, BP_MARK, BP_VOX, BP_REPAIR, BP_ALL = 1, 2, 4, 8, 16, 31
 MASK_BYTES = 0
-RF_TILES, RF_FLAGS, RF_COMPACT, RF_RESOLVE, RF_ALL = 1, 2, 4, 8, 15
+RF_SHADOW, RF_FLAGS, RF_RESOLVE, RF_COMPACT, RF_ALL, RF_SHORT_LISTS = 1, 2, 4, 8, 15, 16
 
 ST_POOL_OVERFLOW = 1
 ST_VOX_OVERFLOW = 2
@@ -223,10 +223,19 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
     _lib.check(rc, "dfu3d_backproject_bin")
 
 
+def shadow_floats(pool_cap):
+    """float32 elements of the radius filter's shadow scratch (DFU3D_SHADOW_BYTES / 4)."""
+    return 4 * pool_cap + 12 * ((pool_cap + 63) // 64 + 1)
+
+
 def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n, b_cap, V,
                    max_inst, pool_cap, pool_cursor, px, py, pz, base_a, cnt_a, base_b, cnt_b,
-                   status):
+                   status, rad_a=None, rad_b=None, shadow=None, base_ab=None, cnt_ab=None, rad_ab=None):
+    """rad_a / rad_b + shadow (+ the joint 2S segment table): everything the one-pass radius filter needs."""
     S = V * max_inst
+    opt = lambda t, name, dt, n: None if t is None else _chk(t, name, dt, numel=n)
+    if shadow is not None and shadow.data_ptr() % 16:
+        raise Dfu3dError("shadow: must be 16-byte aligned")
     rc = _lib.lib().dfu3d_segments_build(
         _chk(a_bits, "a_bits", torch.int32, numel=V * a_cap),
         _chk(a_x, "a_x", torch.float64, numel=V * a_cap),
@@ -241,21 +250,31 @@ def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n
         _chk(pz, "pz", torch.float64, numel=pool_cap),
         _chk(base_a, "base_a", torch.int64, numel=S), _chk(cnt_a, "cnt_a", torch.int32, numel=S),
         _chk(base_b, "base_b", torch.int64, numel=S), _chk(cnt_b, "cnt_b", torch.int32, numel=S),
-        _chk(status, "status", torch.int32, min_numel=1), _stream())
+        _chk(status, "status", torch.int32, min_numel=1),
+        opt(rad_a, "rad_a", torch.float64, S), opt(rad_b, "rad_b", torch.float64, S),
+        opt(shadow, "shadow", torch.float32, shadow_floats(pool_cap)), opt(base_ab, "base_ab", torch.int64, 2 * S),
+        opt(cnt_ab, "cnt_ab", torch.int32, 2 * S), opt(rad_ab, "rad_ab", torch.float64, 2 * S), _stream())
     _lib.check(rc, "dfu3d_segments_build")
 
 
 def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap, tile_off, flags,
-                  queue, phases=RF_ALL):
+                  queue, phases=RF_ALL, shadow=None, n_used=None):
+    """shadow: float32 (4*pool_cap) scratch (allocated here when omitted); n_used: device int64 (1,) or None."""
+    if shadow is None:
+        shadow = torch.empty(shadow_floats(pool_cap), dtype=torch.float32, device=px.device)
+    if shadow.data_ptr() % 16:
+        raise Dfu3dError("shadow: must be 16-byte aligned")
     rc = _lib.lib().dfu3d_radius_filter(
         _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
         _chk(pz, "pz", torch.float64, numel=pool_cap),
         _chk(seg_base, "seg_base", torch.int64, numel=S),
         _chk(seg_cnt, "seg_cnt", torch.int32, numel=S),
         _chk(radius, "radius", torch.float64, numel=S), int(nb_points), S, pool_cap,
+        None if n_used is None else _chk(n_used, "n_used", torch.int64, numel=1),
+        _chk(shadow, "shadow", torch.float32, numel=shadow_floats(pool_cap)),
         _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
         _chk(flags, "flags", torch.uint8, numel=pool_cap),
-        _chk(queue, "queue", torch.int32, min_numel=2 + 2 * pool_cap), int(phases), _stream())
+        _chk(queue, "queue", torch.int32, min_numel=2 + pool_cap), int(phases), _stream())
     _lib.check(rc, "dfu3d_radius_filter")
 
 
@@ -343,7 +362,33 @@ def boxes_bev(boxes_a, boxes_b, iou=True):
     return out
 
 
-def nms_bev(boxes, thresh):
+def boxes_bev_paired(boxes_a, boxes_b, iou=True):
+    """(N,7),(N,7) -> (N,) overlap area / BEV IoU of row i with row i."""
+    n = int(boxes_a.shape[0])
+    if int(boxes_b.shape[0]) != n:
+        raise Dfu3dError("paired overlap needs as many boxes on both sides")
+    out = torch.zeros((n,), dtype=torch.float32, device=boxes_a.device)
+    if n:
+        rc = _lib.lib().dfu3d_boxes_bev_paired(_chk(boxes_a, "boxes_a", torch.float32, numel=n * 7),
+                                               _chk(boxes_b, "boxes_b", torch.float32, numel=n * 7), n,
+                                               _chk(out, "out", torch.float32, numel=n), 1 if iou else 0, _stream())
+        _lib.check(rc, "dfu3d_boxes_bev_paired")
+    return out
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """(N,5),(K,5) float32 CUDA [cx cy w h angle] -> (N,K): the AP evaluator's rotated IoU (dfu3d_rotate_iou_eval)."""
+    n, k = int(boxes.shape[0]), int(query_boxes.shape[0])
+    out = torch.zeros((n, k), dtype=torch.float32, device=boxes.device)
+    if n and k:
+        rc = _lib.lib().dfu3d_rotate_iou_eval(_chk(boxes, "boxes", torch.float32, numel=n * 5), n,
+                                              _chk(query_boxes, "query_boxes", torch.float32, numel=k * 5), k,
+                                              _chk(out, "out", torch.float32, numel=n * k), int(criterion), _stream())
+        _lib.check(rc, "dfu3d_rotate_iou_eval")
+    return out
+
+
+def nms_bev(boxes, thresh, normal=False):
     """boxes (N,7) float32 CUDA sorted by descending score -> (keep int64 (N,), number kept)."""
     n = int(boxes.shape[0])
     dev = boxes.device
@@ -352,9 +397,10 @@ def nms_bev(boxes, thresh):
         return keep[:0], 0
     num = torch.zeros(1, dtype=torch.int32, device=dev)
     mask = torch.empty(max(n * ((n + 63) // 64), 1), dtype=torch.int64, device=dev)
-    rc = _lib.lib().dfu3d_nms_bev(_chk(boxes, "boxes", torch.float32, numel=n * 7), n, ctypes.c_float(thresh),
-                                  _chk(mask, "mask", torch.int64, min_numel=1), _chk(keep, "keep", torch.int64, min_numel=1),
-                                  _chk(num, "num_keep", torch.int32, numel=1), _stream())
+    fn = _lib.lib().dfu3d_nms_normal_bev if normal else _lib.lib().dfu3d_nms_bev
+    rc = fn(_chk(boxes, "boxes", torch.float32, numel=n * 7), n, ctypes.c_float(thresh),
+            _chk(mask, "mask", torch.int64, min_numel=1), _chk(keep, "keep", torch.int64, min_numel=1),
+            _chk(num, "num_keep", torch.int32, numel=1), _stream())
     _lib.check(rc, "dfu3d_nms_bev")
     return keep, int(num.item())
 

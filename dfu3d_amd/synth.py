@@ -197,18 +197,20 @@ def make_scene(seed: int, H=900, W=1600, M=8, cams=6, dense=True, device="cpu", 
                  torch.stack(sl), torch.tensor(boxes))
 
 
-def to_view_batch(scenes: List[Scene], params: Params, device, dense=True, thing_classes=None):
-    """Pack scenes (frames) into the engine's ViewBatch on `device`."""
+def to_view_batch(scenes: List[Scene], params: Params, device, dense=True, thing_classes=None, frame_ids=None):
+    """Pack scenes (frames) into the engine's ViewBatch on `device`.  frame_ids: the global index of every scene
+    (default 0..len-1) -- what the gathered box rows carry."""
     from .engine import ViewBatch
     thing_classes = thing_classes or NUSC_CLASSES
     dev = torch.device(device)
     pts = torch.cat([s.points for s in scenes]).to(dev).contiguous()
     off = np.zeros(len(scenes) + 1, np.int64)
     off[1:] = np.cumsum([s.points.shape[0] for s in scenes])
-    vf, recs = [], []
+    vf, recs, cams = [], [], []
     for f, s in enumerate(scenes):
-        for cal in s.calibs:
+        for c, cal in enumerate(s.calibs):
             vf.append(f)
+            cams.append(c)
             recs.append(cal.record())
     V = len(vf)
     M = scenes[0].masks.shape[1]
@@ -229,4 +231,6 @@ def to_view_batch(scenes: List[Scene], params: Params, device, dense=True, thing
         inst_score=torch.cat([s.inst_score for s in scenes]).to(dev).contiguous(),
         view_key=torch.arange(V, dtype=torch.int64, device=dev),
         host_pt_off=off, host_view_frame=np.array(vf, np.int64),
-        depth=(torch.cat([s.depth for s in scenes]).to(dev).contiguous() if dense else None))
+        depth=(torch.cat([s.depth for s in scenes]).to(dev).contiguous() if dense else None),
+        frame_ids=np.asarray(frame_ids if frame_ids is not None else range(len(scenes)), np.int64),
+        view_cam=np.asarray(cams, np.int64))

@@ -58,6 +58,34 @@ extern "C" {
 int dfu3d_version(void);
 const char *dfu3d_strerror(int code);
 
+/* ---- scratch sizes, uniform over the stages -------------------------------
+ * The library never allocates: every entry point takes its scratch from the caller.
+ * dfu3d_workspace_bytes(stage, sizes) = the bytes of scratch that stage's entry point needs, i.e. the
+ * sum of its scratch arguments (listed with each entry point below), each rounded up to 256 bytes --
+ * one allocation carved in argument order serves the call.  Inputs and outputs are not included.
+ * DFU3D_STAGE_PSEUDO_BOXES = the single workspace of dfu3d_pseudo_boxes (== dfu3d_chain_workspace_bytes).
+ * Returns a negative DFU3D_E* code for an unknown stage or impossible sizes. */
+typedef struct dfu3d_sizes {
+  int32_t V, H, W, max_inst;         /* views per call, mask / depth canvas, instance slots per view */
+  int32_t cap_n, cap_vox, cap_rows;  /* points per frame, voxels per view, box rows per call          */
+  int32_t max_points_per_voxel;      /* 100 (my_loader.py:73)                                        */
+  int64_t pool_cap;                  /* instance pool slots per call                                 */
+  int64_t table_entries;             /* per view, from dfu3d_bin_table_geometry                      */
+  int32_t dense, stat_filter;
+} dfu3d_sizes;
+#define DFU3D_STAGE_FOV_FILTER 0
+#define DFU3D_STAGE_PLANE_RANSAC 1
+#define DFU3D_STAGE_PROJECT_LABEL 2
+#define DFU3D_STAGE_BACKPROJECT_BIN 3
+#define DFU3D_STAGE_SEGMENTS_BUILD 4
+#define DFU3D_STAGE_RADIUS_FILTER 5
+#define DFU3D_STAGE_STAT_FILTER 6
+#define DFU3D_STAGE_BALLQUERY_FUSE 7
+#define DFU3D_STAGE_RANGE_CLUSTER 8
+#define DFU3D_STAGE_LSHAPE_FIT 9
+#define DFU3D_STAGE_PSEUDO_BOXES 10
+int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *sizes);
+
 /* Geometry of the spherical-bin table used by dfu3d_backproject_bin.  Filled by
  * dfu3d_bin_table_geometry from the voxel parameters (my_loader.py:69-83). */
 typedef struct dfu3d_bin_geom {
@@ -160,17 +188,22 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
 /* `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
  * production; single phases let a caller bracket one kernel group with HIP events
  * on its stream).  The phases of one pass must be issued in this order. */
-#define DFU3D_BP_BIN 1     /* k_bp_bin (+ _amb): back-project, bin, table atomics, touched-bin list */
-#define DFU3D_BP_MARK 2    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix   */
-#define DFU3D_BP_VOX 4     /* k_bp_vox: rank, representative, outputs, table reset                 */
-#define DFU3D_BP_REPAIR 8  /* exact repair of bins over the cap / key collisions (no-ops when none) */
-#define DFU3D_BP_ALL 15
+#define DFU3D_BP_BIN 1     /* k_bp_bin: back-project, bin, table atomics, touched-bin list          */
+#define DFU3D_BP_AMB 2     /* k_bp_bin_amb: the pixels float32 could not classify, in fp64           */
+#define DFU3D_BP_MARK 4    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix     */
+#define DFU3D_BP_VOX 8     /* k_bp_vox: rank, representative, outputs, table reset                   */
+#define DFU3D_BP_REPAIR 16 /* exact repair of bins over the cap / key collisions (no-ops when none)  */
+#define DFU3D_BP_ALL 31
 
 /* ---- per-instance point sets (my_loader.py:547-565) ------------------------
  * Builds, for every segment s = v*max_inst + j, the ordered list of LiDAR rows
  * (items A) and voxel representatives (items B) whose bit j is set, in the
  * fp64 pool: [base_a[s], +cnt_a[s]) followed directly by [base_b[s], +cnt_b[s]).
- * pool_cursor: device int64 (in/out) next free pool slot. */
+ * pool_cursor: device int64 (in/out) next free pool slot.
+ * Optional (NULL to skip), for the one-pass radius filter below:
+ *   rad_a / rad_b fp64 (S): the filter radii of the LiDAR / pseudo lists;
+ *   shadow: DFU3D_SHADOW_BYTES(pool_cap), the float32 shadow the filter streams (x, y, z, list | radius);
+ *   base_ab / cnt_ab / rad_ab (2S each): the joint segment table, s < S = LiDAR lists, S+s = pseudo lists. */
 int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
                          const double *a_y, const double *a_z,
                          const int32_t *a_n, int32_t a_cap,
@@ -181,24 +214,34 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
                          int64_t *pool_cursor, double *px, double *py,
                          double *pz, int64_t *base_a, int32_t *cnt_a,
                          int64_t *base_b, int32_t *cnt_b, uint32_t *status,
+                         const double *rad_a, const double *rad_b, void *shadow,
+                         int64_t *base_ab, int32_t *cnt_ab, double *rad_ab,
                          void *stream);
 
 /* ---- a10: Open3D remove_radius_outlier (my_loader.py:581-599) --------------
  * In-place, order-preserving: keeps point i of segment s iff
  * #{j in s : |p_i-p_j|^2 < radius[s]^2, j == i included} > nb_points.
  * radius[s] < 0 drops the whole segment (hazard H4), radius[s] == 0 keeps it.
- * Scratch: tile_off int32 (S+1), flags uint8 (pool_cap), queue int32
- * (2 + 2*pool_cap: undecided (segment, point) pairs between the two kernels). */
+ * The filter streams a float32 SHADOW of the pool (16 B per slot: x, y, z, segment | radius) and
+ * takes only decisions that float32 rounding cannot change; everything else is decided in fp64
+ * from the pool.  Segments must not overlap; S < 65535.
+ * n_used: device int64 = number of pool slots in use (NULL: pool_cap).
+ * Scratch: shadow (DFU3D_SHADOW_BYTES(pool_cap) bytes, 16-byte aligned: 16 B per slot + two bounding boxes
+ * per 64 slots for the second phase), tile_off int32 (S+1), flags uint8
+ * (pool_cap), queue int32 (2 + pool_cap: undecided pool positions between the two kernels). */
 int dfu3d_radius_filter(double *px, double *py, double *pz,
                         const int64_t *seg_base, int32_t *seg_cnt,
                         const double *radius, int32_t nb_points, int32_t S,
-                        int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
+                        int64_t pool_cap, const int64_t *n_used, void *shadow,
+                        int32_t *tile_off, uint8_t *flags,
                         int32_t *queue, int32_t phases, void *stream);
-#define DFU3D_RF_TILES 1    /* k_tile_scan: query-tile list, queue reset        */
-#define DFU3D_RF_FLAGS 2    /* k_radius_flags: list neighbours / own wave       */
-#define DFU3D_RF_COMPACT 4  /* k_seg_compact: ordered in-place compaction       */
-#define DFU3D_RF_RESOLVE 8  /* k_radius_resolve(_long): undecided, whole segment */
+#define DFU3D_SHADOW_BYTES(pool_cap) (16 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 63) / 64 + 1))
+#define DFU3D_RF_SHADOW 1   /* shadow of the given segments (not needed behind dfu3d_segments_build(..., shadow)) */
+#define DFU3D_RF_FLAGS 2    /* k_radius_flags: list neighbours / own wave / own workgroup, float32          */
+#define DFU3D_RF_RESOLVE 4  /* k_radius_resolve: the undecided against their whole segment                   */
+#define DFU3D_RF_COMPACT 8  /* ordered in-place compaction of the given segments                            */
 #define DFU3D_RF_ALL 15
+#define DFU3D_RF_SHORT_LISTS 16 /* hint for COMPACT: one wave per segment (the per-instance LiDAR lists)    */
 
 /* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
  * keep i iff 0 < mean_knn_dist_i < mu + std_ratio * sigma (self included in
@@ -256,20 +299,30 @@ int dfu3d_gt_database(const float *points, const int32_t *pt_off,
                       int32_t *idx_out, float *gt_pts, uint32_t *status,
                       void *stream);
 
-/* ---- f-3: rotated BEV overlap / IoU and rotated NMS --------------------------
- * (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:14-339, iou3d_nms.cpp:120-177)
+/* ---- f-3: overlap of rotated boxes in the ground plane, IoU criteria, rotated NMS -----------
+ * Stands in for pcdet/ops/iou3d_nms (boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu,
+ * iou3d_nms.cpp:120-177) and for the AP evaluator's rotate_iou_gpu_eval
+ * (pcdet/datasets/kitti/kitti_object_eval_python/rotate_iou.py:262-330, numba-CUDA).  The overlap is the EXACT area of
+ * the intersection polygon (clipping in the frame of one box, float32); the reference's kernels over-estimate it by a
+ * thin sliver when a corner lies within their 1e-2 margin outside the other box.
  * boxes: float32 (.,7) [x y z dx dy dz heading].
- * dfu3d_boxes_bev: out float32 (n,m); mode 0 = overlap area (boxes_overlap_bev_gpu),
- * mode 1 = BEV IoU (boxes_iou_bev_gpu).
- * dfu3d_nms_bev: boxes already sorted by descending score (iou3d_nms_utils.nms_gpu
- * does that before the call); keep[0..num_keep) = kept positions in ascending
- * order, box i suppressed iff an earlier kept box j has iou_bev(j,i) > thresh.
- * Scratch: mask uint64 (n * ceil(n/64)).  The walk over the mask runs on the
- * device (the reference copies the mask to the host).  n <= 32768. */
+ * dfu3d_boxes_bev: out float32 (n,m); mode 0 = overlap area, mode 1 = BEV IoU.  _paired: row i with row i, out (n).
+ * dfu3d_rotate_iou_eval: boxes (n,5) / query_boxes (k,5) [cx cy w h angle], out (n,k); criterion -1 = IoU,
+ *   0 = overlap / area(box), 1 = overlap / area(query box), other = overlap   (rotate_iou.py:247-255).
+ * dfu3d_nms_bev / dfu3d_nms_normal_bev (axis-aligned IoU, headings ignored): boxes already sorted by descending
+ * score; keep[0..num_keep) = kept positions in ascending order, box i suppressed iff an earlier kept box j has
+ * IoU(j,i) > thresh.  Scratch: mask uint64 (n * ceil(n/64)); one wave computes one mask word (ballot), the walk over
+ * the mask runs on the device (the reference copies the mask to the host).  n <= 32768. */
 int dfu3d_boxes_bev(const float *boxes_a, int32_t n, const float *boxes_b,
                     int32_t m, float *out, int32_t mode, void *stream);
+int dfu3d_boxes_bev_paired(const float *boxes_a, const float *boxes_b, int32_t n, float *out,
+                           int32_t mode, void *stream);
+int dfu3d_rotate_iou_eval(const float *boxes, int32_t n, const float *query_boxes, int32_t k,
+                          float *out, int32_t criterion, void *stream);
 int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
                   int64_t *keep, int32_t *num_keep, void *stream);
+int dfu3d_nms_normal_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
+                         int64_t *keep, int32_t *num_keep, void *stream);
 
 /* ---- self test of the two-tier bin classification ---------------------------
  * dfu3d_backproject_bin decides a pixel's spherical bin from fp32 angle

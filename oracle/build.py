@@ -12,8 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "dfu3d_oracle.c")
-SRCS = [SRC, os.path.join(HERE, "csrc", "iou3d_oracle.c")]
-DEPS = SRCS + [os.path.join(os.path.dirname(HERE), "dfu3d_amd", "csrc", "iou_common.inc")]
+SRCS = [SRC]
+DEPS = SRCS
 OUT = os.path.join(HERE, "libdfu3d_oracle.so")
 
 

@@ -77,3 +77,38 @@ def test_struct_layouts_match_the_header(tmp_path):
     for f in fields_cfg:
         assert vals[k] == getattr(_lib.ChainCfg, f).offset, f
         k += 1
+
+
+def test_sizes_struct_layout_and_workspace_bytes(tmp_path):
+    """dfu3d_sizes mirrors the header; dfu3d_workspace_bytes answers for every stage and its PSEUDO_BOXES figure is
+    the chain workspace of the same configuration."""
+    import subprocess
+    from dfu3d_amd import _build
+    fields = [f[0] for f in _lib.Sizes._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dfu3d.h"', 'int main(void) {',
+           'printf("%zu\\n", sizeof(dfu3d_sizes));']
+    src += ['printf("%%zu\\n", offsetof(dfu3d_sizes, %s));' % f for f in fields] + ['return 0; }']
+    c = tmp_path / "sz.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "sz")
+    subprocess.check_call(["gcc", "-I", _build.INCLUDE, str(c), "-o", exe])
+    vals = [int(v) for v in subprocess.check_output([exe]).decode().split()]
+    assert vals[0] == ctypes.sizeof(_lib.Sizes)
+    for k, f in enumerate(fields):
+        assert vals[1 + k] == getattr(_lib.Sizes, f).offset, f
+    L = _lib.lib()
+    z = _lib.Sizes()
+    z.V, z.H, z.W, z.max_inst, z.cap_n, z.cap_vox, z.cap_rows, z.max_points_per_voxel = 96, 900, 1600, 8, 34720, 1 << 18, 6144, 100
+    z.pool_cap, z.table_entries, z.dense, z.stat_filter = 96 << 17, 824 * 1573, 1, 0
+    got = [L.dfu3d_workspace_bytes(s, ctypes.byref(z)) for s in range(11)]
+    assert got[0] == 0 and got[4] == 0 and all(g > 0 for i, g in enumerate(got) if i not in (0, 4))
+    assert all(g % 256 == 0 for g in got)
+    assert got[5] >= 16 * z.pool_cap + z.pool_cap + 4 * z.pool_cap            # shadow (+ boxes) + flags + queue
+    assert L.dfu3d_workspace_bytes(11, ctypes.byref(z)) == -1 and L.dfu3d_workspace_bytes(5, None) == -1
+    # == dfu3d_chain_workspace_bytes of the same configuration
+    c = _lib.ChainCfg()
+    c.V, c.H, c.W, c.max_inst, c.cap_n, c.cap_vox, c.cap_rows = 96, 900, 1600, 8, 34720, 1 << 18, 6144
+    c.dense, c.pool_cap, c.bounds_h, c.bounds_w, c.n_theta = 1, 96 << 17, 900, 1600, 89
+    c.geom.max_points_per_voxel, c.geom.t_n, c.geom.p_n = 100, 824, 1573
+    assert got[10] == L.dfu3d_chain_workspace_bytes(ctypes.byref(c))
+    assert got[10] > got[3]                               # the chain holds the back-projection scratch and more

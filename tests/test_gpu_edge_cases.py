@@ -133,6 +133,35 @@ def test_capacity_overflows_are_flagged_and_recoverable():
     _compare(rows, exp)
 
 
+def test_chain_recovers_from_voxel_overflow():
+    """ONE engine with chain=True (its bin table lives inside the chain workspace): a pass that overflows cap_vox
+    leaves that table dirty; collect() re-initialises it, so the next pass of the SAME engine on a batch that fits is
+    right again (a dirty table would give wrong voxels with status 0)."""
+    _need_gpu()
+    from dfu3d_amd import synth, stages as st
+    from dfu3d_amd.engine import PseudoBoxEngine
+    from dfu3d_amd.params import Params
+    H, W, M, cams = 180, 320, 5, 2
+    p = Params(bounds_hw=(H, W), fov_hw=(H, W))
+    big = synth.make_scene(90, H=H, W=W, M=M, cams=cams, dense=True, k_min=14, k_max=18)
+    small = synth.make_scene(91, H=H, W=W, M=M, cams=cams, dense=True, k_min=14, k_max=18)
+    # the second batch keeps depth only in a window, so that it fits under the small cap
+    d = small.depth.clone()
+    keep = torch.zeros_like(d)
+    keep[:, 60:120, 80:240] = d[:, 60:120, 80:240]
+    small = synth.Scene(small.points, small.calibs, keep, small.masks, small.n_inst, small.inst_class, small.inst_box,
+                        small.inst_score, small.boxes3d)
+    n = max(big.points.shape[0], small.points.shape[0])
+    exp = _oracle_rows([small], p, True)
+    for chain in (True, False):
+        eng = PseudoBoxEngine(p, H, W, M, n, views_per_chunk=cams, dense=True, cap_vox=4096, chain=chain)
+        _, status = eng.run(synth.to_view_batch([big], p, DEV, dense=True))
+        assert status & st.ST_VOX_OVERFLOW
+        rows, status = eng.run(synth.to_view_batch([small], p, DEV, dense=True))
+        assert status == 0
+        _compare(rows, exp)
+
+
 def test_wrapper_rejects_bad_operands():
     _need_gpu()
     from dfu3d_amd import stages as st

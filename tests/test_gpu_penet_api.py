@@ -184,3 +184,172 @@ def test_integration_md_ctypes_example_runs_and_matches_oracle(monkeypatch):
     out = ns["filter_and_fuse"](torch.from_numpy(L).cuda(), torch.from_numpy(P).cuda()).cpu().numpy()
     exp, _, _ = O.instance_points("Car", L, P, O.Params())
     assert np.array_equal(out, exp)
+
+
+# ------------------------------------------------------------------ golden G3: hazards H3 / H11 against the reference
+def _check_label_file(path, ref_rows_text):
+    from dfu3d_amd.labels import read_label_file
+    objs = read_label_file(path)
+    ref = [r.split(" ") for r in ref_rows_text.strip().split("\n")]
+    assert len(objs) == len(ref)
+    for o, w in zip(objs, ref):
+        assert o.cls_type == w[0] and len(o.src.strip().split(" ")) == 15
+        got = np.array([o.alpha, *o.box2d, o.h, o.w, o.l, *[float(v) for v in o.src.split(" ")[11:14]], o.ry])
+        np.testing.assert_allclose(got, np.array(w[3:], float), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["crop", "border"])
+def test_g3_depth2pointsrgbpm_reproduces_reference(golden_dir, tmp_path, kind):
+    """The mirror against the reference's own rows / virtual points for the MISALIGNED scene (K < n_ag, H3) and for
+    the shipped size mix: FOV filter + depth on [:352,:1216], masks and the bounds test on 900x1600 (H11)."""
+    _need_gpu()
+    from dfu3d_amd.penet.calibration_kitti import Calibration
+    from dfu3d_amd.penet.my_loader import depth2pointsrgbpm
+    from dfu3d_amd.params import NUSC_CLASSES
+    g = np.load(os.path.join(golden_dir, "g3_%s.npz" % kind))
+    cpath = tmp_path / "c.txt"
+    cpath.write_bytes(bytes(g["calib_text"]))
+    calib = Calibration(str(cpath))
+    lidar = g["lidar_all"][g["fov"]]                       # vis_utils.py:152-154 done by the caller
+    dh, dw = g["depth"].shape
+    depth = g["depth"].copy().reshape(dh, dw, 1)
+    masks = torch.from_numpy(g["masks"].astype(np.float32))
+    assert tuple(masks.shape[1:]) == (900, 1600)
+    boxes = [_Boxes(b) for b in g["boxes"]]
+    img = pattern_image()[:dh, :dw]
+    out = depth2pointsrgbpm(depth, img, img, calib, lidar, NUSC_CLASSES, masks, g["classes"],
+                            np.ones(len(boxes), np.float32), boxes, None, "000310",
+                            label_root=str(tmp_path / "lab"), plane=g["plane"])
+    _check_label_file(str(tmp_path / "lab" / "000310.txt"), bytes(g["rows"]).decode())
+    assert out.shape == g["all_points"].shape
+    np.testing.assert_allclose(out, g["all_points"], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["crop", "border"])
+def test_g3_engine_with_fov_size_different_from_bounds(golden_dir, tmp_path, kind):
+    """PseudoBoxEngine doing the FOV pre-filter itself (apply_fov) with fov_hw != bounds_hw ('crop') and with the
+    border points that round out of bounds ('border'): rows == the reference's label rows."""
+    _need_gpu()
+    from dfu3d_amd.calibration import Calibration
+    from dfu3d_amd.engine import PseudoBoxEngine, ViewBatch
+    from dfu3d_amd.labels import write_label_file
+    from dfu3d_amd.params import NUSC_CLASSES, Params
+    g = np.load(os.path.join(golden_dir, "g3_%s.npz" % kind))
+    cpath = tmp_path / "c.txt"
+    cpath.write_bytes(bytes(g["calib_text"]))
+    calib = Calibration(str(cpath))
+    fov_hw = tuple(int(x) for x in g["fov_hw"])
+    p = Params(fov_hw=fov_hw)                              # bounds stay 900x1600 (my_loader.py:526)
+    H, W, M = 900, 1600, 8
+    dev = "cuda:0"
+    lid = g["lidar_all"]
+    m = g["masks"].shape[0]
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a)).to(dt).to(dev).contiguous()
+    mk = torch.zeros((1, M, H, W), dtype=torch.uint8, device=dev)
+    mk[0, :m] = t(g["masks"], torch.uint8)
+    depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+    dh, dw = g["depth"].shape
+    depth[0, :dh, :dw] = t(g["depth"], torch.float32)
+    names = [NUSC_CLASSES[int(c)] for c in g["classes"]]
+    pad = M - m
+    b = ViewBatch(points=t(lid, torch.float32), pt_off=t([0, lid.shape[0]], torch.int32), view_frame=t([0], torch.int32),
+                  calib=t(calib.record()[None], torch.float32), masks=mk, n_inst=t([m], torch.int32),
+                  inst_class=t([[int(c) for c in g["classes"]] + [0] * pad], torch.int32),
+                  inst_is_car=t([[1 if n == "Car" else 0 for n in names] + [0] * pad], torch.int32),
+                  inst_r_lidar=t([[p.instance_radii(n)[0] for n in names] + [0.0] * pad], torch.float64),
+                  inst_r_pseudo=t([[p.instance_radii(n)[1] for n in names] + [0.0] * pad], torch.float64),
+                  inst_box=t(np.concatenate([g["boxes"], np.zeros((pad, 4), np.float32)])[None], torch.float32),
+                  inst_score=t([[1.0] * m + [0.0] * pad], torch.float32), view_key=t([0], torch.int64),
+                  host_pt_off=np.array([0, lid.shape[0]]), host_view_frame=np.array([0]), depth=depth,
+                  plane=t(np.asarray(g["plane"], np.float64).reshape(1, 4), torch.float64))
+    for fmt in ("bytes", "packed"):
+        if fmt == "packed":
+            b.pack_masks()
+        for chain in (False, True):
+            eng = PseudoBoxEngine(p, H, W, M, lid.shape[0], views_per_chunk=1, dense=True, cap_vox=1 << 18,
+                                  pool_per_view=1 << 19, rows_per_view=256, apply_fov=True, chain=chain)
+            rows, status = eng.run(b)
+            assert status == 0
+            # n_ag / K of the reference (hazard H3)
+            if not chain:
+                assert int(eng.n_fov[0]) == int(g["fov"].sum())
+                assert int(eng.n_ag[0]) == int(g["n_ag"]) and int(eng.K[0]) == int(g["K"])
+            path = str(tmp_path / ("%s_%d.txt" % (fmt, chain)))
+            write_label_file(path, rows.cpu().numpy(), NUSC_CLASSES)
+            _check_label_file(path, bytes(g["rows"]).decode())
+            del eng
+            torch.cuda.empty_cache()
+
+
+def test_module_swap_of_integration_md(golden_dir, tmp_path, monkeypatch):
+    """the reference's vis_utils.py:136-166 with ONLY its two imports swapped
+    (calibration_kitti, depth2pointsrgbpm) -- host-side FOV pre-filter through the swapped Calibration's
+    lidar_to_rect / rect_to_img, then the swapped depth2pointsrgbpm -- reproduces the reference's label rows."""
+    _need_gpu()
+    from dfu3d_amd.penet import calibration_kitti                      # swapped import 1
+    from dfu3d_amd.penet.my_loader import depth2pointsrgbpm            # swapped import 2
+    from dfu3d_amd.params import NUSC_CLASSES
+    g = np.load(os.path.join(golden_dir, "g7_dense.npz"))
+    root = tmp_path / "kitti"
+    for d in ("calib", "velodyne"):
+        (root / d).mkdir(parents=True)
+    (root / "calib" / "000700.txt").write_bytes(bytes(g["calib_text"]))
+    g["lidar_all"].astype(np.float32).tofile(str(root / "velodyne" / "000700.bin"))
+
+    def get_fov_flag(pts_rect, img_shape, calib):                      # vis_utils.py:108-123, as the reference has it
+        pts_img, pts_rect_depth = calib.rect_to_img(pts_rect)
+        f1 = np.logical_and(pts_img[:, 0] >= 0, pts_img[:, 0] < img_shape[1])
+        f2 = np.logical_and(pts_img[:, 1] >= 0, pts_img[:, 1] < img_shape[0])
+        return np.logical_and(np.logical_and(f1, f2), pts_rect_depth >= 0)
+
+    def save_depth_as_points_stub(depth, idx, root_path):              # the shape of vis_utils.py:136-166
+        file_idx = str(idx).zfill(6)
+        calib = calibration_kitti.Calibration(os.path.join(root_path, 'calib', file_idx + '.txt'))
+        lidar = np.fromfile(os.path.join(root_path, 'velodyne', file_idx + '.bin'), dtype=np.float32).reshape(-1, 4)
+        image = pattern_image()
+        masks = torch.from_numpy(g["masks"].astype(np.float32))        # SegSeem stand-in
+        boxes = [_Boxes(b_) for b_ in g["boxes"]]
+        pts_rect = calib.lidar_to_rect(lidar[:, 0:3])
+        lidar = lidar[get_fov_flag(pts_rect, image.shape, calib)]
+        return depth2pointsrgbpm(depth.reshape(900, 1600, 1), image, image, calib, lidar, NUSC_CLASSES, masks,
+                                 g["classes"], np.ones(len(boxes), np.float32), boxes, None, file_idx,
+                                 label_root=os.path.join(root_path, "label_2"), plane=g["plane"])
+
+    out = save_depth_as_points_stub(g["depth"].copy(), 700, str(root))
+    _check_label_file(str(root / "label_2" / "000700.txt"), bytes(g["rows"]).decode())
+    np.testing.assert_allclose(out, g["all_points"], rtol=1e-12, atol=1e-9)
+
+
+def test_more_than_32_instances_are_all_labelled(tmp_path):
+    """A frame with 40 instances (DFU3D_MAX_INST = 32): the mirror processes them in groups and labels every one,
+    in instance order, like the reference's loop over mask_image.shape[0] (my_loader.py:547)."""
+    _need_gpu()
+    from dfu3d_amd import synth
+    from dfu3d_amd.calibration import Calibration
+    from dfu3d_amd.penet.my_loader import depth2pointsrgbpm
+    from dfu3d_amd.params import NUSC_CLASSES, Params
+    H, W, M = 180, 320, 8
+    s = synth.make_scene(77, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20)
+    n = int(s.n_inst[0])
+    assert n >= 5
+    reps = (40 + n - 1) // n
+    idx = np.tile(np.arange(n), reps)[:40]
+    masks = s.masks[0][:n].numpy()[idx].astype(np.float32)
+    classes = s.inst_class[0][:n].numpy()[idx]
+    boxes = s.inst_box[0][:n].numpy()[idx]
+    cal = s.calibs[0]
+    calib = Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
+    oc = O.Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
+    lid, _ = O.fov_filter(s.points.numpy(), oc, (H, W))
+    p = Params(bounds_hw=(H, W), fov_hw=(H, W))
+    op = O.Params(bounds_hw=(H, W), fov_hw=(H, W))
+    res = O.depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], None, oc, lid, O.NUSC_CLASSES, masks, classes,
+                              boxes, op, plane_key=5, want_points=False)
+    _, rows = depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], None, None, calib, lid, NUSC_CLASSES,
+                                torch.from_numpy(masks), classes, np.ones(40, np.float32), boxes, None, "000005",
+                                label_root=str(tmp_path / "lab"), params=p, return_rows=True)
+    assert len(res.rows) == rows.shape[0] and rows.shape[0] > 0
+    assert int(rows[:, 1].max()) >= 32                      # instances beyond the 32nd produced boxes
+    for got, r in zip(rows, res.rows):
+        assert (int(got[1]), int(got[2]), int(got[3])) == (r.inst, r.cluster, r.cls)
+        np.testing.assert_allclose(got[4:16], r.as_vector(), rtol=1e-6, atol=1e-6)

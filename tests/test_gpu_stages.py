@@ -105,6 +105,48 @@ def test_radius_filter_matches_oracle(st):
             assert np.array_equal(got, pts[keep]), (s, nb)
 
 
+def test_radius_filter_pairs_at_the_threshold(st):
+    """The filter screens in float32 and must hand every comparison that float32 cannot decide to the fp64
+    predicate d2 < r2 (strict, nanoflann): pairs at distance r*(1 +- 1e-5 ... 1e-15), exactly r, far from the
+    origin (large coordinates = large float32 rounding) and with fp64 coordinates that are not float32 values."""
+    rng = np.random.default_rng(77)
+    segs, radius = [], []
+    for r in (3.0, 0.6):
+        for scale in (1.0, 40.0, 95.0):
+            pts = []
+            for k, rel in enumerate((1e-5, 1e-6, 3e-7, 1e-7, 1e-8, 1e-10, 1e-13, 1e-15, 0.0)):
+                for sign in (-1.0, 1.0):
+                    c = rng.uniform(-1, 1, 3) * scale + np.array([400.0 * (2 * k + (sign > 0)), 0, 0]) * (scale / 95.0 + 0.2)
+                    u = rng.normal(0, 1, 3)
+                    u /= np.linalg.norm(u)
+                    d = r * (1.0 + sign * rel)
+                    pts += [c, c + u * d]                 # an isolated pair at (almost exactly) distance d
+            pts = np.array(pts)
+            segs.append(pts[rng.permutation(len(pts))])
+            radius.append(r)
+    radius = np.array(radius)
+    for nb in (1,):
+        P, base, cnt, cap = _pool_from_segments(segs)
+        px, py, pz = _t(P[:, 0]), _t(P[:, 1]), _t(P[:, 2])
+        S = len(segs)
+        seg_cnt = _t(cnt)
+        st.radius_filter(px, py, pz, _t(base), seg_cnt, _t(radius), nb, S, cap,
+                         torch.zeros(S + 1, dtype=torch.int32, device=DEV),
+                         torch.zeros(cap, dtype=torch.uint8, device=DEV),
+                         torch.zeros(2 + cap, dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        out_cnt = seg_cnt.cpu().numpy()
+        X = torch.stack([px, py, pz], 1).cpu().numpy()
+        n_kept = n_drop = 0
+        for s, pts in enumerate(segs):
+            keep = O.radius_outlier(pts, nb, radius[s])
+            n_kept += len(keep)
+            n_drop += len(pts) - len(keep)
+            assert out_cnt[s] == len(keep), (s, out_cnt[s], len(keep))
+            assert np.array_equal(X[base[s]:base[s] + out_cnt[s]], pts[keep]), s
+        assert n_kept > 20 and n_drop > 20            # both outcomes occur right at the threshold
+
+
 # ------------------------------------------------------------------ a12
 def test_ballquery_fuse_matches_oracle(st):
     rng = np.random.default_rng(12)
@@ -429,6 +471,28 @@ def _bp_oracle(depth_v, cal, masks_v, max_points, max_voxels, key_axis):
     return pix, p0[rep], bits
 
 
+def test_backproject_repair_path_with_colliding_keys(st, monkeypatch):
+    """Test build of the library whose packed min-(key|pixel) word keeps only 14 key bits: the cheap representative
+    is wrong for a large share of the voxels, so k_bp_vox queues them and the exact repair (k_bp_rebin, k_ovf_*,
+    k_bp_fix) produces the answer -- it must still be the oracle's, bit for bit."""
+    from dfu3d_amd import _lib, synth
+    L = _lib.load_variant("keybits14")
+    monkeypatch.setattr(_lib, "_LIB", L)
+    s = synth.make_scene(33, H=180, W=320, M=4, cams=2, dense=True, k_min=10, k_max=14)
+    depth = s.depth.numpy().copy()
+    depth[0, 100:110, :] = 7.5
+    masks = s.masks.numpy()
+    for key_axis in (1, 2):
+        n_vox, vox_pix, bits, xyz, status = _bp_run(st, depth, s.calibs, masks, 100, 1000000, key_axis)
+        assert status == 0
+        for v in range(depth.shape[0]):
+            pix, pts, ob = _bp_oracle(depth[v], s.calibs[v], masks[v], 100, 1000000, key_axis)
+            assert n_vox[v] == len(pix)
+            assert np.array_equal(vox_pix[v, :len(pix)], pix), v
+            assert np.array_equal(bits[v, :len(pix)], ob), v
+            assert np.array_equal(xyz[v, :len(pix)], pts), v
+
+
 @pytest.mark.parametrize("max_points,max_voxels,key_axis", [(100, 1000000, 1), (100, 1000000, 2),
                                                             (3, 1000000, 1), (1, 1000000, 2),
                                                             (100, 500, 1), (2, 300, 1)])
@@ -447,4 +511,4 @@ def test_backproject_bin_matches_oracle(st, max_points, max_voxels, key_axis):
         assert n_vox[v] == len(pix), (v, n_vox[v], len(pix))
         assert np.array_equal(vox_pix[v, :len(pix)], pix), v
         assert np.array_equal(bits[v, :len(pix)], ob), v
-        np.testing.assert_allclose(xyz[v, :len(pix)], pts, rtol=1e-13, atol=1e-12)
+        assert np.array_equal(xyz[v, :len(pix)], pts), v       # back-projection bit-exact (fp64 FMA chain == numpy's dgemm)

@@ -1,6 +1,6 @@
 """Build profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> <views_per_launch> <out.json> "<command>"
+usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> <views_per_launch> <out.json> "<command>" [passes]
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB; on gfx950
 FETCH_SIZE tallies 64 B per 128 B request of a wide coalesced read, so it is doubled."""
 import csv, glob, json, sys, collections
@@ -18,6 +18,7 @@ def means(d, counter):
 
 
 fd, wd, views, out, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+passes = int(sys.argv[6]) if len(sys.argv) > 6 else 2        # --steps 1 --warmup 1
 F, Wr = means(fd, "FETCH_SIZE"), means(wd, "WRITE_SIZE")
 kern = {}
 for k in sorted(set(F) | set(Wr)):
@@ -25,7 +26,8 @@ for k in sorted(set(F) | set(Wr)):
     w = Wr.get(k, (None, 0))
     kern[k] = {"fetch_bytes": None if f[0] is None else int(2 * f[0] * 1024),
                "write_bytes": None if w[0] is None else int(w[0] * 1024),
-               "FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB_raw": w[0], "launches": max(f[1], w[1])}
+               "FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB_raw": w[0], "launches": max(f[1], w[1]),
+               "launches_per_pass": max(1, round(max(f[1], w[1]) / passes))}
 json.dump({"command": cmd, "views_per_launch": views,
            "units": "bytes per launch (mean over the launches of the run)",
            "correction": "FETCH_SIZE is in KB and, on gfx950, counts 64 B per 128 B request for wide coalesced "
