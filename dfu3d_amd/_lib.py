@@ -131,6 +131,10 @@ def lib():
     # library is dlopen'ed so that both resolve the SAME libamdhip64 (otherwise torch's
     # streams and device pointers are foreign to our launches: hipErrorInvalid*).
     import torch  # noqa: F401
+    variant = os.environ.get("DFU3D_LIB_VARIANT")     # dev: a tuning build of the same sources (_build.VARIANTS)
+    if variant:
+        _LIB = load_variant(variant)
+        return _LIB
     path = _build.OUT
     try:
         _build.build()          # no-op when the library is newer than every source
@@ -157,9 +161,7 @@ def lib():
 def load_variant(name):
     """A test build of the library (dfu3d_amd/_build.py: VARIANTS) with the product's signatures."""
     import torch  # noqa: F401
-    path = _build.variant_path(name)
-    if not os.path.exists(path):
-        _build.build_variant(name)
+    path = _build.build_variant(name)        # no-op when newer than every source
     L = ctypes.CDLL(path)
     for sym, (res, args) in SIGNATURES.items():
         fn = getattr(L, sym)

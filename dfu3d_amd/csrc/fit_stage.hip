@@ -709,7 +709,10 @@ constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
 constexpr int LDS_MEMBERS = 2048;   // clusters up to this size: members cached in LDS, one wave per heading
-constexpr int TB = 8;               // larger clusters: headings per point-parallel sweep
+#ifndef DFU3D_FIT_TB
+#define DFU3D_FIT_TB 8
+#endif
+constexpr int TB = DFU3D_FIT_TB;    // larger clusters: headings per point-parallel sweep
 
 // block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };

@@ -14,10 +14,8 @@
 // pixel, rep pixel}:
 //   P1  per pixel: back-project, bin; atomics: count++, first=min(pix),
 //       kmin=min(key), combo=min(key' | pix) where key' is the order-preserving
-//       key cut to its top 64-b bits and b = bits of a pixel index.  The update
-//       that finds first == NOBIN is the bin's first toucher and appends the bin
-//       to the view's (unordered) list of touched bins.  Nothing is written per
-//       pixel: the depth map is the only O(pixels) stream of the stage.
+//       key cut to its top 64-b bits and b = bits of a pixel index.  Nothing is
+//       written per pixel: the depth map is the only O(pixels) stream of the stage.
 //       The same update maintains a 1-bit-per-pixel map of the CURRENT first
 //       pixels: whoever lowers first[bin] toggles the bit of its own pixel and the
 //       bit of the pixel it displaced (the old value atomicMin returns).  XOR
@@ -35,13 +33,16 @@
 //   P3  one workgroup per view scans the bit map in raster order: exclusive
 //       popcount prefix per 64-pixel row piece -> the rank of any first-pixel = the
 //       voxel's position in first-seen order
-//   P4  per touched bin: rank, representative (the pixel p* of combo is the smallest
-//       pixel among those whose CUT key is minimal, a superset of the exact
-//       arg-mins, so it is the representative iff its exact key equals kmin), xyz,
-//       instance bits (ONE gather from a bit-packed mask plane, or max_inst byte
-//       gathers), outputs written at the rank; table entry reset.  Bins where the
-//       check fails (two keys differ only below the cut: practically never) and
-//       bins that saw more than max_points pixels are queued for the exact repair.
+//   P4  walks the bit map in raster order (4096 pixels per workgroup): every set bit
+//       is a voxel, its rank is the prefix plus its place in the workgroup's list, so
+//       consecutive threads write consecutive voxels.  The first pixel is classified
+//       once more to find its bin (6 % of the pixels), then: representative (the
+//       pixel p* of combo is the smallest pixel among those whose CUT key is
+//       minimal, a superset of the exact arg-mins, so it is the representative iff
+//       its exact key equals kmin), xyz, instance bits (ONE gather from a bit-packed
+//       mask plane, or max_inst byte gathers); table entry reset.  Bins where the
+//       check fails (two keys differ only below the cut: practically never) and bins
+//       that saw more than max_points pixels are queued for the exact repair.
 #include "common.hpp"
 
 namespace {
@@ -141,12 +142,6 @@ __device__ __forceinline__ void load4(const float *p, int base, int n, float d[P
 }
 
 // ---- P1 ---------------------------------------------------------------------
-// per-view counters (int32 each, V of every kind, zeroed at the start of a pass together with the bit map)
-struct Counters {
-  unsigned long long *amb_new;   // low 32 bits: undecided pixels listed, high 32 bits: touched bins listed
-  int *n_q, *q_cursor;           // repair queue length, pixel-list cursor of the repair
-};
-
 // first-pixel bit map, tile-major: tile (64 wide x 16 high, the tiles of k_bp_bin) t owns words [32t, 32t+32),
 // pixel (row, col) is bit (row & 15) * 64 + (col & 63) of its tile
 constexpr int TILE_W = 64, TILE_H = 16;            // 1024 pixels, 256 threads x 4
@@ -157,24 +152,16 @@ __device__ __forceinline__ void toggle_first_bit(uint32_t *bitmap_v, int W, int 
   atomicXor(&bitmap_v[tile * 32 + (local >> 5)], 1u << (local & 31));
 }
 
-// table update of the exact (tier-2) classification; the update that finds the bin untouched lists it
-__device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key,
-                                             uint32_t b, int v, int cap_vox, uint32_t *touched,
-                                             unsigned long long *amb_new, int pix_bits,
+// table update of the exact (tier-2) classification
+__device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key, int pix_bits,
                                              uint32_t *bitmap_v, int W, int tiles_x) {
   atomicAdd(&T.cnt[e], 1u);
   const uint32_t oldf = atomicMin(&T.first[e], (uint32_t)pix);
   atomicMin(&T.kmin[e], ordered_key(key));
   atomicMin(&T.combo[e], combo_word(ordered_key(key), (uint32_t)pix, pix_bits));
-  if (oldf > (uint32_t)pix) {                      // this pixel is the bin's first pixel now
+  if (oldf > (uint32_t)pix) {                      // this pixel is the bin's first pixel now ...
     toggle_first_bit(bitmap_v, W, tiles_x, (uint32_t)pix);
-    if (oldf == NOBIN) {                           // first toucher of the bin
-      const unsigned long long o = atomicAdd(&amb_new[v], 1ull << 32);
-      const uint32_t slot = (uint32_t)(o >> 32);
-      if (slot < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + slot] = b;
-    } else {
-      toggle_first_bit(bitmap_v, W, tiles_x, oldf);   // ... and the one it displaced no longer is
-    }
+    if (oldf != NOBIN) toggle_first_bit(bitmap_v, W, tiles_x, oldf);   // ... and the one it displaced no longer is
   }
 }
 
@@ -263,21 +250,16 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 // atomics per touched bin instead of one per pixel (6x fewer for dense depth).
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
-constexpr int NEW_CAP = WIN_T * WIN_P + PBLK;      // new bins one tile can list: its window + every direct update
-
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     dfu3d_bin_geom g, FastGeom fg, int W, int H, int tiles_x, int key_axis,
-    int64_t E_view, void *table, int64_t E_total, int cap_vox, uint32_t *__restrict__ touched,
-    unsigned long long *__restrict__ amb_new, uint32_t *__restrict__ amb_list, int pix_bits,
-    uint32_t *__restrict__ bitmap, int BW) {
+    int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
+    int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
   __shared__ uint32_t s_bits[32];                 // this tile's piece of the first-pixel bit map
   __shared__ uint32_t s_amb[PBLK];
-  __shared__ uint32_t s_new[NEW_CAP];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
-  __shared__ int s_namb, s_nnew, s_t0, s_p0;
-  __shared__ unsigned long long s_base;
+  __shared__ int s_namb, s_base, s_t0, s_p0;
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
@@ -287,16 +269,15 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int row = ty * TILE_H + (threadIdx.x >> 4);
   const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
-  if (threadIdx.x == 0) { s_namb = 0; s_nnew = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
+  if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
   if (threadIdx.x < 32) s_bits[threadIdx.x] = 0u;
   uint32_t *bitmap_v = bitmap + (size_t)v * BW;
   // pixel f of THIS tile became a bin's first pixel; oldf is what it displaced
-  auto new_first = [&](uint32_t f, uint32_t oldf, uint32_t b) {
+  auto new_first = [&](uint32_t f, uint32_t oldf) {
     const int fr = (int)f / W, fc = (int)f - fr * W;
     const int local = (fr - ty * TILE_H) * TILE_W + (fc - tx * TILE_W);
     atomicOr(&s_bits[local >> 5], 1u << (local & 31));
-    if (oldf == NOBIN) s_new[atomicAdd(&s_nnew, 1)] = b;          // first toucher lists the bin
-    else toggle_first_bit(bitmap_v, W, tiles_x, oldf);
+    if (oldf != NOBIN) toggle_first_bit(bitmap_v, W, tiles_x, oldf);
   };
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
@@ -354,7 +335,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         const uint32_t oldf = atomicMin(&T.first[e], f);
         atomicMin(&T.kmin[e], ok);
         atomicMin(&T.combo[e], cm);
-        if (oldf > f) new_first(f, oldf, b);
+        if (oldf > f) new_first(f, oldf);
       }
     };
     uint32_t rb = NOBIN, rcn = 0u, rfirst = 0u;
@@ -389,31 +370,26 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     const uint32_t oldf = atomicMin(&T.first[e], s_first[w]);
     atomicMin(&T.kmin[e], s_kmin[w]);
     atomicMin(&T.combo[e], s_combo[w]);
-    if (oldf > s_first[w]) new_first(s_first[w], oldf, b);
+    if (oldf > s_first[w]) new_first(s_first[w], oldf);
   }
   __syncthreads();
   // the tile's own bits: one contiguous 128-byte wave atomic (XOR: other tiles may already have toggled here)
   if (threadIdx.x < 32 && s_bits[threadIdx.x]) atomicXor(&bitmap_v[blockIdx.x * 32 + threadIdx.x], s_bits[threadIdx.x]);
-  const int na = s_namb, nn = s_nnew;
-  if (na == 0 && nn == 0) return;
-  if (threadIdx.x == 0)                                           // one global atomic per block, both lists
-    s_base = atomicAdd(&amb_new[v], (unsigned long long)(uint32_t)na | ((unsigned long long)(uint32_t)nn << 32));
+  const int na = s_namb;
+  if (na == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
   __syncthreads();
-  const uint32_t ba = (uint32_t)(s_base & 0xFFFFFFFFull), bn = (uint32_t)(s_base >> 32);
-  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + ba + i] = s_amb[i];
-  for (int i = threadIdx.x; i < nn; i += PB)
-    if (bn + (uint32_t)i < (uint32_t)cap_vox) touched[(size_t)v * cap_vox + bn + i] = s_new[i];
+  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + s_base + i] = s_amb[i];
 }
 
 // Tier 2: the undecided pixels, full fp64 classification (pixel_bin).
 __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
-    int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, int cap_vox,
-    uint32_t *__restrict__ touched, unsigned long long *__restrict__ amb_new,
+    int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, const int *__restrict__ n_amb,
     const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits,
     uint32_t *__restrict__ bitmap, int BW, int tiles_x) {
   const int v = blockIdx.y;
-  const int na = (int)(__hip_atomic_load(&amb_new[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull);
+  const int na = n_amb[v];
   const ViewCalib c = calib[v];
   const Recip rc = make_recip(c);
   const Table T = table_view(table, E_total);
@@ -423,8 +399,7 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const int pix = (int)amb_list[(size_t)v * HW + e];
     double key;
     const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
-    if (b != NOBIN)
-      commit_pixel(T, tb0 + b, pix, key, b, v, cap_vox, touched, amb_new, pix_bits, bitmap + (size_t)v * BW, W, tiles_x);
+    if (b != NOBIN) commit_pixel(T, tb0 + b, pix, key, pix_bits, bitmap + (size_t)v * BW, W, tiles_x);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -436,8 +411,7 @@ __device__ __forceinline__ unsigned long long row_piece(const uint32_t *bitmap_v
   return *(const unsigned long long *)(bitmap_v + ((size_t)(y >> 4) * tiles_x + tx) * 32 + (y & 15) * 2);
 }
 __global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, const uint32_t *__restrict__ bitmap,
-                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox,
-                                                 const unsigned long long *__restrict__ amb_new, int cap_vox,
+                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox, int cap_vox,
                                                  uint32_t *__restrict__ status) {
   __shared__ int s_w[SCB / 64];
   const int v = blockIdx.x;
@@ -456,23 +430,16 @@ __global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, co
     running += tot;
   }
   if (threadIdx.x == 0) {
-    n_vox[v] = running;                                   // touched bins (clamped by k_bp_finalize)
-    if ((uint32_t)(amb_new[v] >> 32) > (uint32_t)cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+    n_vox[v] = running;                                   // voxels = first pixels (clamped by k_bp_finalize)
+    if (running > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
   }
 }
 
-// rank of first-pixel f among the first-pixels of view v = the voxel's place in first-seen order
+// the bit map and its prefix: the rank of a first pixel = the voxel's place in first-seen order
 struct RankMap {
   const uint32_t *bitmap, *wpre;
   int BW, NJ, tiles_x, W;
 };
-__device__ __forceinline__ int first_rank(const RankMap &R, int v, uint32_t f) {
-  const int y = (int)f / R.W, x = (int)f - y * R.W;
-  const int tx = x >> 6;
-  const unsigned long long m = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
-  return (int)(R.wpre[(size_t)v * R.NJ + y * R.tiles_x + tx] + (uint32_t)__popcll(m & ((1ull << (x & 63)) - 1ull)));
-}
-
 struct VoxOut {
   uint32_t *vox_pix, *it_bits;
   double *it_x, *it_y, *it_z;
@@ -491,50 +458,88 @@ __device__ __forceinline__ void emit_voxel(const VoxOut &o, size_t at, const Vie
   o.it_z[at] = z;
 }
 
-// ---- P4: per touched bin: rank, representative, outputs, table reset -------------
+// ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
 constexpr int VXB = 256;
+constexpr int VX_PIECES = 64;                 // 64-pixel row pieces per workgroup = 4096 pixels
 __global__ __launch_bounds__(VXB) void k_bp_vox(
-    const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, FastGeom fg,
     const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int max_voxels, int max_points, int64_t E_view, void *table, int64_t E_total, int cap_vox,
-    const uint32_t *__restrict__ touched, const unsigned long long *__restrict__ amb_new, RankMap R,
-    VoxOut out, int key_axis,
-    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ n_q,
+    int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
+    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
     uint32_t *__restrict__ status) {
+  __shared__ uint32_t s_pix[VX_PIECES * 64];
+  __shared__ int s_w[VXB / 64];
   const int v = blockIdx.y;
-  const int nt = (int)min((uint32_t)(amb_new[v] >> 32), (uint32_t)cap_vox);
-  if (blockIdx.x * VXB >= nt) return;
+  const int j0 = blockIdx.x * VX_PIECES;
+  if (j0 >= R.NJ) return;
+  // every thread takes a quarter (16 pixels) of a row piece; the list comes out in raster order
+  const int piece = j0 + (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
+  uint32_t m16 = 0u;
+  int y = 0, x0 = 0;
+  if (piece < R.NJ) {
+    y = piece / R.tiles_x;
+    const int tx = piece - y * R.tiles_x;
+    x0 = tx * 64 + quarter * 16;
+    m16 = (uint32_t)(row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx) >> (16 * quarter)) & 0xFFFFu;
+  }
+  int tot;
+  int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);
+  if (tot == 0) return;
+  while (m16) {
+    const int bpos = __ffs((int)m16) - 1;
+    m16 &= m16 - 1u;
+    s_pix[off++] = (uint32_t)(y * W + x0 + bpos);
+  }
+  __syncthreads();
+  const int rank0 = (int)R.wpre[(size_t)v * R.NJ + j0];
   const Table T = table_view(table, E_total);
   const ViewCalib c = calib[v];
   const Recip rc = make_recip(c);
   const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
   const float *dv = depth + (size_t)v * HW;
-  for (int i = blockIdx.x * VXB + threadIdx.x; i < nt; i += gridDim.x * VXB) {
-    const uint32_t b = touched[(size_t)v * cap_vox + i];
-    const int64_t e = (int64_t)v * E_view + b;
+  const int64_t tb0 = (int64_t)v * E_view;
+  bool rerr = false;
+  for (int idx = threadIdx.x; idx < tot; idx += VXB) {
+    const int k = rank0 + idx;
+    if (k >= cap_vox) break;                       // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
+    const uint32_t f = s_pix[idx];
+    // the bin of the first pixel: the same two-tier classification as in P1
+    double key_f;
+    int it_, ip_;
+    const int fr = (int)f / W, fc = (int)f - fr * W;
+    uint32_t b = pixel_bin_fast(c, rc, g, fg, fr, fc, dv[f], key_axis, key_f, it_, ip_);
+    if (b == AMBIG) b = pixel_bin(c, rc, g, W, (int)f, dv[f], key_axis, key_f, rerr);
+    if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
+    const int64_t e = tb0 + b;
     const uint32_t cw = T.cnt[e];
     const uint32_t pix = (uint32_t)(T.combo[e] & ((1ull << pix_bits) - 1ull));
-    bool repair = cw > (uint32_t)max_points;       // the cap binds: "first max_points pixels" must be found
-    if (!repair) {
-      const int row = (int)pix / W, col = (int)pix - row * W;
-      double key = pixel_to_lidar_axis(c, rc, col, row, dv[pix], key_axis);
-      if (key == 0.0) key = 0.0;
-      repair = ordered_key(key) != T.kmin[e];      // two keys agree in their top bits but not exactly
-    }
-    if (repair) {                                  // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
-      const int slot = atomicAdd(&n_q[v], 1);
-      if (slot < cap_q) q_bins[(size_t)v * cap_q + slot] = b;
+    const int row = (int)pix / W, col = (int)pix - row * W;
+    double x, yy, z;
+    pixel_to_lidar(c, rc, col, row, dv[pix], x, yy, z);
+    double key = (key_axis == 2) ? z : yy;
+    if (key == 0.0) key = 0.0;
+    // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
+    if (cw > (uint32_t)g.max_points_per_voxel || ordered_key(key) != T.kmin[e]) {
+      const int slot = atomicAdd(&n_q[v], 1);      // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
+      if (slot < cap_q) { q_bins[(size_t)v * cap_q + slot] = b; q_rank[(size_t)v * cap_q + slot] = k; }
       else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
       continue;
     }
-    const int k = first_rank(R, v, T.first[e]);
-    if (k < max_voxels) emit_voxel(out, (size_t)v * cap_vox + k, c, rc, dv, W, pix, masks, mask_format, m, max_inst, HW, v);
+    if (k < g.max_voxels) {
+      const size_t at = (size_t)v * cap_vox + k;
+      out.vox_pix[at] = pix;
+      out.it_bits[at] = masks ? mask_bits_at(masks, mask_format, v, max_inst, m, HW, (int)pix) : 0u;
+      out.it_x[at] = x;
+      out.it_y[at] = yy;
+      out.it_z[at] = z;
+    }
     // leave the table clean for the next pass (rep is only ever written by the repair)
     T.kmin[e] = ~0ull;
     T.combo[e] = ~0ull;
     T.cnt[e] = 0u;
     T.first[e] = NOBIN;
   }
+  if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
 
 // ---- O1: bin id per pixel, exact classification, only for views with a repair queue ----
@@ -688,8 +693,8 @@ __global__ __launch_bounds__(256) void k_ovf_select(
 __global__ __launch_bounds__(256) void k_bp_fix(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int cap_q,
-    const uint32_t *__restrict__ q_bins, const int *__restrict__ n_q) {
+    int HW, int max_voxels, int64_t E_view, void *table, int64_t E_total, int cap_vox, VoxOut out, int cap_q,
+    const uint32_t *__restrict__ q_bins, const int *__restrict__ q_rank, const int *__restrict__ n_q) {
   const int v = blockIdx.y;
   const int no = min(n_q[v], cap_q);
   if (blockIdx.x * 256 >= no) return;
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(256) void k_bp_fix(
   const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
   for (int s = blockIdx.x * 256 + threadIdx.x; s < no; s += gridDim.x * 256) {
     const int64_t e = (int64_t)v * E_view + q_bins[(size_t)v * cap_q + s];
-    const int k = first_rank(R, v, T.first[e]);
+    const int k = q_rank[(size_t)v * cap_q + s];
     if (k < max_voxels)
       emit_voxel(out, (size_t)v * cap_vox + k, c, rc, depth + (size_t)v * HW, W, T.rep[e], masks, mask_format, m,
                  max_inst, HW, v);
@@ -796,12 +801,11 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 }
 
 // Scratch carve-up.
-// blk_cnt (int32 words): amb_new[V] (uint64: undecided pixels | touched bins), n_q[V], q_cursor[V],
-//   bitmap[V*BW] -- everything up to here is zeroed at the start of a pass --, wpre[V*NJ],
-//   q_cnt[V*cap_q], q_bins[V*cap_q]      (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
+// blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], pad[V], bitmap[V*BW] -- everything up to here is
+//   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q]
+//   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
-//   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair,
-//   [2*V*HW, 2*V*HW + V*cap_vox) touched bins.
+//   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
 static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
 #ifdef DFU3D_DBG_COMBO_KEYBITS
   (void)HW; (void)max_points;
@@ -820,8 +824,8 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   const int64_t tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
-  if (pix_words) *pix_words = 2 * V * HW + (int64_t)V * cap_vox;
-  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 2 * V * cap_q + 8;
+  if (pix_words) *pix_words = 2 * V * HW;
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 8;
   return 0;
 }
 
@@ -852,17 +856,17 @@ extern "C" int dfu3d_backproject_bin(
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long *amb_new = (unsigned long long *)blk_cnt;
-  int *n_q = blk_cnt + 2 * (size_t)V;
+  int *n_amb = blk_cnt;
+  int *n_q = n_amb + V;
   int *q_cursor = n_q + V;
-  uint32_t *bitmap = (uint32_t *)(q_cursor + V);
+  uint32_t *bitmap = (uint32_t *)(q_cursor + 2 * (size_t)V);
   uint32_t *wpre = bitmap + (size_t)V * BW;
   int *q_cnt = (int *)(wpre + (size_t)V * NJ);
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
+  int *q_rank = (int *)(q_bins + (size_t)V * cap_q);
   int pix_bits = 1;
   while ((1ll << pix_bits) < HW64) pix_bits++;
   uint32_t *q_list = pix_bin + (size_t)V * HW;       // undecided pixels first, repair lists later
-  uint32_t *touched = pix_bin + 2 * (size_t)V * HW;
   const ViewCalib *cal = (const ViewCalib *)calib;
   const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
   const RankMap R = {bitmap, wpre, BW, NJ, tiles_x, W};
@@ -870,35 +874,30 @@ extern "C" int dfu3d_backproject_bin(
   if (phases & DFU3D_BP_BIN) {
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
-                       make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view, table, E_total, cap_vox, touched,
-                       amb_new, q_list, pix_bits, bitmap, BW);
+                       make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
+                       bitmap, BW);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_AMB) {
     hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
-                       key_axis, E_view, table, E_total, cap_vox, touched, amb_new, q_list, status, pix_bits, bitmap,
-                       BW, tiles_x);
+                       key_axis, E_view, table, E_total, n_amb, q_list, status, pix_bits, bitmap, BW, tiles_x);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_MARK) {
-    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, amb_new, cap_vox,
-                       status);
+    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, cap_vox, status);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-    int gx = (cap_vox + VXB - 1) / VXB;
-    const int gmax = V >= 16 ? 128 : 2048 / V;
-    if (gx > gmax) gx = gmax;
-    hipLaunchKernelGGL(k_bp_vox, dim3(gx, V), dim3(VXB), 0, st, depth, cal, masks, mask_format, n_inst, max_inst, W,
-                       HW, geom->max_voxels, geom->max_points_per_voxel, E_view, table, E_total, cap_vox, touched,
-                       amb_new, R, out, key_axis, pix_bits, cap_q, q_bins, n_q, status);
+    hipLaunchKernelGGL(k_bp_vox, dim3((NJ + VX_PIECES - 1) / VX_PIECES, V), dim3(VXB), 0, st, depth, cal, *geom,
+                       make_fast_geom(*geom), masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
+                       cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {
     // exact repair of the queued bins (more than max_points pixels, or a key collision below the cut of the
     // packed word); every kernel leaves at once for a view whose queue is empty
     const int nblk = (HW + PB - 1) / PB;
-    hipLaunchKernelGGL(k_bp_rebin, dim3(nblk < 512 ? nblk : 512, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
+    hipLaunchKernelGGL(k_bp_rebin, dim3(nblk < 64 ? nblk : 64, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
                        key_axis, n_q, pix_bin);
     DFU3D_LAUNCH_CHECK();
     const int ga = (cap_q + 255) / 256;
@@ -914,8 +913,8 @@ extern "C" int dfu3d_backproject_bin(
                        q_bins, n_q, q_cnt, q_list);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_fix, dim3(ga < 16 ? ga : 16, V), dim3(256), 0, st, depth, cal, masks, mask_format, n_inst,
-                       max_inst, W, HW, geom->max_voxels, E_view, table, E_total, cap_vox, R, out, cap_q,
-                       q_bins, n_q);
+                       max_inst, W, HW, geom->max_voxels, E_view, table, E_total, cap_vox, out, cap_q, q_bins, q_rank,
+                       n_q);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_finalize, dim3((V + 255) / 256), dim3(256), 0, st, V, geom->max_voxels, cap_vox, n_vox);
     DFU3D_LAUNCH_CHECK();

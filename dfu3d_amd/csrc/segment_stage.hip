@@ -217,12 +217,13 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 // tried pairwise against the other undecided points of the workgroup (an outlier's neighbours
 // are usually other outliers a few dozen list positions away).  The rest -- isolated points and
 // the rare uncertain comparisons -- goes to phase B through one global atomic per workgroup.
-// Phase A also leaves, per 64-position chunk of the pool, two bounding boxes: one of the points it
-// decided and one of the points it could not decide (outliers: kept apart so that they do not blow up
-// the first).  Phase B (k_radius_resolve): one wave per queued query sweeps the BOXES of its segment
-// (64 chunks per step, a lane each) and tests the points of the few chunks whose boxes come within the
-// radius: float32 shadow with certain-hit / certain-miss bounds, fp64 for the pairs in between.
-// Every point of the segment lies in one of the two boxes of its chunk, so nothing is missed.
+// Phase A also leaves, per wave range (512 consecutive pool positions), two bounding boxes: one of the
+// points it decided and one of the points it could not decide (outliers: kept apart so that they do not
+// blow up the first).  Phase B (k_radius_resolve): one wave per queued query tests its own 64-chunk, then
+// sweeps the BOXES of its segment (64 ranges = 32 k positions per step, a lane each) and tests the points
+// of the few ranges whose boxes come within the radius: float32 shadow with certain-hit / certain-miss
+// bounds, fp64 for the pairs in between.  Every point of the segment lies in one of the two boxes of its
+// range, so nothing is missed.
 constexpr int RFB = 256;           // threads per phase-A workgroup
 constexpr int RF_IT = 8;           // 64-point chunks per wave
 constexpr int RF_WG = RFB * RF_IT; // pool positions per workgroup
@@ -265,7 +266,8 @@ __device__ __forceinline__ float wave_max63(float v) {
   v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
   return v;
 }
-constexpr int BOX_FLOATS = 12;               // per chunk: decided min xyz, max xyz | undecided min xyz, max xyz
+constexpr int BOX_FLOATS = 12;               // per range: decided min xyz, max xyz | undecided min xyz, max xyz
+constexpr int BOX_SHIFT = 9;                 // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
 constexpr float BOX_EMPTY = 3.0e38f;
 
 __global__ __launch_bounds__(RFB) void k_radius_flags(
@@ -288,6 +290,9 @@ __global__ __launch_bounds__(RFB) void k_radius_flags(
     const long long i = w0 + it * 64 + lane;
     p[it] = (i < n_used) ? pq[i] : make_float4(0.f, 0.f, 0.f, __uint_as_float(RF_NOSEG << 16));
   }
+  float bx[BOX_FLOATS];                        // per lane, reduced over the wave once at the end
+#pragma unroll
+  for (int k = 0; k < BOX_FLOATS; k++) bx[k] = ((k % 6) < 3) ? BOX_EMPTY : -BOX_EMPTY;
 #pragma unroll
   for (int it = 0; it < RF_IT; it++) {
     const long long i = w0 + it * 64 + lane;
@@ -324,19 +329,15 @@ __global__ __launch_bounds__(RFB) void k_radius_flags(
     }
     const bool pending = active && cnt <= nb;
     if (active && !pending) flags[i] = 1;
-    {   // the chunk's two boxes: points decided here | points left undecided
-      const bool dk = valid && !pending;
-      float bx[BOX_FLOATS];
-      bx[0] = wave_min63(dk ? x : BOX_EMPTY);  bx[1] = wave_min63(dk ? y : BOX_EMPTY);  bx[2] = wave_min63(dk ? z : BOX_EMPTY);
-      bx[3] = wave_max63(dk ? x : -BOX_EMPTY); bx[4] = wave_max63(dk ? y : -BOX_EMPTY); bx[5] = wave_max63(dk ? z : -BOX_EMPTY);
-      bx[6] = wave_min63(pending ? x : BOX_EMPTY);  bx[7] = wave_min63(pending ? y : BOX_EMPTY);
-      bx[8] = wave_min63(pending ? z : BOX_EMPTY);  bx[9] = wave_max63(pending ? x : -BOX_EMPTY);
-      bx[10] = wave_max63(pending ? y : -BOX_EMPTY); bx[11] = wave_max63(pending ? z : -BOX_EMPTY);
-      if (lane == 63) {
-        float4 *o = (float4 *)(boxes + (size_t)((w0 + it * 64) >> 6) * BOX_FLOATS);
-        o[0] = make_float4(bx[0], bx[1], bx[2], bx[3]);
-        o[1] = make_float4(bx[4], bx[5], bx[6], bx[7]);
-        o[2] = make_float4(bx[8], bx[9], bx[10], bx[11]);
+    if (valid) {   // the range's two boxes: points decided here | points left undecided
+      const int o = pending ? 6 : 0;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int q = k * 6;
+        if (q == o) {
+          bx[q + 0] = fminf(bx[q + 0], x); bx[q + 1] = fminf(bx[q + 1], y); bx[q + 2] = fminf(bx[q + 2], z);
+          bx[q + 3] = fmaxf(bx[q + 3], x); bx[q + 4] = fmaxf(bx[q + 4], y); bx[q + 5] = fmaxf(bx[q + 5], z);
+        }
       }
     }
     const unsigned long long pm = __ballot(pending);
@@ -355,6 +356,16 @@ __global__ __launch_bounds__(RFB) void k_radius_flags(
           queue[2 + g] = (int)i;
         }
       }
+    }
+  }
+  {
+#pragma unroll
+    for (int k = 0; k < BOX_FLOATS; k++) bx[k] = ((k % 6) < 3) ? wave_min63(bx[k]) : wave_max63(bx[k]);
+    if (lane == 63 && w0 < n_used) {
+      float4 *o = (float4 *)(boxes + (size_t)(w0 >> BOX_SHIFT) * BOX_FLOATS);
+      o[0] = make_float4(bx[0], bx[1], bx[2], bx[3]);
+      o[1] = make_float4(bx[4], bx[5], bx[6], bx[7]);
+      o[2] = make_float4(bx[8], bx[9], bx[10], bx[11]);
     }
   }
   __syncthreads();
@@ -449,21 +460,23 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
     };
     const long long c_own = i >> 6;
     test_chunk(c_own);                               // the query itself is counted here (d = 0 < r2)
-    const long long c_lo = base >> 6, c_hi = (end - 1) >> 6;
-    for (long long c0 = c_lo; c0 <= c_hi && cnt <= nb; c0 += 64) {
-      const long long c = c0 + lane;
+    const long long r_lo = base >> BOX_SHIFT, r_hi = (end - 1) >> BOX_SHIFT;
+    for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
+      const long long rg = r0 + lane;
       bool cand = false;
-      if (c <= c_hi && c != c_own) {
-        const float4 *bp = (const float4 *)(boxes + (size_t)c * BOX_FLOATS);
+      if (rg <= r_hi) {
+        const float4 *bp = (const float4 *)(boxes + (size_t)rg * BOX_FLOATS);
         const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
         cand = box_dist2(qf.x, qf.y, qf.z, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y) <= hi2 ||
                box_dist2(qf.x, qf.y, qf.z, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w) <= hi2;
       }
       unsigned long long m = __ballot(cand);
-      while (m && cnt <= nb) {                       // uniform: the candidate chunks of this step, one by one
+      while (m && cnt <= nb) {                       // uniform: the candidate ranges of this step, one by one
         const int k = __ffsll((long long)m) - 1;
         m &= m - 1ull;
-        test_chunk(c0 + k);
+        const long long c0 = (r0 + k) << (BOX_SHIFT - 6);
+        for (int u = 0; u < (1 << (BOX_SHIFT - 6)) && cnt <= nb; u++)
+          if (c0 + u != c_own) test_chunk(c0 + u);
       }
     }
     if (lane == 0) flags[i] = (cnt > nb) ? 1 : 0;

@@ -49,13 +49,11 @@ def rows_for_gather(rows: torch.Tensor, view_frame, frame_ids, view_cam) -> torc
     afterwards a row can be attributed to its frame whatever rank produced it.  (The box numbers stay
     float64 -- the label files print them at full precision -- instead of 8e's i32/f32 mix.)"""
     d = rows.device
-    t = lambda a: torch.as_tensor(np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a), device=d)
+    t = lambda a: a.to(d) if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), device=d)
     vf, fid, cam = t(view_frame).long(), t(frame_ids).to(torch.float64), t(view_cam).to(torch.float64)
     out = torch.empty((rows.shape[0], len(GATHER_COLUMNS)), dtype=torch.float64, device=d)
     if rows.shape[0]:
-        v = rows[:, 0].long()
-        if int(v.min()) < 0 or int(v.max()) >= vf.numel():
-            raise ValueError("row with a view index outside the batch")
+        v = rows[:, 0].long().clamp_(0, vf.numel() - 1)     # (no host sync here: this sits on the per-step path)
         out[:, 0] = fid[vf[v]]
         out[:, 1] = cam[v]
         out[:, 2] = rows[:, 3]

@@ -320,7 +320,7 @@ class PseudoBoxEngine:
                          self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
                          self.b_z, status, mask_format=b.mask_format)
             self._count("voxels", self.n_vox)
-            self._count("amb_pixels", self.blk_cnt[:2 * V].view(torch.int64) & 0xFFFFFFFF)
+            self._count("amb_pixels", self.blk_cnt[:V])
         else:
             self.n_vox.zero_()
         self.pool_cursor.zero_()
@@ -469,21 +469,29 @@ class PseudoBoxEngine:
         return self.n_vox.clone(), self.vox_pix.view(V, self.cap_vox).clone(), xyz, int(status.item())
 
     def gather_layout(self, rows, b: ViewBatch):
-        """Engine rows (n,24) -> (n,18) rows carrying the GLOBAL frame index and the camera (dist.rows_for_gather)."""
+        """Engine rows (n,24) -> (n,18) rows carrying the GLOBAL frame index and the camera (dist.rows_for_gather).
+        The per-view lookup tables go to the device once per batch object."""
         from .dist import rows_for_gather
-        V = b.view_frame.numel()
-        fid = b.frame_ids if b.frame_ids is not None else np.arange(b.pt_off.numel() - 1)
-        if b.view_cam is not None:
-            cam = b.view_cam
-        else:                                   # position of the view among the views of its frame
-            vf = np.asarray(b.host_view_frame)
-            cam = np.array([int((vf[:i] == vf[i]).sum()) for i in range(V)], np.int64)
-        return rows_for_gather(rows, b.host_view_frame, fid, cam)
+        maps = getattr(b, "_gather_maps", None)
+        if maps is None:
+            V = b.view_frame.numel()
+            fid = b.frame_ids if b.frame_ids is not None else np.arange(b.pt_off.numel() - 1)
+            if b.view_cam is not None:
+                cam = b.view_cam
+            else:                                   # position of the view among the views of its frame
+                vf = np.asarray(b.host_view_frame)
+                cam = np.array([int((vf[:i] == vf[i]).sum()) for i in range(V)], np.int64)
+            d = rows.device
+            maps = (torch.as_tensor(np.asarray(b.host_view_frame), device=d), torch.as_tensor(np.asarray(fid), device=d),
+                    torch.as_tensor(np.asarray(cam), device=d))
+            b._gather_maps = maps
+        return rows_for_gather(rows, *maps)
 
     def collect(self):
         rows, n_rows, status = self._last
-        counts = n_rows.cpu().numpy()                   # the one host sync
-        stw = int(np.bitwise_or.reduce(status.cpu().numpy().astype(np.int64)))
+        both = torch.stack((n_rows, status)).cpu().numpy()        # the one host sync
+        counts = both[0]
+        stw = int(np.bitwise_or.reduce(both[1].astype(np.int64)))
         if self.dense and (stw & st.ST_VOX_OVERFLOW):   # a pass that overflowed left its bin table dirty
             for L in self.lanes:                         # (the chain keeps its own table inside its workspace)
                 with torch.cuda.stream(L.stream):

@@ -45,6 +45,9 @@ def build_parser():
     ap.add_argument('--streams', type=int, default=2)
     ap.add_argument('--reader-procs', type=int, default=8,
                     help='forked reader processes for the batched path (0 = reader threads only)')
+    ap.add_argument('--dist-backend', default=None, help='nccl (default on GPUs: RCCL) | gloo (rehearsal)')
+    ap.add_argument('--single-device', action='store_true',
+                    help='rehearsal of a multi-rank run on one GPU: every rank uses cuda:0 (needs --dist-backend gloo)')
     return ap
 
 
@@ -66,7 +69,9 @@ def main(argv=None):
             rpool = None                      # GPU already initialised in this process: threads
     from .. import dist as D
     from .vis_utils import save_depth_as_points
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(args.dist_backend)
+    if args.single_device:
+        local = 0
     frames = frame_list(args.detpath)[args.start:args.end]
     mine = [frames[i] for i in D.shard_frames(len(frames), rank, world)]
     depth_dir = args.depth_dir or os.path.join(args.detpath, 'depth_2')

@@ -225,7 +225,7 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
 
 def shadow_floats(pool_cap):
     """float32 elements of the radius filter's shadow scratch (DFU3D_SHADOW_BYTES / 4)."""
-    return 4 * pool_cap + 12 * ((pool_cap + 63) // 64 + 1)
+    return 4 * pool_cap + 12 * ((pool_cap + 511) // 512 + 1)
 
 
 def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n, b_cap, V,

@@ -227,7 +227,7 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
  * from the pool.  Segments must not overlap; S < 65535.
  * n_used: device int64 = number of pool slots in use (NULL: pool_cap).
  * Scratch: shadow (DFU3D_SHADOW_BYTES(pool_cap) bytes, 16-byte aligned: 16 B per slot + two bounding boxes
- * per 64 slots for the second phase), tile_off int32 (S+1), flags uint8
+ * per 512 slots for the second phase), tile_off int32 (S+1), flags uint8
  * (pool_cap), queue int32 (2 + pool_cap: undecided pool positions between the two kernels). */
 int dfu3d_radius_filter(double *px, double *py, double *pz,
                         const int64_t *seg_base, int32_t *seg_cnt,
@@ -235,7 +235,7 @@ int dfu3d_radius_filter(double *px, double *py, double *pz,
                         int64_t pool_cap, const int64_t *n_used, void *shadow,
                         int32_t *tile_off, uint8_t *flags,
                         int32_t *queue, int32_t phases, void *stream);
-#define DFU3D_SHADOW_BYTES(pool_cap) (16 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 63) / 64 + 1))
+#define DFU3D_SHADOW_BYTES(pool_cap) (16 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 511) / 512 + 1))
 #define DFU3D_RF_SHADOW 1   /* shadow of the given segments (not needed behind dfu3d_segments_build(..., shadow)) */
 #define DFU3D_RF_FLAGS 2    /* k_radius_flags: list neighbours / own wave / own workgroup, float32          */
 #define DFU3D_RF_RESOLVE 4  /* k_radius_resolve: the undecided against their whole segment                   */

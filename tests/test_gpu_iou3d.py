@@ -63,7 +63,7 @@ def test_far_from_the_origin_and_degenerate_boxes():
     ov = st.boxes_bev(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), iou=False).cpu().numpy()
     exp = I.boxes_bev(a, b, iou=False)
     np.testing.assert_allclose(ov, exp, rtol=2e-5, atol=2e-3)       # 400 m * 2^-24 * perimeter
-    assert (ov[1] == 0).all() and ov[2, 2] < 2e-3
+    assert (ov[1] < 1e-6).all() and ov[2, 2] < 2e-3            # a zero-width box has no area (up to float32 dust)
     assert np.isfinite(ov).all()
 
 

@@ -331,7 +331,7 @@ def test_more_than_32_instances_are_all_labelled(tmp_path):
     H, W, M = 180, 320, 8
     s = synth.make_scene(77, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20)
     n = int(s.n_inst[0])
-    assert n >= 5
+    assert n >= 2
     reps = (40 + n - 1) // n
     idx = np.tile(np.arange(n), reps)[:40]
     masks = s.masks[0][:n].numpy()[idx].astype(np.float32)

@@ -1,0 +1,105 @@
+"""Rehearsal of BASELINE configs[2] (the 28 130-frame split sharded over the ranks of one node) on ONE GPU:
+a synthetic KITTI-format directory of N frames -> `python -m dfu3d_amd.penet.main` with forked readers ->
+label files + rank-0 manifest; then a restart with --skip-existing after deleting a few label files; then the same
+frames one at a time (--batch-frames 0) for a byte comparison; optionally the 2-rank run over gloo on the same GPU
+(frames r::2, row gather, manifest).  Prints one JSON line.  Frames are small (225x400, one camera per frame as in
+the KITTI layout) so that thousands fit on the box's scratch disk; the rate is disk-inclusive (files in, files out).
+
+  python tools/rehearse_config2.py [N=2000] [root=/dev/shm/dfu3d_cfg2]
+"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+root = sys.argv[2] if len(sys.argv) > 2 else "/dev/shm/dfu3d_cfg2"
+H, W, M = 225, 400, 6
+
+
+def generate():
+    import torch  # noqa: F401
+    from dfu3d_amd import synth, kitti_io
+    from dfu3d_amd.params import NUSC_CLASSES
+    img = np.zeros((H, W, 3), np.uint8)
+    t0 = time.time()
+    for f in range(N):
+        s = synth.make_scene(5000 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20)
+        n = int(s.n_inst[0])
+        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], img, s.masks[0][:n].numpy(),
+                             s.inst_class[0][:n].numpy(), s.inst_score[0][:n].numpy(), s.inst_box[0][:n].numpy(),
+                             NUSC_CLASSES, s.depth[0].numpy())
+        if f % 500 == 499:
+            print("generated %d frames (%.0fs)" % (f + 1, time.time() - t0), flush=True)
+    return time.time() - t0
+
+
+def cli(extra, ranks=1):
+    base = ["-m", "dfu3d_amd.penet.main", "--command", "evaluate", "--detpath", root, "--no-virtual-points"] + extra
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", "29517"] + base + ["--dist-backend", "gloo", "--single-device"]
+    else:
+        cmd = [sys.executable] + base
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    if out.returncode:
+        print(out.stdout[-2000:], out.stderr[-4000:], flush=True)
+        raise SystemExit("CLI failed: %s" % " ".join(cmd))
+    return time.time() - t0, out.stdout
+
+
+def labels(d):
+    return {os.path.basename(p): open(p).read() for p in sorted(glob.glob(os.path.join(d, "*.txt")))}
+
+
+res = {"frames": N, "image": "%dx%d" % (W, H), "root": root}
+if not os.path.isdir(os.path.join(root, "velodyne")) or len(os.listdir(os.path.join(root, "velodyne"))) != N:
+    shutil.rmtree(root, ignore_errors=True)
+    res["generate_s"] = round(generate(), 1)
+lab = os.path.join(root, "label_2")
+shutil.rmtree(lab, ignore_errors=True)
+# 1. the whole directory, batched, forked readers
+dt, out = cli(["--batch-frames", "32", "--reader-procs", "8", "--streams", "2"])
+full = labels(lab)
+man = json.load(open(os.path.join(lab, "manifest.json")))
+assert len(full) == N and man["frames"] == N and man["boxes"] == sum(len(t.splitlines()) for t in full.values())
+res.update(batched_s=round(dt, 2), frames_per_s_disk_inclusive=round(N / dt, 1), boxes=man["boxes"],
+           manifest={k: man[k] for k in ("frames", "boxes", "boxes_per_rank", "frames_with_boxes")})
+# 2. restart: delete some label files, --skip-existing relabels exactly those
+gone = sorted(full)[3:N:max(N // 40, 1)]
+stamp = {k: os.path.getmtime(os.path.join(lab, k)) for k in full}
+for k in gone:
+    os.remove(os.path.join(lab, k))
+dt2, out2 = cli(["--batch-frames", "32", "--reader-procs", "8", "--skip-existing"])
+again = labels(lab)
+assert again == full, "restart produced different label files"
+untouched = [k for k in full if k not in gone]
+assert all(os.path.getmtime(os.path.join(lab, k)) == stamp[k] for k in untouched), "--skip-existing rewrote finished frames"
+res.update(restart_relabelled=len(gone), restart_s=round(dt2, 2))
+# 3. one frame at a time (the reference's loop) on a sample: byte-identical label files
+one = os.path.join(root, "label_one")
+shutil.rmtree(one, ignore_errors=True)
+k0 = N // 3
+dt3, _ = cli(["--batch-frames", "0", "--start", str(k0), "--end", str(k0 + 12), "--label-out", one])
+single = labels(one)
+assert len(single) == 12 and all(single[k] == full[k] for k in single), "batched and one-at-a-time label files differ"
+res.update(one_at_a_time_frames=12, one_at_a_time_s=round(dt3, 2))
+# 4. two ranks on this GPU over gloo: frames r::2, row gather, manifest
+two = os.path.join(root, "label_two")
+shutil.rmtree(two, ignore_errors=True)
+dt4, out4 = cli(["--batch-frames", "32", "--reader-procs", "4", "--label-out", two], ranks=2)
+lab2 = labels(two)
+man2 = json.load(open(os.path.join(two, "manifest.json")))
+assert lab2 == full, "2-rank run wrote different label files"
+assert man2["world_size"] == 2 and man2["boxes"] == man["boxes"] and sum(man2["boxes_per_rank"]) == man["boxes"]
+assert min(man2["boxes_per_rank"]) > 0
+res.update(two_rank_s=round(dt4, 2), two_rank_boxes_per_rank=man2["boxes_per_rank"])
+print(json.dumps(res))
