@@ -336,8 +336,8 @@ def main():
 
     eng = make_engine(args.lanes, views)
 
-    def step():
-        rows, status = eng.run(batch)
+    def finish(handle):
+        rows, status = eng.collect(handle)
         if status:
             from dfu3d_amd.stages import status_message
             raise SystemExit("device status: " + status_message(status))
@@ -348,12 +348,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        rows = step()
+    def steps(k):
+        """k passes; pass i+1 is enqueued before the host waits for the rows of pass i (every pass is collected,
+        sorted and gathered inside the loop -- nothing is left for after the timed region)."""
+        rows, pending = None, None
+        for _ in range(k):
+            h = eng.launch(batch)
+            if pending is not None:
+                rows = finish(pending)
+            pending = h
+        if pending is not None:
+            rows = finish(pending)
+        return rows
+
+    rows = steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        rows = step()
+    rows = steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

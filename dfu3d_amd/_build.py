@@ -51,8 +51,6 @@ VARIANTS = {
     # packed min-(key|pixel) word with only 14 key bits: keys collide below the cut all the time, so the exact
     # repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never taken in the product build) does the work
     "keybits14": ["-DDFU3D_DBG_COMBO_KEYBITS=14"],
-    # tuning experiments (dev): selected at load time with DFU3D_LIB_VARIANT=<name>
-    "fit_tb4": ["-DDFU3D_FIT_TB=4"],
 }
 
 

@@ -79,7 +79,8 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P, c_i32, _P]),
     "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,
                                      c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, _P, _P, _P, _P, _P, _P]),
+                                     _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfu3d_segments_scratch_words": (c_i64, [c_i32, c_i32, c_i32]),
     "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P, _P, _P,
                                     c_i32, _P]),
     "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,
@@ -101,7 +102,8 @@ SIGNATURES = {
     "dfu3d_chain_workspace_bytes": (c_i64, [ctypes.POINTER(ChainCfg)]),
     "dfu3d_chain_workspace_init": (c_i32, [ctypes.POINTER(ChainCfg), _P, _P]),
     "dfu3d_pseudo_boxes": (c_i32, [ctypes.POINTER(ChainCfg)] + [_P] * 20),
-    "dfu3d_selftest_angles": (c_i32, [c_i64, ctypes.c_uint64, c_f64, c_f64, c_f64, _P, _P]),
+    "dfu3d_selftest_classify": (c_i32, [_P, c_i32, c_i32, _P, c_i32, c_i64, ctypes.c_uint64, c_f64, c_f64, _P, _P, _P]),
+    "dfu3d_selftest_backproject": (c_i32, [_P, c_i32, c_i32, c_i64, ctypes.c_uint64, c_f64, c_f64, _P, _P, _P]),
     "dfu3d_lshape_fit_ws_doubles": (c_i64, [c_i64, c_i32]),
     "dfu3d_lshape_fit": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, _P, _P, _P, _P, _P,
                                  c_i32, c_f64, c_f64, _P, _P, _P, c_i32, _P, _P, _P, _P, c_i64,

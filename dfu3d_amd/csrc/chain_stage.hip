@@ -26,6 +26,7 @@ struct ChainWs {
   int32_t *cnt_a, *cnt_b, *cnt_all, *cnt_ab, *tile_off, *queue, *stat_enable;
   double *rad_ab, *mean_d;
   void *shadow;
+  int32_t *chunk_cnt;
   int64_t *pool_cursor;
   int64_t table_entries;
 };
@@ -66,9 +67,10 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
   t.flags = (uint8_t *)take(P);
   t.base_a = (int64_t *)take(8 * S); t.base_b = (int64_t *)take(8 * S); t.base_ab = (int64_t *)take(8 * 2 * S);
   t.cnt_a = (int32_t *)take(4 * S); t.cnt_b = (int32_t *)take(4 * S); t.cnt_all = (int32_t *)take(4 * S);
-  t.cnt_ab = (int32_t *)take(4 * 2 * S); t.tile_off = (int32_t *)take(4 * (2 * S + 1));
+  t.cnt_ab = (int32_t *)take(4 * 2 * S); t.tile_off = (int32_t *)take(4 * (2 * S + 2));
   t.queue = (int32_t *)take(4 * (2 + P)); t.stat_enable = (int32_t *)take(4 * S);
   t.shadow = take(DFU3D_SHADOW_BYTES(P));
+  t.chunk_cnt = (int32_t *)take(4 * dfu3d_segments_scratch_words(c->V, c->cap_n, c->cap_vox));
   t.rad_ab = (double *)take(8 * 2 * S);
   t.mean_d = c->stat_filter ? (double *)take(8 * P) : nullptr;
   t.pool_cursor = (int64_t *)take(8);
@@ -118,8 +120,9 @@ extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
   const int64_t V = z->V, S = V * z->max_inst, P = z->pool_cap, N = V * (int64_t)z->cap_n;
   switch (stage) {
     case DFU3D_STAGE_FOV_FILTER:
-    case DFU3D_STAGE_SEGMENTS_BUILD:
       return 0;
+    case DFU3D_STAGE_SEGMENTS_BUILD:                     /* chunk_cnt */
+      return (z->cap_n > 0 && z->cap_vox > 0) ? up(4 * dfu3d_segments_scratch_words(z->V, z->cap_n, z->cap_vox)) : DFU3D_EINVAL;
     case DFU3D_STAGE_PLANE_RANSAC:                       /* cand_idx */
       return z->cap_n > 0 ? up(4 * N) : DFU3D_EINVAL;
     case DFU3D_STAGE_PROJECT_LABEL:                      /* ag_pt, ib_pix */
@@ -136,7 +139,7 @@ extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
     case DFU3D_STAGE_STAT_FILTER:                        /* tile_off, flags, mean_d */
       return P > 0 ? up(4 * (S + 1)) + up(P) + up(8 * P) : DFU3D_EINVAL;
     case DFU3D_STAGE_BALLQUERY_FUSE:                     /* tile_off, flags */
-      return P > 0 ? up(4 * (S + 1)) + up(P) : DFU3D_EINVAL;
+      return P > 0 ? up(4 * (2 * S + 2)) + up(P) : DFU3D_EINVAL;
     case DFU3D_STAGE_RANGE_CLUSTER:                      /* sx, sy, si */
       return P > 0 ? 2 * up(8 * P) + up(12 * P) : DFU3D_EINVAL;
     case DFU3D_STAGE_LSHAPE_FIT:                         /* sx, sy, sroot, fit_ws */
@@ -234,7 +237,7 @@ extern "C" int dfu3d_pseudo_boxes(
                                  w.n_vox, cfg->cap_vox, V, M, cfg->pool_cap, w.pool_cursor, w.px, w.py, w.pz,
                                  w.base_a, w.cnt_a, w.base_b, w.cnt_b, status, inst_r_lidar, inst_r_pseudo,
                                  joint ? w.shadow : nullptr, joint ? w.base_ab : nullptr, w.cnt_ab, w.rad_ab,
-                                 stream));
+                                 w.chunk_cnt, stream));
   // a10 (+a11) + a12
   if (joint) {
     // the shadow and the joint segment table come from the segment build; the LiDAR lists are compacted in

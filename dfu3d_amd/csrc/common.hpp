@@ -103,6 +103,15 @@ __device__ __forceinline__ double wave_max_d(double v) {
   for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_d(v, m));
   return v;
 }
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned int lo = (unsigned int)__shfl_xor((int)(v & 0xFFFFFFFFull), m, 64);
+    const unsigned int hi = (unsigned int)__shfl_xor((int)(v >> 32), m, 64);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -175,13 +184,21 @@ __device__ __forceinline__ void pixel_to_lidar(const ViewCalib &c, const Recip &
   z = fma(zr, (double)M[8], fma(yr, (double)M[5], xr * (double)M[2])) + (double)M[11];
 }
 // only the coordinate that serves as the voxel key (key_axis 1 = y, 2 = z)
-__device__ __forceinline__ double pixel_to_lidar_axis(const ViewCalib &c, const Recip &rc, int u, int v,
-                                                      float d, int axis) {
+// The column of Minv that gives one LiDAR coordinate (axis 0/1/2), read from the record in GLOBAL memory: indexing a
+// private copy of the record with a run-time axis would put the whole record into scratch memory.
+struct KeyCol { float m0, m3, m6, m9; };
+__device__ __forceinline__ KeyCol load_key_col(const ViewCalib *c, int axis) {
+  const float *M = c->Minv + axis;
+  KeyCol k;
+  k.m0 = M[0]; k.m3 = M[3]; k.m6 = M[6]; k.m9 = M[9];
+  return k;
+}
+__device__ __forceinline__ double pixel_to_lidar_axis(const ViewCalib &c, const Recip &rc, const KeyCol &kc, int u,
+                                                      int v, float d) {
   const double dd = (double)d;
   const double xr = div_reused(((double)u - (double)c.cu) * dd, (double)c.fu, rc.rfu) + (double)c.tx;
   const double yr = div_reused(((double)v - (double)c.cv) * dd, (double)c.fv, rc.rfv) + (double)c.ty;
-  const float *M = c.Minv + axis;
-  return fma(dd, (double)M[6], fma(yr, (double)M[3], xr * (double)M[0])) + (double)M[9];
+  return fma(dd, (double)kc.m6, fma(yr, (double)kc.m3, xr * (double)kc.m0)) + (double)kc.m9;
 }
 
 // ---- instance masks -------------------------------------------------------------

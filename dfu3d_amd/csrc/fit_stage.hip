@@ -709,10 +709,6 @@ constexpr int FT = 512;
 constexpr int FW = FT / 64;
 constexpr int MAXTH = 128;
 constexpr int LDS_MEMBERS = 2048;   // clusters up to this size: members cached in LDS, one wave per heading
-#ifndef DFU3D_FIT_TB
-#define DFU3D_FIT_TB 8
-#endif
-constexpr int TB = DFU3D_FIT_TB;    // larger clusters: headings per point-parallel sweep
 
 // block-wide reduction of K per-thread doubles (sum / min / max by OP): result in out[0..K)
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
@@ -804,7 +800,7 @@ __device__ void emit_box(double thb, double sin_s, double cos_s, double c1min, d
 
 // ---- workspace layout (doubles) ----------------------------------------------
 //   [0]            int q_count | int big_count
-//   [1]            spare
+//   [1]            int ticket counter of k_fit_big_cost (64 per item) | spare
 //   [2 ...)        cluster descriptors, 8 doubles each (cap_q of them):
 //                  0 segment s, 1 cluster ordinal kc, 2 root (smallest point index), 3 members m,
 //                  4 position of the members in gsx/gsy, 5 max z of the instance, 6 ordinal among
@@ -1185,133 +1181,84 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
   }
 }
 
-// ---- large clusters: (cluster, heading batch) workgroups over the whole chip ----
-__global__ __launch_bounds__(FT) void k_fit_big_cost(const double *__restrict__ gsx,
-                                                     const double *__restrict__ gsy, int n_theta,
-                                                     double dtheta, int nb, double *__restrict__ fit_ws,
-                                                     int cap_rows, int cap_big) {
-  __shared__ double s_ct[TB], s_st[TB];
-  __shared__ double s_part[FW][4 * TB], s_bext[4 * TB], s_bsum[4 * TB];
+// ---- large clusters: one WAVE per (cluster, heading), items handed out through a counter -------------
+// The members stay in global memory (a cluster's 16 B x m are read by the waves that work on its headings at the
+// same time: L2 / L1 traffic, not HBM).  A wave sweeps the members three times (extents; sums and counts of
+// E1 / E2; squared deviations -- rectangle_fitting.py:83-111) with everything per heading in registers: no LDS
+// operand, no barrier and no workgroup-wide reduction inside an item, a dozen live values per lane (the first
+// formulation scored eight headings per sweep from 512-thread workgroups: 64 accumulators per lane, two waves per
+// SIMD, 80 wave reductions and seven barriers per item).
+constexpr int BIGC_T = 256;
+__global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restrict__ gsx,
+                                                         const double *__restrict__ gsy, int n_theta,
+                                                         double dtheta, double *__restrict__ fit_ws,
+                                                         int cap_rows, int cap_big) {
+  __shared__ double s_ct[MAXTH], s_st[MAXTH];
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
   const int nbig = min(W.counters[1], cap_big);
-  for (int item = blockIdx.x; item < nbig * nb; item += gridDim.x) {     // uniform per block
-  const int c = item / nb;
-  const int tb = (item - c * nb) * TB;
-  if (tb >= n_theta) continue;
-  __syncthreads();
-  const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
-  const int m = (int)dsc[3];
-  const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
-  double *s_cost = W.big_cost + (size_t)c * MAXTH;                              // heading costs of cluster c
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  if (threadIdx.x < TB) {
-    const double theta = (double)(tb + threadIdx.x) * dtheta;
+  if (nbig == 0) return;
+  if (threadIdx.x < MAXTH) {                   // heading table (rectangle_fitting.py:119-122)
+    const double theta = (double)threadIdx.x * dtheta;
     s_ct[threadIdx.x] = cos(theta);
     s_st[threadIdx.x] = sin(theta);
   }
   __syncthreads();
-  {
-      const int nt = min(TB, n_theta - tb);
-      double acc[4 * TB];
-#pragma unroll
-      for (int t = 0; t < TB; t++) { acc[4 * t] = INFINITY; acc[4 * t + 1] = -INFINITY; acc[4 * t + 2] = INFINITY; acc[4 * t + 3] = -INFINITY; }
-      double xn = 0.0, yn = 0.0;
-      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
-        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[t], st = s_st[t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          acc[4 * t] = fmin(acc[4 * t], c1); acc[4 * t + 1] = fmax(acc[4 * t + 1], c1);
-          acc[4 * t + 2] = fmin(acc[4 * t + 2], c2); acc[4 * t + 3] = fmax(acc[4 * t + 3], c2);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) {
-        const double r = (k & 1) ? wave_red<OpMax>(acc[k]) : wave_red<OpMin>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < 4 * TB) {
-        const int k = threadIdx.x;
-        double r = s_part[0][k];
-        for (int w = 1; w < FW; w++) r = (k & 1) ? fmax(r, s_part[w][k]) : fmin(r, s_part[w][k]);
-        s_bext[k] = r;
-      }
-      __syncthreads();
-      // sums and counts of E1 / E2
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) acc[k] = 0.0;
-      xn = 0.0; yn = 0.0;
-      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
-        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[t], st = s_st[t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
-          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
-          if (d1 < d2) { acc[4 * t] += d1; acc[4 * t + 1] += 1.0; }
-          else { acc[4 * t + 2] += d2; acc[4 * t + 3] += 1.0; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4 * TB; k++) {
-        const double r = wave_red<OpSum>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < 4 * TB) {
-        const int k = threadIdx.x;
-        double r = s_part[0][k];
-        for (int w = 1; w < FW; w++) r += s_part[w][k];
-        s_bsum[k] = r;
-      }
-      __syncthreads();
-      // squared deviations from the means
-#pragma unroll
-      for (int k = 0; k < 2 * TB; k++) acc[k] = 0.0;
-      xn = 0.0; yn = 0.0;
-      if ((int)threadIdx.x < m) { xn = mx[threadIdx.x]; yn = my[threadIdx.x]; }
-      for (int i = threadIdx.x; i < m; i += FT) {
-        const double x = xn, y = yn;                      // prefetched: the next load flies during the math
-        if (i + FT < m) { xn = mx[i + FT]; yn = my[i + FT]; }
-#pragma unroll
-        for (int t = 0; t < TB; t++) {
-          const double ct = s_ct[t], st = s_st[t];
-          const double c1 = x * ct + y * st;
-          const double c2 = x * (-st) + y * ct;
-          const double d1 = fmin(fabs(s_bext[4 * t + 1] - c1), fabs(c1 - s_bext[4 * t]));
-          const double d2 = fmin(fabs(s_bext[4 * t + 3] - c2), fabs(c2 - s_bext[4 * t + 2]));
-          const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
-          if (d1 < d2) { const double u = d1 - (n1 > 0.0 ? s_bsum[4 * t] / n1 : 0.0); acc[2 * t] += u * u; }
-          else { const double u = d2 - (n2 > 0.0 ? s_bsum[4 * t + 2] / n2 : 0.0); acc[2 * t + 1] += u * u; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2 * TB; k++) {
-        const double r = wave_red<OpSum>(acc[k]);
-        if (lane == 0) s_part[wave][k] = r;
-      }
-      __syncthreads();
-      if (threadIdx.x < nt) {
-        const int t = threadIdx.x;
-        double q1 = s_part[0][2 * t], q2 = s_part[0][2 * t + 1];
-        for (int w = 1; w < FW; w++) { q1 += s_part[w][2 * t]; q2 += s_part[w][2 * t + 1]; }
-        const double n1 = s_bsum[4 * t + 1], n2 = s_bsum[4 * t + 3];
-        double V1 = 0.0, V2 = 0.0;
-        if (n1 > 0.0) V1 = -(q1 / n1);
-        if (n2 > 0.0) V2 = -(q2 / n2);
-        s_cost[tb + t] = V1 + V2;
-      }
-      __syncthreads();
-  }
+  const int lane = lane_id();
+  const long long items = (long long)nbig * n_theta;
+  // Every lane adds 1 (the compiler turns that into ONE atomic of +64 per wave), so the counter runs in units of 64
+  // and the wave's item is its first lane's ticket / 64.  An atomic under `if (lane == 0)` at the head of this loop
+  // must not be used: the loop is then restructured so that the other 63 lanes spin on the old item while lane 0
+  // waits for them -- it never ends.
+  while (true) {
+    const int ticket = atomicAdd(&W.counters[2], 1);
+    const int it = __builtin_amdgcn_readfirstlane(ticket) >> 6;
+    if (it >= items) break;                    // every wave gets here: the counter only grows
+    const int c = it / n_theta, th = it - c * n_theta;
+    const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
+    const int m = (int)dsc[3];
+    const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
+    const double ct = s_ct[th], st = s_st[th], nst = -st;
+    double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+#pragma unroll 4
+    for (int i = lane; i < m; i += 64) {
+      const double x = mx[i], y = my[i];
+      const double c1 = x * ct + y * st;
+      const double c2 = x * nst + y * ct;
+      a0 = fmin(a0, c1); a1 = fmax(a1, c1);
+      b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+    }
+    a0 = wave_min_d(a0); a1 = wave_max_d(a1);
+    b0 = wave_min_d(b0); b1 = wave_max_d(b1);
+    double s1 = 0.0, s2 = 0.0;
+    int n1 = 0, n2 = 0;
+#pragma unroll 4
+    for (int i = lane; i < m; i += 64) {
+      const double x = mx[i], y = my[i];
+      const double c1 = x * ct + y * st;
+      const double c2 = x * nst + y * ct;
+      const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+      const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+      if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    n1 = wave_sum_i(n1); n2 = wave_sum_i(n2);
+    const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll 4
+    for (int i = lane; i < m; i += 64) {
+      const double x = mx[i], y = my[i];
+      const double c1 = x * ct + y * st;
+      const double c2 = x * nst + y * ct;
+      const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+      const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+      if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
+      else { const double u = d2 - m2; q2 += u * u; }
+    }
+    q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
+    double V1 = 0.0, V2 = 0.0;
+    if (n1) V1 = -(q1 / (double)n1);
+    if (n2) V2 = -(q2 / (double)n2);
+    if (lane == 0) W.big_cost[(size_t)c * MAXTH + th] = V1 + V2;
   }
 }
 
@@ -1441,10 +1388,10 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
                      vc, inst_class, inst_is_car, inst_box, inst_score, n_theta, dtheta,
                      car_aspect_max, cap_rows, rows, n_rows, status, fit_ws, cap_big);
   DFU3D_LAUNCH_CHECK();
-  const int nb = (n_theta + TB - 1) / TB;
-  const int g2 = cap_big * nb < 4096 ? cap_big * nb : 4096;           // persistent: items are looped over
-  hipLaunchKernelGGL(k_fit_big_cost, dim3(g2), dim3(FT), 0, st, sx, sy, n_theta, dtheta,
-                     nb, fit_ws, cap_rows, cap_big);
+  const long long bw = (long long)cap_big * n_theta;                    // one wave per item, at most
+  const int g2 = (int)(bw / (BIGC_T / 64) + 1 < 4096 ? bw / (BIGC_T / 64) + 1 : 4096);
+  hipLaunchKernelGGL(k_fit_big_cost, dim3(g2), dim3(BIGC_T), 0, st, sx, sy, n_theta, dtheta,
+                     fit_ws, cap_rows, cap_big);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_fit_big_box, dim3(cap_big < 2048 ? cap_big : 2048), dim3(FT), 0, st, sx, sy, max_inst,
                      vc, inst_class, inst_is_car, inst_box, inst_score,

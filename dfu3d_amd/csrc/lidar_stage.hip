@@ -56,9 +56,29 @@ __device__ __forceinline__ unsigned int f32_key(float v) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// One histogram increment per lane with active set, for a wave whose keys crowd into few buckets (the high bytes
+// of a view's heights do: thousands of equal sign/exponent bytes): up to four rounds in which the first remaining
+// lane's bucket is counted by ballot and added once, plain LDS atomics for what is left.  Same-address LDS
+// atomics serialise lane by lane; this was most of the kernel's time.
+__device__ __forceinline__ void hist_add_wave(int *hist, bool active, int bucket) {
+  unsigned long long rem = __ballot(active);
+  const int lane = lane_id();
+  for (int r = 0; r < 4 && rem; r++) {                      // uniform
+    const int leader = __ffsll((long long)rem) - 1;
+    const int lb = __shfl(bucket, leader, 64);
+    const bool same = active && bucket == lb;
+    const unsigned long long sm = __ballot(same);
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(sm));
+    rem &= ~sm;
+    if (same) active = false;
+  }
+  if (active) atomicAdd(&hist[bucket], 1);
+}
+
 // Radix select of the value with 0-based rank k among n keys produced by
 // keyfn(i) (64-bit ordered keys).  All threads of the block call it; returns
-// the key to every thread.  hist: 256 ints of LDS, s_sel: 2 x u64 of LDS.
+// the key to every thread.  hist: 256 ints of LDS, s_sel: 3 x u64 of LDS.
+// Leaves as soon as the bucket that holds the rank has a single key in it (one more sweep fetches that key).
 template <typename KeyFn>
 __device__ unsigned long long block_select(int n, int k, KeyFn keyfn, int *hist,
                                            unsigned long long *s_sel) {
@@ -67,27 +87,46 @@ __device__ unsigned long long block_select(int n, int k, KeyFn keyfn, int *hist,
   for (int shift = 56; shift >= 0; shift -= 8) {
     for (int b = threadIdx.x; b < 256; b += NT) hist[b] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
-      const unsigned long long key = keyfn(i);
-      if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xFFull)], 1);
+    for (int base = 0; base < n; base += NT) {              // uniform trip count: ballots inside
+      const int i = base + threadIdx.x;
+      unsigned long long key = 0ull;
+      bool act = false;
+      if (i < n) { key = keyfn(i); act = (key & mask) == prefix; }
+      hist_add_wave(hist, act, (int)((key >> shift) & 0xFFull));
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, b = 0;
-      for (; b < 256; b++) {
-        const int c = hist[b];
-        if (acc + c > kk) break;
-        acc += c;
+    if (threadIdx.x < 64) {       // the bucket that holds rank kk: one wave, four buckets per lane
+      const int l = threadIdx.x;
+      const int c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+      const int inc = wave_incl_scan(c0 + c1 + c2 + c3);
+      const unsigned long long past = __ballot(inc > kk);     // lanes whose running total passes kk
+      const int tl = past ? (__ffsll((long long)past) - 1) : 63;   // (past == 0 cannot happen for k < n)
+      if (l == tl) {
+        int acc = inc - (c0 + c1 + c2 + c3), b = 4 * l, cb = c0;
+        if (acc + c0 <= kk) { acc += c0; b++; cb = c1;
+          if (acc + c1 <= kk) { acc += c1; b++; cb = c2;
+            if (acc + c2 <= kk) { acc += c2; b++; cb = c3; } } }
+        s_sel[0] = prefix | ((unsigned long long)b << shift);
+        s_sel[1] = (unsigned long long)(kk - acc);
+        s_sel[2] = (unsigned long long)cb;
       }
-      if (b > 255) b = 255;      // cannot happen for k < n
-      s_sel[0] = prefix | ((unsigned long long)b << shift);
-      s_sel[1] = (unsigned long long)(kk - acc);
     }
     __syncthreads();
     prefix = s_sel[0];
     kk = (int)s_sel[1];
+    const int in_bucket = (int)s_sel[2];
     mask |= (0xFFull << shift);
     __syncthreads();
+    if (in_bucket == 1 && shift > 0) {                      // (uniform) exactly one key carries this prefix
+      for (int i = threadIdx.x; i < n; i += NT) {
+        const unsigned long long key = keyfn(i);
+        if ((key & mask) == prefix) s_sel[0] = key;
+      }
+      __syncthreads();
+      prefix = s_sel[0];
+      __syncthreads();
+      return prefix;
+    }
   }
   return prefix;
 }
@@ -98,15 +137,39 @@ __device__ __forceinline__ double key_to_double(unsigned long long k) {
 }
 
 // median of n fp64 values valfn(i) exactly as np.median: mean of the two
-// middle order statistics for even n.
+// middle order statistics for even n.  The lower one needs no second selection: it is the upper one again when
+// enough keys equal it, otherwise the largest key below it -- one sweep.
 template <typename ValFn>
 __device__ double block_median(int n, ValFn valfn, int *hist, unsigned long long *s_sel) {
   auto keyfn = [&](int i) { return ordered_key(valfn(i)); };
   const int k2 = n / 2;
-  const double hi = key_to_double(block_select(n, k2, keyfn, hist, s_sel));
+  const unsigned long long hk = block_select(n, k2, keyfn, hist, s_sel);
+  const double hi = key_to_double(hk);
   if (n & 1) return hi;
-  const double lo = key_to_double(block_select(n, k2 - 1, keyfn, hist, s_sel));
-  return (lo + hi) / 2.0;
+  if (threadIdx.x == 0) { s_sel[0] = 0ull; hist[0] = 0; }
+  __syncthreads();
+  int less = 0;
+  unsigned long long below = 0ull;                          // ordered keys of real numbers are > 0
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const unsigned long long key = keyfn(i);
+    if (key < hk) { less++; below = key > below ? key : below; }
+  }
+  less = wave_sum_i(less);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long o = ((unsigned long long)(unsigned int)__shfl_xor((int)(below >> 32), m, 64) << 32) |
+                                 (unsigned long long)(unsigned int)__shfl_xor((int)(below & 0xFFFFFFFFull), m, 64);
+    below = o > below ? o : below;
+  }
+  if (lane_id() == 0) {
+    if (less) atomicAdd(&hist[0], less);
+    if (below) atomicMax(&s_sel[0], below);
+  }
+  __syncthreads();
+  const int n_less = hist[0];
+  const unsigned long long lk = (n_less <= k2 - 1) ? hk : s_sel[0];
+  __syncthreads();
+  return (key_to_double(lk) + hi) / 2.0;
 }
 
 __device__ __forceinline__ double block_sum_d(double v, double *s_red) {
@@ -142,7 +205,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
     int *__restrict__ cand_idx, double *__restrict__ plane) {
   __shared__ int s_w[NW];
   __shared__ int s_hist[256];
-  __shared__ unsigned long long s_sel[2];
+  __shared__ unsigned long long s_sel[3];
   __shared__ double s_red[NW];
   __shared__ int s_redi[NW];
   __shared__ double s_model[RB][3];

@@ -165,81 +165,201 @@ __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix,
   }
 }
 
+// ---- tier 1 of the classification: boundary tables instead of inverse trigonometry ------------------
+// The reference bins theta = acos(z/r) and phi = atan(y/x) (my_loader.py:166-177).  Both functions are monotone, so
+// "theta lies in bin k" is the same statement as "q = -z/r lies between -cos of the bin's two edges", and likewise
+// for phi with q = t / (1 + |t|), t = y/x = tan(phi) -- computed as y sgn(x) / (|x| + |y|), stable for every
+// direction, and with 1/2 <= dq/dphi <= 1.  Tier 1 therefore never evaluates acos / atan: per axis a table
+// over q (uniform cells, built on the device in fp64 by k_bp_tables, float32 entries) gives for the cell of q
+// three CONSECUTIVE bin edges in q-space (prv < nxt < nxt2) and the index kn of the middle one; q is accepted for
+// bin kn-1 or kn only when it is farther than delta from the edges around it, delta bounding |q - q of the fp64
+// reference| (see pixel_bin_fast).  Correctness needs only that the three edges are consecutive -- how well the cell
+// matches q merely decides how often the answer is "undecided".  Edges outside the range of the angle are +-inf.
+constexpr int TAB_T_MAX = 65536, TAB_P_MAX = 16384;    // cells per axis (16 B each)
 constexpr uint32_t AMBIG = 0xFFFFFFFEu;
+constexpr int TB_AMBIG = (int)0x80000000;
 
-// constants of the tier-1 classification, prepared on the host
 struct FastGeom {
-  float r_lo, r_hi, theta_min;
-  double inv_t, inv_p;
+  float r_lo, r_hi, z_max, q_tmin;       // q_tmin = -cos(theta_min) (-inf / +inf outside (0, pi))
+  float tq0, tinv, pq0, pinv;            // cell of q: (q - q0) * inv
+  int tJ, pJ;
+  double tq0d, twd, pq0d, pwd;           // the same origins and the cell widths in fp64, for the table builder
 };
 inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
+  const double pi = 3.14159265358979323846;
   FastGeom f;
   // r certain only for the 1-cell grid and well inside it; otherwise an empty interval
   f.r_lo = (g.grid_r == 1) ? (float)(g.rmin_r + 2e-3) : 1.0f;
   f.r_hi = (g.grid_r == 1) ? (float)((g.rmin_r + g.vsize_r) * 0.9998) : 0.0f;
-  f.theta_min = (float)g.theta_min;
-  f.inv_t = 1.0 / g.vsize_t;
-  f.inv_p = 1.0 / g.vsize_p;
+  f.z_max = (float)g.z_max;
+  f.q_tmin = g.theta_min <= 0.0 ? -INFINITY : (g.theta_min >= pi ? INFINITY : (float)-__builtin_cos(g.theta_min));
+  auto cells = [](double lo, double hi, double min_width, int cap, double &q0, double &w) {
+    if (!(hi > lo) || !(min_width > 0.0)) { q0 = lo; w = 1.0; return 1; }
+    double J = __builtin_ceil((hi - lo) / (0.5 * min_width));
+    if (!(J >= 1.0)) J = 1.0;
+    if (J > (double)cap) J = (double)cap;
+    q0 = lo; w = (hi - lo) / J;
+    return (int)J;
+  };
+  {   // theta: the window's edges, clipped to where tier 1 works at all (sin(theta)^2 > 1e-4)
+    const double a_lo = __builtin_fmax(g.rmin_t + (double)g.t_lo * g.vsize_t, 0.0100002);
+    const double a_hi = __builtin_fmin(g.rmin_t + (double)(g.t_lo + g.t_n) * g.vsize_t, pi - 0.0100002);
+    const double smin = __builtin_fmin(__builtin_sin(a_lo), __builtin_sin(a_hi));
+    f.tJ = cells(-__builtin_cos(a_lo), -__builtin_cos(a_hi), g.vsize_t * smin, TAB_T_MAX, f.tq0d, f.twd);
+  }
+  {   // phi: q = tan(phi) / (1 + |tan(phi)|) in (-1, 1); dq/dphi lies in [1/2, 1]
+    const double b_lo = __builtin_fmax(g.rmin_p + (double)g.p_lo * g.vsize_p, -pi / 2);
+    const double b_hi = __builtin_fmin(g.rmin_p + (double)(g.p_lo + g.p_n) * g.vsize_p, pi / 2);
+    auto qphi = [](double P) { return __builtin_sin(P) / (__builtin_fabs(__builtin_cos(P)) + __builtin_fabs(__builtin_sin(P))); };
+    f.pJ = cells(qphi(b_lo), qphi(b_hi), 0.5 * g.vsize_p, TAB_P_MAX, f.pq0d, f.pwd);
+  }
+  f.tq0 = (float)f.tq0d; f.tinv = (float)(1.0 / f.twd);
+  f.pq0 = (float)f.pq0d; f.pinv = (float)(1.0 / f.pwd);
   return f;
 }
 
-// fp32 estimates of the spherical angles of an fp64 point, each with a bound on
-// |estimate - fp64 value| (my_loader.py:166-169 evaluated in double).  Error budget:
-//   cz = zf/rf       relative 5.1e-7 (three float conversions, the sum of squares, v_sqrt and
-//                    v_rcp at 1 ulp each, one product), i.e. <= 5.1e-7/sin(theta) in theta;
-//                    acosf <= 4 ulp <= 1e-6
-//   ph = atanf(y/x)  <= 1.5e-7 from the ratio (v_rcp), atanf <= 5 ulp <= 6e-7
-// eps_t / eps_p carry a factor >= 3 on top; dfu3d_selftest_angles() measures the real
-// ratio error/bound on the device and the GPU tests require it to stay below 0.5.
-// Returns false where no bound is given (origin, poles, x == 0).
-__device__ __forceinline__ bool angle_estimate(double x, double y, double z, float &rf, float &th,
-                                               float &eps_t, float &ph, float &eps_p) {
-  const float xf = (float)x, yf = (float)y, zf = (float)z;
-  const float r2 = xf * xf + yf * yf + zf * zf;
-  rf = __builtin_amdgcn_sqrtf(r2);                               // 1 ulp, no denormal handling needed
-  if (!(rf > 1e-3f) || !(rf < 1e15f)) return false;
-  const float cz = zf * __builtin_amdgcn_rcpf(rf);                // 1 ulp reciprocal
-  const float s2 = 1.0f - cz * cz;
-  if (!(s2 > 1e-4f)) return false;                                // near the poles: d(acos) blows up
-  th = acosf(cz);
-  eps_t = 3e-6f + 1e-6f * rsqrtf(s2);
-  if (!(fabsf(xf) > 1e-20f)) return false;
-  ph = atanf(yf * __builtin_amdgcn_rcpf(xf));
-  eps_p = 3e-6f;
-  return true;
+// one thread per cell: entry = (prv, nxt, nxt2, kn) with nxt the first edge at or above the cell's start
+__global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float4 *__restrict__ tab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fg.tJ + fg.pJ) return;
+  const double pi = 3.14159265358979323846;
+  const bool is_t = i < fg.tJ;
+  const int j = is_t ? i : i - fg.tJ;
+  const double s = is_t ? fg.tq0d + (double)j * fg.twd : fg.pq0d + (double)j * fg.pwd;
+  const double rmin = is_t ? g.rmin_t : g.rmin_p, vs = is_t ? g.vsize_t : g.vsize_p;
+  auto edge = [&](long long k) -> double {          // edge k of the axis in q-space
+    const double B = rmin + (double)k * vs;
+    if (is_t) return B <= 0.0 ? -INFINITY : (B >= pi ? INFINITY : -cos(B));
+    return B <= -pi / 2 ? -INFINITY : (B >= pi / 2 ? INFINITY : sin(B) / (fabs(cos(B)) + fabs(sin(B))));
+  };
+  // the angle at the cell's start: theta = acos(-q); phi = atan(q / (1 - |q|))
+  const double a = is_t ? acos(fmin(fmax(-s, -1.0), 1.0)) : (fabs(s) < 1.0 ? atan(s / (1.0 - fabs(s))) : copysign(pi / 2, s));
+  double kf = ceil((a - rmin) / vs);
+  kf = fmin(fmax(kf, -1.0e9), 1.0e9);
+  long long kn = (long long)kf;
+  for (int r = 0; r < 8 && edge(kn) < s; r++) kn++;
+  for (int r = 0; r < 8 && edge(kn - 1) >= s; r++) kn--;
+  tab[i] = make_float4((float)edge(kn - 1), (float)edge(kn), (float)edge(kn + 1), __int_as_float((int)kn));
 }
 
-// Tier 1 of the classification.  x,y,z come from the exact fp64 back-projection;
-// the spherical angles are estimated in fp32 and accepted only when the
-// estimate is farther from every decision boundary (theta_min, bin edges,
-// r range) than a rigorous bound on |fp32 estimate - fp64 value|, in which case
-// the fp64 path of pixel_bin() would decide identically.  Everything else
-// returns AMBIG and is classified by pixel_bin() in k_bp_bin_amb.
-__device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc,
+// bin of q from the axis' table, or TB_AMBIG
+__device__ __forceinline__ int tab_bin(const float4 *__restrict__ tab, float q0, float inv_w, int J, float q,
+                                       float delta) {
+  int j = (int)((q - q0) * inv_w);
+  j = min(max(j, 0), J - 1);
+  const float4 e = tab[j];
+  const int kn = __float_as_int(e.w);
+  if (!(q > e.x + delta)) return TB_AMBIG;
+  if (q < e.y - delta) return kn - 1;
+  if (q > e.y + delta && q < e.z - delta) return kn;
+  return TB_AMBIG;
+}
+
+// ---- float32 back-projection estimate ------------------------------------------------------------
+// calibration_kitti.py:134-144 + 89-102 collapse, per LiDAR coordinate j, to
+//   p_j = d * (a_j*u + b_j*v + c_j) + e_j      a_j = M0j/fu, b_j = M1j/fv, c_j = M2j - cu*a_j - cv*b_j,
+//                                             e_j = tx*M0j + ty*M1j + M3j          (M = rows of Minv)
+// k_bp_prep forms the twelve constants per view in fp64 and rounds them to float32; a pixel then costs
+// nine float32 FMAs.  ERR bounds |estimate - fp64 value| per coordinate: the constants carry 2^-24 relative
+// rounding each, the three FMAs one rounding each, so |err| <= 2^-24 (3 d W_j + |e_j| + |p_j|) with
+// W_j = |a_j| u + |b_j| v + |c_j|; the bound used is 2^-22 (d * wsum + esum + |p|_1), wsum / esum being the sums of
+// the per-view maxima of W_j / |e_j| -- at least 1.3x that, and dfu3d_selftest_backproject measures
+// the real ratio on the device (the GPU test requires < 0.5).
+struct FastCal {
+  float a[3], b[3], c[3], e[3];
+  float wsum, esum, pad0, pad1;
+};
+static_assert(sizeof(FastCal) == 64, "FastCal");
+
+__global__ void k_bp_prep(const ViewCalib *__restrict__ calib, int V, int H, int W, FastCal *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const ViewCalib c = calib[v];
+  FastCal f;
+  double wsum = 0.0, esum = 0.0;
+  for (int j = 0; j < 3; j++) {
+    const double a = (double)c.Minv[0 + j] / (double)c.fu, b = (double)c.Minv[3 + j] / (double)c.fv;
+    const double cc = (double)c.Minv[6 + j] - (double)c.cu * a - (double)c.cv * b;
+    const double e = (double)c.tx * (double)c.Minv[0 + j] + (double)c.ty * (double)c.Minv[3 + j] + (double)c.Minv[9 + j];
+    f.a[j] = (float)a; f.b[j] = (float)b; f.c[j] = (float)cc; f.e[j] = (float)e;
+    // the terms of c_j cancel against a_j*u + b_j*v: bound W_j by the magnitudes of its parts
+    wsum += fabs(a) * (double)(W > 1 ? W - 1 : 1) + fabs(b) * (double)(H > 1 ? H - 1 : 1) + fabs((double)c.Minv[6 + j]) +
+            fabs((double)c.cu * a) + fabs((double)c.cv * b);
+    esum += fabs((double)c.tx * (double)c.Minv[0 + j]) + fabs((double)c.ty * (double)c.Minv[3 + j]) + fabs((double)c.Minv[9 + j]);
+  }
+  f.wsum = (float)(wsum * 1.0000002);
+  f.esum = (float)(esum * 1.0000002);
+  f.pad0 = f.pad1 = 0.0f;
+  out[v] = f;
+}
+
+__device__ __forceinline__ void backproject_f32(const FastCal &fc, int col, int row, float d, float &xf, float &yf,
+                                                float &zf, float &err) {
+  const float u = (float)col, v = (float)row;
+  const float w0 = __fmaf_rn(fc.a[0], u, __fmaf_rn(fc.b[0], v, fc.c[0]));
+  const float w1 = __fmaf_rn(fc.a[1], u, __fmaf_rn(fc.b[1], v, fc.c[1]));
+  const float w2 = __fmaf_rn(fc.a[2], u, __fmaf_rn(fc.b[2], v, fc.c[2]));
+  xf = __fmaf_rn(d, w0, fc.e[0]);
+  yf = __fmaf_rn(d, w1, fc.e[1]);
+  zf = __fmaf_rn(d, w2, fc.e[2]);
+  err = 2.3841858e-07f * (__fmaf_rn(fabsf(d), fc.wsum, fc.esum) + fabsf(xf) + fabsf(yf) + fabsf(zf));
+}
+
+// Tier 1 of the classification, all in float32.  From the back-projection estimate (coordinates within `err` of
+// the reference's fp64 ones) it forms q_t = -zf/rf and q_p = yf/xf and looks both up in the edge tables; a decision
+// is taken only when the estimate is farther from every boundary involved (z_max, theta_min, the r range, the bin
+// edges) than a bound on |estimate - fp64 value|, in which case the fp64 path of pixel_bin() decides identically;
+// everything else returns AMBIG and is classified by pixel_bin() (k_bp_bin_amb).  Error budget:
+//   q_t   v_sqrt, v_rcp at 1 ulp, the sum of squares and one product: <= 5.1e-7 relative, i.e. 5.1e-7 absolute
+//         (|q_t| <= 1); the coordinate error turns the direction by at most turn = sqrt(3) err / r, which moves the
+//         cosine by at most turn; table entries are rounded to float32 (6e-8).  delta_t = 1.5e-6 + 1.05 turn.
+//   q_p   one sum, v_rcp, one product: <= 2.4e-7 (|q_p| < 1), table rounding 6e-8; the coordinate error moves phi by
+//         at most turn / sin(theta) and q_p by no more than that (dq/dphi <= 1).
+//         delta_p = 1.5e-6 + 1.1 turn / sin(theta).
+// dfu3d_selftest_classify() runs this function against pixel_bin() on random pixels of the real geometry and
+// calibration: the GPU tests require zero disagreements among the decided ones.
+// The exact fp64 coordinate that serves as the voxel key is computed only for pixels that are kept (want_key).
+__device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc, const FastCal &fc,
                                                    const dfu3d_bin_geom &g, const FastGeom &fg,
-                                                   int row, int col,
-                                                   float d, int key_axis, double &key, int &it_out,
-                                                   int &ip_out) {
+                                                   const float4 *__restrict__ tab,
+                                                   int row, int col, float d, const KeyCol &kc, bool want_key,
+                                                   double &key, int &it_out, int &ip_out) {
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
-  double x, y, z;
-  pixel_to_lidar(c, rc, col, row, d, x, y, z);
-  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540 (exact)
-  key = (key_axis == 2) ? z : y;
-  if (key == 0.0) key = 0.0;
-  float rf, th, eps_t, ph, eps_p;
-  if (!angle_estimate(x, y, z, rf, th, eps_t, ph, eps_p)) return AMBIG;
+  float xf, yf, zf, err;
+  backproject_f32(fc, col, row, d, xf, yf, zf, err);
+  if (zf > fg.z_max + err) return NOBIN;                          // certainly z >= z_max (my_loader.py:540)
+  if (!(zf < fg.z_max - err)) return AMBIG;
+  const float r2 = xf * xf + yf * yf + zf * zf;
+  const float rf = __builtin_amdgcn_sqrtf(r2);
+  if (!(rf > 1e-3f) || !(rf < 1e15f)) return AMBIG;
   // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
-  if (!(rf > fg.r_lo && rf < fg.r_hi)) return AMBIG;
-  if (th < fg.theta_min - eps_t) return NOBIN;                    // certainly theta <= theta_min
-  if (!(th > fg.theta_min + eps_t)) return AMBIG;
-  const double qt = ((double)th - g.rmin_t) * fg.inv_t, qp = ((double)ph - g.rmin_p) * fg.inv_p;
-  const double ft = qt - floor(qt), fp = qp - floor(qp);
-  const double mt = (double)eps_t * fg.inv_t + 1e-6, mp = (double)eps_p * fg.inv_p + 1e-6;
-  if (!(ft > mt && ft < 1.0 - mt && fp > mp && fp < 1.0 - mp)) return AMBIG;
-  const int it = (int)floor(qt) - g.t_lo, ip = (int)floor(qp) - g.p_lo;
+  const float er = 2.0f * err;                                    // |rf - r| <= sqrt(3) err + rounding
+  if (!(rf - er > fg.r_lo && rf + er < fg.r_hi)) return AMBIG;
+  const float ir = __builtin_amdgcn_rcpf(rf);
+  const float cz = zf * ir;
+  const float s2 = 1.0f - cz * cz;
+  if (!(s2 > 1e-4f)) return AMBIG;                                // near the poles
+  const float turn = err * ir * 1.7320510f;                       // direction error: |(dx,dy,dz)| <= sqrt(3) err
+  const float dq = 1.5e-6f + 1.05f * turn;
+  const float qt = -cz;
+  if (qt < fg.q_tmin - dq) return NOBIN;                          // certainly theta <= theta_min (my_loader.py:175)
+  if (!(qt > fg.q_tmin + dq)) return AMBIG;
+  const int kt = tab_bin(tab, fg.tq0, fg.tinv, fg.tJ, qt, dq);
+  if (kt == TB_AMBIG) return AMBIG;
+  if (!(fabsf(xf) > 8.0f * err + 1e-20f)) return AMBIG;           // the sign of x decides the branch of atan(y/x)
+  const float qa = yf * __builtin_amdgcn_rcpf(fabsf(xf) + fabsf(yf));
+  const float qp = xf < 0.0f ? -qa : qa;
+  const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * rsqrtf(s2));
+  if (kp == TB_AMBIG) return AMBIG;
+  // (kt - t_lo) cannot wrap: |kt| <= 1e9
+  const int it = kt - g.t_lo, ip = kp - g.p_lo;
   if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) return AMBIG;
   it_out = it;
   ip_out = ip;
+  if (want_key) {
+    key = pixel_to_lidar_axis(c, rc, kc, col, row, d);
+    if (key == 0.0) key = 0.0;
+  }
   return (uint32_t)(it * g.p_n + ip);
 }
 
@@ -252,7 +372,8 @@ constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x ph
 
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
-    dfu3d_bin_geom g, FastGeom fg, int W, int H, int tiles_x, int key_axis,
+    const FastCal *__restrict__ fastcal, const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
+    int tiles_x, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
     int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
   __shared__ uint32_t s_bits[32];                 // this tile's piece of the first-pixel bit map
@@ -263,7 +384,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
+  const FastCal fc = fastcal[v];
   const Recip rc = make_recip(c);
+  const KeyCol kcol = load_key_col(calib + v, key_axis);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -297,7 +420,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       keys[k] = 0.0;
       its[k] = 0; ips[k] = 0;
       if (col + k < W) {
-        const uint32_t b = pixel_bin_fast(c, rc, g, fg, row, col + k, d[k], key_axis, keys[k],
+        const uint32_t b = pixel_bin_fast(c, rc, fc, g, fg, tab, row, col + k, d[k], kcol, true, keys[k],
                                           its[k], ips[k]);
         if (b == AMBIG) {
           s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
@@ -462,8 +585,8 @@ __device__ __forceinline__ void emit_voxel(const VoxOut &o, size_t at, const Vie
 constexpr int VXB = 256;
 constexpr int VX_PIECES = 64;                 // 64-pixel row pieces per workgroup = 4096 pixels
 __global__ __launch_bounds__(VXB) void k_bp_vox(
-    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, FastGeom fg,
-    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
+    const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
     uint32_t *__restrict__ status) {
@@ -494,7 +617,9 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   const int rank0 = (int)R.wpre[(size_t)v * R.NJ + j0];
   const Table T = table_view(table, E_total);
   const ViewCalib c = calib[v];
+  const FastCal fc = fastcal[v];
   const Recip rc = make_recip(c);
+  const KeyCol kcol = load_key_col(calib + v, key_axis);
   const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
   const float *dv = depth + (size_t)v * HW;
   const int64_t tb0 = (int64_t)v * E_view;
@@ -506,8 +631,8 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     // the bin of the first pixel: the same two-tier classification as in P1
     double key_f;
     int it_, ip_;
-    const int fr = (int)f / W, fc = (int)f - fr * W;
-    uint32_t b = pixel_bin_fast(c, rc, g, fg, fr, fc, dv[f], key_axis, key_f, it_, ip_);
+    const int fr = (int)f / W, fcol = (int)f - fr * W;
+    uint32_t b = pixel_bin_fast(c, rc, fc, g, fg, tab, fr, fcol, dv[f], kcol, false, key_f, it_, ip_);
     if (b == AMBIG) b = pixel_bin(c, rc, g, W, (int)f, dv[f], key_axis, key_f, rerr);
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
     const int64_t e = tb0 + b;
@@ -722,49 +847,109 @@ __global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restric
   n_vox[v] = min(min(n_vox[v], cap_vox), max_voxels);
 }
 
-// max over n pseudo-random points of |fp32 estimate - fp64 value| / bound, for theta and phi
-__global__ void k_selftest_angles(long long n, unsigned long long seed, double range_xy,
-                                  double z_lo, double z_hi, unsigned long long *out) {
-  double worst_t = 0.0, worst_p = 0.0;
+// tier 1 (pixel_bin_fast) against the fp64 classification (pixel_bin) on n pseudo-random pixels of view 0:
+// out[0] pixels tried, out[1] undecided by tier 1, out[2] DISAGREEMENTS among the decided (bin, or the key of a kept
+// pixel), out[3] pixels tier 1 kept.  Depths in [d_lo, d_hi), every fourth one 50x closer.
+__global__ void k_selftest_classify(const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
+                                    const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int H, int W,
+                                    int key_axis, long long n, unsigned long long seed, double d_lo, double d_hi,
+                                    unsigned long long *out) {
+  const ViewCalib c = calib[0];
+  const FastCal fc = fastcal[0];
+  const Recip rc = make_recip(c);
+  const KeyCol kcol = load_key_col(calib, key_axis);
+  unsigned long long tried = 0, undecided = 0, wrong = 0, kept = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const unsigned long long a = mix64(seed + 3ull * (unsigned long long)i),
                              b = mix64(seed + 3ull * (unsigned long long)i + 1ull),
-                             c = mix64(seed + 3ull * (unsigned long long)i + 2ull);
-    const double ux = (double)(a >> 11) * (1.0 / 9007199254740992.0),
-                 uy = (double)(b >> 11) * (1.0 / 9007199254740992.0),
-                 uz = (double)(c >> 11) * (1.0 / 9007199254740992.0);
-    // every third point close to the sensor, where the angles move fastest
-    const double sc = (i % 3 == 0) ? 0.02 : 1.0;
-    const double x = (2.0 * ux - 1.0) * range_xy * sc, y = (2.0 * uy - 1.0) * range_xy * sc,
-                 z = z_lo + (z_hi - z_lo) * uz;
-    float rf, th, et, ph, ep;
-    if (!angle_estimate(x, y, z, rf, th, et, ph, ep)) continue;
-    double s2 = x * x;
-    s2 = s2 + y * y;
-    s2 = s2 + z * z;
-    const double theta = acos(z / sqrt(s2)), phi = atan(y / x);
-    worst_t = fmax(worst_t, fabs((double)th - theta) / (double)et);
-    worst_p = fmax(worst_p, fabs((double)ph - phi) / (double)ep);
+                             e = mix64(seed + 3ull * (unsigned long long)i + 2ull);
+    const int col = (int)(a % (unsigned long long)W), row = (int)(b % (unsigned long long)H);
+    const double ud = (double)(e >> 11) * (1.0 / 9007199254740992.0);
+    const float d = (float)((d_lo + (d_hi - d_lo) * ud) * ((i & 3) == 0 ? 0.02 : 1.0));
+    double k1 = 0.0, k2 = 0.0;
+    int it_, ip_;
+    bool rerr = false;
+    const uint32_t b1 = pixel_bin_fast(c, rc, fc, g, fg, tab, row, col, d, kcol, true, k1, it_, ip_);
+    const uint32_t b2 = pixel_bin(c, rc, g, W, row * W + col, d, key_axis, k2, rerr);
+    tried++;
+    if (b1 == AMBIG) { undecided++; continue; }
+    if (b1 != b2 || (b1 != NOBIN && __double_as_longlong(k1) != __double_as_longlong(k2))) wrong++;
+    if (b1 != NOBIN) kept++;
   }
-  worst_t = wave_max_d(worst_t);
-  worst_p = wave_max_d(worst_p);
-  if (lane_id() == 0) {                      // non-negative doubles order like their bit patterns
-    atomicMax(&out[0], (unsigned long long)__double_as_longlong(worst_t));
-    atomicMax(&out[1], (unsigned long long)__double_as_longlong(worst_p));
+  tried = wave_sum_u64(tried); undecided = wave_sum_u64(undecided);
+  wrong = wave_sum_u64(wrong); kept = wave_sum_u64(kept);
+  if (lane_id() == 0) {
+    atomicAdd(&out[0], tried); atomicAdd(&out[1], undecided); atomicAdd(&out[2], wrong); atomicAdd(&out[3], kept);
   }
+}
+
+// max over n pseudo-random pixels of |float32 back-projection - fp64 back-projection| / bound, over the three
+// coordinates (view 0 of `calib`, depths in [d_lo, d_hi), every fourth one 50x closer)
+__global__ void k_selftest_backproject(const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
+                                       int H, int W, long long n, unsigned long long seed, double d_lo,
+                                       double d_hi, unsigned long long *out) {
+  const ViewCalib c = calib[0];
+  const FastCal fc = fastcal[0];
+  const Recip rc = make_recip(c);
+  double worst = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long a = mix64(seed + 3ull * (unsigned long long)i),
+                             b = mix64(seed + 3ull * (unsigned long long)i + 1ull),
+                             e = mix64(seed + 3ull * (unsigned long long)i + 2ull);
+    const int col = (int)(a % (unsigned long long)W), row = (int)(b % (unsigned long long)H);
+    const double ud = (double)(e >> 11) * (1.0 / 9007199254740992.0);
+    const float d = (float)((d_lo + (d_hi - d_lo) * ud) * ((i & 3) == 0 ? 0.02 : 1.0));
+    if (!(d > 0.0f)) continue;
+    double x, y, z;
+    pixel_to_lidar(c, rc, col, row, d, x, y, z);
+    float xf, yf, zf, err;
+    backproject_f32(fc, col, row, d, xf, yf, zf, err);
+    const double m = fmax(fmax(fabs((double)xf - x), fabs((double)yf - y)), fabs((double)zf - z));
+    worst = fmax(worst, m / (double)err);
+  }
+  worst = wave_max_d(worst);
+  if (lane_id() == 0) atomicMax(&out[0], (unsigned long long)__double_as_longlong(worst));
 }
 
 }  // namespace
 
-extern "C" int dfu3d_selftest_angles(int64_t n, uint64_t seed, double range_xy, double z_lo,
-                                     double z_hi, double *out2, void *stream) {
+extern "C" int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
+                                       int32_t key_axis, int64_t n, uint64_t seed, double d_lo, double d_hi,
+                                       void *scratch, uint64_t *out4, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
-  if (!out2 || n <= 0 || !(range_xy > 0.0) || !(z_hi > z_lo)) return DFU3D_EINVAL;
-  if (hipMemsetAsync(out2, 0, 16, (hipStream_t)stream) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_selftest_angles, dim3(4096), dim3(256), 0, (hipStream_t)stream,
-                     (long long)n, (unsigned long long)seed, range_xy, z_lo, z_hi,
-                     (unsigned long long *)out2);
+  if (!calib || !geom || !scratch || !out4 || n <= 0 || H <= 0 || W <= 0 || !(d_hi > d_lo) || !(d_lo >= 0.0))
+    return DFU3D_EINVAL;
+  if (key_axis != 1 && key_axis != 2) return DFU3D_EINVAL;
+  if ((uintptr_t)scratch & 15u) return DFU3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const FastGeom fg = make_fast_geom(*geom);
+  FastCal *fastcal = (FastCal *)scratch;
+  float4 *tab = (float4 *)((char *)scratch + 64);
+  if (hipMemsetAsync(out4, 0, 32, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_bp_prep, dim3(1), dim3(64), 0, st, (const ViewCalib *)calib, 1, H, W, fastcal);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 255) / 256), dim3(256), 0, st, *geom, fg, tab);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_selftest_classify, dim3(2048), dim3(256), 0, st, (const ViewCalib *)calib, fastcal, tab,
+                     *geom, fg, H, W, key_axis, (long long)n, (unsigned long long)seed, d_lo, d_hi,
+                     (unsigned long long *)out4);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
+extern "C" int dfu3d_selftest_backproject(const float *calib, int32_t H, int32_t W, int64_t n, uint64_t seed,
+                                          double d_lo, double d_hi, void *scratch64, double *out1, void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!calib || !scratch64 || !out1 || n <= 0 || H <= 0 || W <= 0 || !(d_hi > d_lo) || !(d_lo >= 0.0)) return DFU3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out1, 0, 8, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_bp_prep, dim3(1), dim3(64), 0, st, (const ViewCalib *)calib, 1, H, W, (FastCal *)scratch64);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_selftest_backproject, dim3(2048), dim3(256), 0, st, (const ViewCalib *)calib,
+                     (const FastCal *)scratch64, H, W, (long long)n, (unsigned long long)seed, d_lo, d_hi,
+                     (unsigned long long *)out1);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
@@ -802,7 +987,8 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 
 // Scratch carve-up.
 // blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], pad[V], bitmap[V*BW] -- everything up to here is
-//   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q]
+//   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
+//   calibration constants (64 B per view) and the edge tables of tier 1 (16 B x (TAB_T_MAX + TAB_P_MAX) at most)
 //   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
@@ -825,7 +1011,8 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW;
-  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 8;
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 16 * (int64_t)V + 16 +
+                              4 * (int64_t)(TAB_T_MAX + TAB_P_MAX) + 16;
   return 0;
 }
 
@@ -864,6 +1051,9 @@ extern "C" int dfu3d_backproject_bin(
   int *q_cnt = (int *)(wpre + (size_t)V * NJ);
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int *q_rank = (int *)(q_bins + (size_t)V * cap_q);
+  FastCal *fastcal = (FastCal *)(((uintptr_t)(q_rank + (size_t)V * cap_q) + 15) & ~(uintptr_t)15);   // 64 B per view
+  const float4 *tab = (const float4 *)(fastcal + V);                  // edge tables of tier 1: (tJ + pJ) x 16 B
+  const FastGeom fg = make_fast_geom(*geom);
   int pix_bits = 1;
   while ((1ll << pix_bits) < HW64) pix_bits++;
   uint32_t *q_list = pix_bin + (size_t)V * HW;       // undecided pixels first, repair lists later
@@ -873,8 +1063,12 @@ extern "C" int dfu3d_backproject_bin(
 
   if (phases & DFU3D_BP_BIN) {
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
-    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, *geom,
-                       make_fast_geom(*geom), W, H, tiles_x, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
+    hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 255) / 256), dim3(256), 0, st, *geom, fg, (float4 *)tab);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
+                       fg, W, H, tiles_x, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
                        bitmap, BW);
     DFU3D_LAUNCH_CHECK();
   }
@@ -888,8 +1082,8 @@ extern "C" int dfu3d_backproject_bin(
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-    hipLaunchKernelGGL(k_bp_vox, dim3((NJ + VX_PIECES - 1) / VX_PIECES, V), dim3(VXB), 0, st, depth, cal, *geom,
-                       make_fast_geom(*geom), masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
+    hipLaunchKernelGGL(k_bp_vox, dim3((NJ + VX_PIECES - 1) / VX_PIECES, V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
+                       fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
                        cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status);
     DFU3D_LAUNCH_CHECK();
   }

@@ -34,25 +34,74 @@ __device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
 
 
 // ---------------------------------------------------------------- build
-__global__ __launch_bounds__(1024) void k_seg_count(const uint32_t *__restrict__ bits,
-                                                   const int *__restrict__ n_item,
-                                                   int cap_item, int max_inst,
-                                                   int *__restrict__ cnt) {
-  __shared__ int s_c[DFU3D_MAX_INST];
-  const int v = blockIdx.x;
-  if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
-  __syncthreads();
-  const int n = min(n_item[v], cap_item);
-  for (int t = threadIdx.x; t < n; t += 1024) {
-    uint32_t b = bits[(size_t)v * cap_item + t];
-    while (b) {
-      const int j = __ffs((int)b) - 1;
-      atomicAdd(&s_c[j], 1);
-      b &= b - 1u;
+// A view's items are cut into chunks of SEG_CH; every (view, chunk) is one workgroup in the counting and in
+// the writing pass, and inside a chunk every WAVE owns SEG_WI consecutive items.  Lane j of a wave keeps the
+// wave's running count of instance j in a register, so neither pass has a barrier or an LDS round trip inside
+// its item loop (the first formulation stepped a whole workgroup through 1024 items at a time with two barriers
+// per step and was bound by the latency of that chain, not by its 0.2 GB of traffic).
+constexpr int SEG_WAVES = 16, SEG_WI = 512, SEG_STEPS = SEG_WI / 64;
+constexpr int SEG_CH = SEG_WAVES * SEG_WI;          // 8192 items per workgroup
+static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x |= (uint32_t)__shfl_xor((int)x, m, 64);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+}
+
+// lane j: how many of the wave's items (bit words b[k], one per lane and step) carry instance j
+__device__ __forceinline__ int wave_instance_counts(const uint32_t (&b)[SEG_STEPS], uint32_t (&wany)[SEG_STEPS]) {
+  int mine = 0;
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < SEG_STEPS; k++) {
+    wany[k] = wave_or_u32(b[k]);
+    for (uint32_t w = wany[k]; w; w &= w - 1u) {     // uniform
+      const int j = __ffs((int)w) - 1;
+      const int c = __popcll(__ballot((b[k] >> j) & 1u));
+      if (lane == j) mine += c;
     }
   }
+  return mine;
+}
+
+__global__ __launch_bounds__(SEG_WAVES * 64) void k_seg_count(const uint32_t *__restrict__ bits,
+                                                             const int *__restrict__ n_item,
+                                                             int cap_item, int max_inst,
+                                                             int *__restrict__ cnt, int *__restrict__ chunk_cnt) {
+  __shared__ int s_c[DFU3D_MAX_INST];
+  const int v = blockIdx.y, ch = blockIdx.x;
+  const int lane = lane_id();
+  const int w0 = ch * SEG_CH + (int)(threadIdx.x >> 6) * SEG_WI;
+  // every load of the workgroup is requested before the first is looked at (one memory round trip, not a chain):
+  // the bit words are read up to the capacity and cut to the view's item count afterwards
+  const int n_raw = n_item[v];
+  const int t_cap = min(cap_item, (ch + 1) * SEG_CH);
+  uint32_t b[SEG_STEPS], wany[SEG_STEPS];
+#pragma unroll
+  for (int k = 0; k < SEG_STEPS; k++) {
+    const int t = w0 + k * 64 + lane;
+    b[k] = (t < t_cap) ? bits[(size_t)v * cap_item + t] : 0u;
+  }
+  const int n = min(n_raw, t_cap);
+  int *cc = chunk_cnt + ((size_t)v * gridDim.x + ch) * DFU3D_MAX_INST;
+  if (ch * SEG_CH >= n) {                          // (uniform) nothing in this chunk
+    if (threadIdx.x < DFU3D_MAX_INST) cc[threadIdx.x] = 0;
+    return;
+  }
+  if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x < max_inst) cnt[v * max_inst + threadIdx.x] = s_c[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < SEG_STEPS; k++)
+    if (w0 + k * 64 + lane >= n) b[k] = 0u;
+  const int mine = wave_instance_counts(b, wany);
+  if (lane < DFU3D_MAX_INST && mine) atomicAdd(&s_c[lane], mine);
+  __syncthreads();
+  if (threadIdx.x < DFU3D_MAX_INST) {
+    const int c = s_c[threadIdx.x];
+    cc[threadIdx.x] = c;
+    if (c && (int)threadIdx.x < max_inst) atomicAdd(&cnt[v * max_inst + threadIdx.x], c);
+  }
 }
 
 // joint view of the 2S lists for the one-pass radius filter: s < S the LiDAR lists, S + s the pseudo lists
@@ -110,65 +159,88 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt
   if (threadIdx.x == 0) *cursor = (s_end >= 0) ? s_end : (running < pool_cap ? running : pool_cap);
 }
 
-// One workgroup per VIEW writes the ordered lists of all its instances in a single sweep over the view's
-// items (a workgroup per instance read the 100k+ items of the view once per instance: L2-bound).  Per step of
-// 1024 items: per-instance ballots inside each wave, wave totals through LDS, two barriers.
-constexpr int SWT = 1024;
+// One workgroup per (view, chunk) writes its part of the ordered lists of all the view's instances: a list starts
+// where the earlier chunks of the view end (their counts), a wave's part of it where the earlier waves of the chunk
+// end (one barrier), and inside the wave ballots give the order.  The bit words stay in registers between the
+// counting and the writing sweep; the coordinates of all SEG_STEPS steps are requested before the first is used.
+constexpr int SWT = SEG_WAVES * 64;
 __global__ __launch_bounds__(SWT) void k_seg_write(
     const uint32_t *__restrict__ bits, const double *__restrict__ ix,
     const double *__restrict__ iy, const double *__restrict__ iz,
     const int *__restrict__ n_item, int cap_item, int max_inst,
-    const long long *__restrict__ base, const int *__restrict__ cnt,
+    const long long *__restrict__ base, const int *__restrict__ cnt, const int *__restrict__ chunk_cnt,
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off) {
-  __shared__ int s_wc[SWT / 64][DFU3D_MAX_INST];      // per wave: items of instance j in this step
-  __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items written before this step
-  const int v = blockIdx.x;
-  const int n = min(n_item[v], cap_item);
+  __shared__ int s_wc[SEG_WAVES][DFU3D_MAX_INST];     // per wave: items of instance j in this chunk
+  __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items of the earlier chunks
+  const int v = blockIdx.y, ch = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  uint32_t live = 0u;                                  // instances of this view with a non-empty list
-  for (int j = 0; j < max_inst; j++)
-    if (cnt[v * max_inst + j] > 0) live |= 1u << j;
-  if (live == 0u || n == 0) return;
+  const int w0 = ch * SEG_CH + wave * SEG_WI;
+  // every first-level load is requested before any is looked at: one memory round trip instead of a chain
+  // (item count -> list sizes -> bases -> earlier chunks -> bit words); the bit words are read up to the
+  // capacity and cut to the view's item count afterwards
+  const int n_raw = n_item[v];
+  const bool lj = lane < max_inst;                     // lane j < max_inst: the facts of instance j
+  const int cj = lj ? cnt[v * max_inst + lane] : 0;    // (0 also for the lists that did not fit the pool)
+  long long off = lj ? base[v * max_inst + lane] : 0;
+  const double rj = (lj && pq) ? rad[v * max_inst + lane] : 0.0;
+  const int *cc = chunk_cnt + (size_t)v * gridDim.x * DFU3D_MAX_INST;
+  const int jj = threadIdx.x & (DFU3D_MAX_INST - 1), c_first = threadIdx.x / DFU3D_MAX_INST;
+  int q_first = 0;                                     // chunks 0..31 in one go, the rest (if any) in the loop below
+  if (c_first < ch) q_first = cc[(size_t)c_first * DFU3D_MAX_INST + jj];
+  const int t_cap = min(cap_item, (ch + 1) * SEG_CH);
+  uint32_t b[SEG_STEPS], wany[SEG_STEPS];
+#pragma unroll
+  for (int k = 0; k < SEG_STEPS; k++) {
+    const int t = w0 + k * 64 + lane;
+    b[k] = (t < t_cap) ? bits[(size_t)v * cap_item + t] : 0u;
+  }
+  const int n = min(n_raw, t_cap);
+  if (ch * SEG_CH >= n) return;
+  const uint32_t live = (uint32_t)__ballot(cj > 0);   // instances of this view with a non-empty list
+  if (live == 0u) return;
+  const uint32_t sw = (lj && pq) ? shadow_word(seg_off + v * max_inst + lane, rj) : 0u;
   if (threadIdx.x < DFU3D_MAX_INST) s_run[threadIdx.x] = 0;
-  int mytot = 0;                                       // thread j < max_inst: instance j's total of the previous step
-  for (int t0 = 0; t0 < n; t0 += SWT) {
-    const int t = t0 + threadIdx.x;
-    const size_t o = (size_t)v * cap_item + t;
-    const uint32_t b = (t < n) ? (bits[o] & live) : 0u;
-    __syncthreads();                                   // A: the previous step's s_wc / s_run have been read
-    if ((int)threadIdx.x < max_inst) s_run[threadIdx.x] += mytot;
-    for (uint32_t w = live; w; w &= w - 1u) {          // uniform: every live instance, every wave
-      const int j = __ffs((int)w) - 1;
-      const unsigned long long m = __ballot((b >> j) & 1u);
-      if (lane == 0) s_wc[wave][j] = __popcll(m);
-    }
-    __syncthreads();                                   // B: counts of all waves, running totals up to date
-    if ((int)threadIdx.x < max_inst) {
-      int tsum = 0;
+  __syncthreads();
+  if (q_first) atomicAdd(&s_run[jj], q_first);
+  for (int c = c_first + SWT / DFU3D_MAX_INST; c < ch; c += SWT / DFU3D_MAX_INST) {
+    const int q = cc[(size_t)c * DFU3D_MAX_INST + jj];
+    if (q) atomicAdd(&s_run[jj], q);
+  }
 #pragma unroll
-      for (int w = 0; w < SWT / 64; w++) tsum += s_wc[w][threadIdx.x];
-      mytot = ((live >> threadIdx.x) & 1u) ? tsum : 0;
-    }
-    uint32_t wany = b;                                 // instances present in this wave (uniform after the OR)
+  for (int k = 0; k < SEG_STEPS; k++) b[k] = (w0 + k * 64 + lane < n) ? (b[k] & live) : 0u;
+  double x[SEG_STEPS], y[SEG_STEPS], z[SEG_STEPS];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wany |= (uint32_t)__shfl_xor((int)wany, m, 64);
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (b) { x = ix[o]; y = iy[o]; z = iz[o]; }
-    for (uint32_t w = wany; w; w &= w - 1u) {          // uniform per wave
+  for (int k = 0; k < SEG_STEPS; k++) {
+    const size_t o = (size_t)v * cap_item + w0 + k * 64 + lane;
+    x[k] = 0.0; y[k] = 0.0; z[k] = 0.0;
+    if (b[k]) { x[k] = ix[o]; y[k] = iy[o]; z[k] = iz[o]; }
+  }
+  const int mine = wave_instance_counts(b, wany);
+  if (lane < DFU3D_MAX_INST) s_wc[wave][lane] = mine;
+  __syncthreads();
+  if (lane < DFU3D_MAX_INST) {
+    int before = s_run[lane];
+    for (int ww = 0; ww < wave; ww++) before += s_wc[ww][lane];
+    off += before;
+  }
+#pragma unroll
+  for (int k = 0; k < SEG_STEPS; k++) {
+    for (uint32_t w = wany[k]; w; w &= w - 1u) {       // uniform per wave
       const int j = __ffs((int)w) - 1;
-      const unsigned long long m = __ballot((b >> j) & 1u);
-      int before = s_run[j];
-      for (int ww = 0; ww < wave; ww++) before += s_wc[ww][j];
-      if ((b >> j) & 1u) {
-        const long long d = base[v * max_inst + j] + before + __popcll(m & ((1ull << lane) - 1ull));
-        px[d] = x;
-        py[d] = y;
-        pz[d] = z;
+      const bool has = (b[k] >> j) & 1u;
+      const unsigned long long m = __ballot(has);
+      const long long start = __shfl(off, j, 64);
+      const uint32_t swj = (uint32_t)__shfl((int)sw, j, 64);
+      if (has) {
+        const long long d = start + __popcll(m & ((1ull << lane) - 1ull));
+        px[d] = x[k];
+        py[d] = y[k];
+        pz[d] = z[k];
         if (pq)                                        // float32 shadow for the radius filter
-          pq[d] = make_float4((float)x, (float)y, (float)z,
-                              __uint_as_float(shadow_word(seg_off + v * max_inst + j, rad[v * max_inst + j])));
+          pq[d] = make_float4((float)x[k], (float)y[k], (float)z[k], __uint_as_float(swj));
       }
+      if (lane == j) off += __popcll(m);
     }
   }
 }
@@ -537,15 +609,37 @@ __global__ __launch_bounds__(256) void k_seg_compact_short(
 // coordinates give a lower bound of the distance that discards almost every
 // non-neighbour without touching memory; the rest is decided by the
 // reference's predicate on the fp64 coordinates (d2 < T <=> sqrt(d2) < C).
-// A workgroup of 1024 threads walks BQ_TPB consecutive 1024-query tiles and
-// rebuilds the table only when the instance changes (BQ_TPB = 1 measured best:
+// A workgroup takes one query tile of one instance and builds that instance's table
+// (one tile per workgroup measured best:
 // more, smaller workgroups balance better than amortising the build).  Instances with more
 // LiDAR points than the table holds, or beyond the quantised range, use the
 // brute-force tile loop.
-constexpr int BT = 1024;                       // queries per tile = threads per workgroup
-constexpr int BH_HEADS = 8192;                 // 32 KB of LDS
-constexpr int BH_MAX = 4096;                   // nodes: 32 KB of LDS; 12-bit index
-constexpr int BQ_TPB = 1;
+// Two builds of the kernel share the work by the size of the instance's LiDAR list: almost every instance has a
+// few hundred LiDAR points, so its table fits 16 KB of LDS and 256-thread workgroups -- eight of them per compute
+// unit instead of two, which is what hides the dependent loads at the start of a workgroup (segment search,
+// segment facts, LiDAR points); the big build (64 KB, 1024 threads) takes the rest and the brute-force case.
+constexpr int BT_BIG = 1024, BH_HEADS_BIG = 8192, BH_MAX_BIG = 4096;      // 32 KB + 32 KB of LDS; 12-bit node index
+constexpr int BT_SMALL = 256, BH_HEADS_SMALL = 2048, BH_MAX_SMALL = 1024; // 8 KB + 8 KB of LDS
+
+// query tiles of the segments whose LiDAR list has lo < cnt_a <= hi entries
+__global__ __launch_bounds__(1024) void k_tile_scan_class(int S, const int *__restrict__ cnt, const int *__restrict__ cnt_a,
+                                                          int lo, int hi, int *__restrict__ tile_off, int qt) {
+  __shared__ int s_w[16];
+  int running = 0;
+  for (int b0 = 0; b0 < S; b0 += 1024) {
+    const int s = b0 + threadIdx.x;
+    int nt = 0;
+    if (s < S) {
+      const int na = cnt_a[s];
+      if (na > lo && na <= hi) nt = (cnt[s] + qt - 1) / qt;
+    }
+    int tot;
+    const int ex = block_excl_scan<16>(nt, s_w, tot);
+    if (s < S) tile_off[s] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) tile_off[S] = running;
+}
 
 __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
   uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
@@ -553,6 +647,7 @@ __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t i
   return h;
 }
 
+template <int BT, int BH_MAX, int BH_HEADS>
 __global__ __launch_bounds__(BT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ base_a,
@@ -563,9 +658,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
   __shared__ uint32_t s_head[BH_HEADS];
   __shared__ int s_pending;
   const int ntile = tile_off[S];
-  int t = blockIdx.x * BQ_TPB;
+  int t = blockIdx.x;
   if (t >= ntile) return;
-  const int t_end = min(t + BQ_TPB, ntile);
+  const int t_end = t + 1;
   int s = find_segment(tile_off, S, t);
   const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
   const double Cq = C * (1.0 + 1e-6);
@@ -663,9 +758,10 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     }
     // brute force over LDS tiles (more LiDAR points than the table holds, or a huge extent)
     hashed_s = -1;                               // the tiles below overwrite the table
-    double *sx = (double *)s_node, *sy = sx + PT, *sz = sy + PT;    // 24 KB of the nodes' LDS
-    for (int j0 = 0; j0 < na; j0 += PT) {
-      const int m = min(PT, na - j0);
+    constexpr int PTB = BH_MAX / 3;              // points per tile: x | y | z in the nodes' LDS
+    double *sx = (double *)s_node, *sy = sx + PTB, *sz = sy + PTB;
+    for (int j0 = 0; j0 < na; j0 += PTB) {
+      const int m = min(PTB, na - j0);
       __syncthreads();
       if (threadIdx.x == 0) s_pending = 0;
       for (int i = threadIdx.x; i < m; i += BT) {
@@ -843,6 +939,11 @@ inline int tile_grid(int64_t pool_cap, int S) {
 
 }  // namespace
 
+extern "C" int64_t dfu3d_segments_scratch_words(int32_t V, int32_t a_cap, int32_t b_cap) {
+  if (V <= 0 || a_cap <= 0 || b_cap <= 0) return DFU3D_EINVAL;
+  return (int64_t)V * DFU3D_MAX_INST * ((a_cap + SEG_CH - 1) / SEG_CH + (b_cap + SEG_CH - 1) / SEG_CH);
+}
+
 extern "C" int dfu3d_segments_build(
     const uint32_t *a_bits, const double *a_x, const double *a_y, const double *a_z,
     const int32_t *a_n, int32_t a_cap, const uint32_t *b_bits, const double *b_x,
@@ -850,10 +951,10 @@ extern "C" int dfu3d_segments_build(
     int32_t max_inst, int64_t pool_cap, int64_t *pool_cursor, double *px, double *py,
     double *pz, int64_t *base_a, int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
     uint32_t *status, const double *rad_a, const double *rad_b, void *shadow, int64_t *base_ab,
-    int32_t *cnt_ab, double *rad_ab, void *stream) {
+    int32_t *cnt_ab, double *rad_ab, int32_t *chunk_cnt, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!a_bits || !a_x || !a_y || !a_z || !a_n || !b_bits || !b_x || !b_y || !b_z || !b_n ||
-      !pool_cursor || !px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !status)
+      !pool_cursor || !px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !status || !chunk_cnt)
     return DFU3D_EINVAL;
   if (V <= 0 || max_inst <= 0 || a_cap <= 0 || b_cap <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
   if (max_inst > DFU3D_MAX_INST) return DFU3D_ERANGE;
@@ -863,20 +964,24 @@ extern "C" int dfu3d_segments_build(
   if (shadow && 2 * (int64_t)S >= (int64_t)RF_NOSEG) return DFU3D_ERANGE;   // 16-bit segment ids in the shadow
   if (shadow && ((uintptr_t)shadow & 15u)) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a);
+  const int nca = (a_cap + SEG_CH - 1) / SEG_CH, ncb = (b_cap + SEG_CH - 1) / SEG_CH;
+  int32_t *cc_a = chunk_cnt, *cc_b = chunk_cnt + (size_t)V * nca * DFU3D_MAX_INST;
+  if (hipMemsetAsync(cnt_a, 0, sizeof(int32_t) * S, st) != hipSuccess) return DFU3D_ELAUNCH;
+  if (hipMemsetAsync(cnt_b, 0, sizeof(int32_t) * S, st) != hipSuccess) return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_seg_count, dim3(nca, V), dim3(SEG_WAVES * 64), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a, cc_a);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_count, dim3(V), dim3(1024), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b);
+  hipLaunchKernelGGL(k_seg_count, dim3(ncb, V), dim3(SEG_WAVES * 64), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b, cc_b);
   DFU3D_LAUNCH_CHECK();
   const JointSegs J = {(long long *)base_ab, cnt_ab, rad_ab, rad_a, rad_b};
   hipLaunchKernelGGL(k_seg_alloc, dim3(1), dim3(1024), 0, st, S, cnt_a, cnt_b,
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
                      (long long *)pool_cursor, status, J);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
-                     max_inst, (const long long *)base_a, cnt_a, px, py, pz, (float4 *)shadow, rad_a, 0);
+  hipLaunchKernelGGL(k_seg_write, dim3(nca, V), dim3(SWT), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
+                     max_inst, (const long long *)base_a, cnt_a, cc_a, px, py, pz, (float4 *)shadow, rad_a, 0);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(V), dim3(SWT), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
-                     max_inst, (const long long *)base_b, cnt_b, px, py, pz, (float4 *)shadow, rad_b, S);
+  hipLaunchKernelGGL(k_seg_write, dim3(ncb, V), dim3(SWT), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
+                     max_inst, (const long long *)base_b, cnt_b, cc_b, px, py, pz, (float4 *)shadow, rad_b, S);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
@@ -975,12 +1080,22 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   double T = C * C;
   while (__builtin_sqrt(T) >= C) T = __builtin_nextafter(T, 0.0);
   while (__builtin_sqrt(T) < C) T = __builtin_nextafter(T, __builtin_inf());
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, cnt_b, tile_off, BT);
+  // small build: instances with at most BH_MAX_SMALL LiDAR points (and those with none: the fuse is skipped there);
+  // big build: the others.  tile_off: two lists of S+1 entries.
+  int32_t *tile_small = tile_off, *tile_big = tile_off + S + 1;
+  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, -1, BH_MAX_SMALL, tile_small, BT_SMALL);
   DFU3D_LAUNCH_CHECK();
-  const int ball_tiles = (int)((pool_cap + BT - 1) / BT + S);
-  hipLaunchKernelGGL(k_ball_flags, dim3((ball_tiles + BQ_TPB - 1) / BQ_TPB), dim3(BT), 0, st, px, py, pz,
+  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, BH_MAX_SMALL, 0x7FFFFFFF, tile_big, BT_BIG);
+  DFU3D_LAUNCH_CHECK();
+  const int g_small = (int)((pool_cap + BT_SMALL - 1) / BT_SMALL + S);
+  hipLaunchKernelGGL((k_ball_flags<BT_SMALL, BH_MAX_SMALL, BH_HEADS_SMALL>), dim3(g_small), dim3(BT_SMALL), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
-                     tile_off, flags, masked);
+                     tile_small, flags, masked);
+  DFU3D_LAUNCH_CHECK();
+  const int g_big = (int)((pool_cap + BT_BIG - 1) / BT_BIG + S);
+  hipLaunchKernelGGL((k_ball_flags<BT_BIG, BH_MAX_BIG, BH_HEADS_BIG>), dim3(g_big), dim3(BT_BIG), 0, st, px, py, pz,
+                     (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
+                     tile_big, flags, masked);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz, (long long *)base_b,
                      cnt_b, flags, (const long long *)base_a, cnt_a);

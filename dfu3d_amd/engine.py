@@ -149,12 +149,13 @@ class PseudoBoxEngine:
             L.base_a = torch.empty(S, dtype=torch.int64, device=d)
             L.base_b = torch.empty(S, dtype=torch.int64, device=d)
             L.cnt_a, L.cnt_b, L.cnt_all = i32(S), i32(S), i32(S)
-            L.tile_off = i32(2 * S + 1)
+            L.tile_off = i32(2 * S + 2)
             L.base_ab = torch.empty(2 * S, dtype=torch.int64, device=d)
             L.cnt_ab = i32(2 * S)
             L.rad_ab = f64(2 * S)
             L.queue = i32(2 + pc)
             L.shadow = torch.empty(st.shadow_floats(pc), dtype=torch.float32, device=d)
+            L.chunk_cnt = i32(int(st._lib.lib().dfu3d_segments_scratch_words(V, cap_n, cv)))
             L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
             L.stat_enable = torch.ones(S, dtype=torch.int32, device=d)
             L.rf_points = torch.zeros(1, dtype=torch.int64, device=d)   # timing mode only
@@ -332,7 +333,8 @@ class PseudoBoxEngine:
                           self.pool_cap, self.pool_cursor, self.px, self.py, self.pz,
                           self.base_a, self.cnt_a, self.base_b, self.cnt_b, status,
                           rad_a=rl.contiguous(), rad_b=rp.contiguous(), shadow=self.shadow if fused else None,
-                          base_ab=self.base_ab if fused else None, cnt_ab=self.cnt_ab, rad_ab=self.rad_ab)
+                          base_ab=self.base_ab if fused else None, cnt_ab=self.cnt_ab, rad_ab=self.rad_ab,
+                          chunk_cnt=self.chunk_cnt)
         if self.timing:
             self.rf_points += self.cnt_a.sum() + self.cnt_b.sum()
         self._count("pool_points", self.pool_cursor)
@@ -487,8 +489,14 @@ class PseudoBoxEngine:
             b._gather_maps = maps
         return rows_for_gather(rows, *maps)
 
-    def collect(self):
-        rows, n_rows, status = self._last
+    def launch(self, b: ViewBatch):
+        """Enqueue a pass and return a handle for collect(): the host can enqueue the NEXT pass before it waits for
+        this one (the row buffers are per pass; the workspace is reused in stream order)."""
+        self.run(b, sync=False)
+        return self._last
+
+    def collect(self, handle=None):
+        rows, n_rows, status = handle if handle is not None else self._last
         both = torch.stack((n_rows, status)).cpu().numpy()        # the one host sync
         counts = both[0]
         stw = int(np.bitwise_or.reduce(both[1].astype(np.int64)))

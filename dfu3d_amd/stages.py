@@ -230,9 +230,12 @@ def shadow_floats(pool_cap):
 
 def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n, b_cap, V,
                    max_inst, pool_cap, pool_cursor, px, py, pz, base_a, cnt_a, base_b, cnt_b,
-                   status, rad_a=None, rad_b=None, shadow=None, base_ab=None, cnt_ab=None, rad_ab=None):
+                   status, rad_a=None, rad_b=None, shadow=None, base_ab=None, cnt_ab=None, rad_ab=None, chunk_cnt=None):
     """rad_a / rad_b + shadow (+ the joint 2S segment table): everything the one-pass radius filter needs."""
     S = V * max_inst
+    nw = int(_lib.lib().dfu3d_segments_scratch_words(V, a_cap, b_cap))
+    if chunk_cnt is None:
+        chunk_cnt = torch.empty(nw, dtype=torch.int32, device=px.device)
     opt = lambda t, name, dt, n: None if t is None else _chk(t, name, dt, numel=n)
     if shadow is not None and shadow.data_ptr() % 16:
         raise Dfu3dError("shadow: must be 16-byte aligned")
@@ -253,7 +256,8 @@ def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n
         _chk(status, "status", torch.int32, min_numel=1),
         opt(rad_a, "rad_a", torch.float64, S), opt(rad_b, "rad_b", torch.float64, S),
         opt(shadow, "shadow", torch.float32, shadow_floats(pool_cap)), opt(base_ab, "base_ab", torch.int64, 2 * S),
-        opt(cnt_ab, "cnt_ab", torch.int32, 2 * S), opt(rad_ab, "rad_ab", torch.float64, 2 * S), _stream())
+        opt(cnt_ab, "cnt_ab", torch.int32, 2 * S), opt(rad_ab, "rad_ab", torch.float64, 2 * S),
+        _chk(chunk_cnt, "chunk_cnt", torch.int32, min_numel=nw), _stream())
     _lib.check(rc, "dfu3d_segments_build")
 
 
@@ -300,7 +304,7 @@ def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, til
         _chk(pz, "pz", torch.float64, numel=pool_cap),
         _chk(base_a, "base_a", torch.int64, numel=S), _chk(cnt_a, "cnt_a", torch.int32, numel=S),
         _chk(base_b, "base_b", torch.int64, numel=S), _chk(cnt_b, "cnt_b", torch.int32, numel=S),
-        float(C), S, pool_cap, _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
+        float(C), S, pool_cap, _chk(tile_off, "tile_off", torch.int32, min_numel=2 * S + 2),
         _chk(flags, "flags", torch.uint8, numel=pool_cap), _stream())
     _lib.check(rc, "dfu3d_ballquery_fuse")
 
@@ -405,14 +409,35 @@ def nms_bev(boxes, thresh, normal=False):
     return keep, int(num.item())
 
 
-def selftest_angles(n, seed=1, range_xy=100.0, z_lo=-6.0, z_hi=1.0, device="cuda:0"):
-    """-> (max error/bound for theta, for phi) of the fp32 angle estimates on this device."""
-    out = torch.zeros(2, dtype=torch.float64, device=device)
-    rc = _lib.lib().dfu3d_selftest_angles(int(n), int(seed), float(range_xy), float(z_lo), float(z_hi),
-                                          _chk(out, "out", torch.float64, numel=2), _stream())
-    _lib.check(rc, "dfu3d_selftest_angles")
-    t, p = out.cpu().tolist()
-    return t, p
+SELFTEST_SCRATCH_BYTES = 64 + 16 * (65536 + 16384) + 64
+
+
+def selftest_classify(calib_record, H, W, geom, key_axis, n, seed=1, d_lo=0.5, d_hi=120.0, device="cuda:0"):
+    """Float32 tier of the bin classification against the fp64 one on n random pixels under one calibration record
+    and the BinGeom `geom` -> dict(tried, undecided, wrong, kept); `wrong` must be 0 (dfu3d_selftest_classify)."""
+    cal = torch.as_tensor(np.asarray(calib_record, np.float32).reshape(CALIB_FLOATS)).to(device).contiguous()
+    scratch = torch.zeros(SELFTEST_SCRATCH_BYTES // 4, dtype=torch.float32, device=device)
+    out = torch.zeros(4, dtype=torch.int64, device=device)
+    rc = _lib.lib().dfu3d_selftest_classify(_chk(cal, "calib", torch.float32, numel=CALIB_FLOATS), int(H), int(W),
+                                            ctypes.byref(geom), int(key_axis), int(n), int(seed), float(d_lo),
+                                            float(d_hi), _chk(scratch, "scratch", torch.float32),
+                                            _chk(out, "out", torch.int64, numel=4), _stream())
+    _lib.check(rc, "dfu3d_selftest_classify")
+    t, u, w, k = out.cpu().tolist()
+    return {"tried": t, "undecided": u, "wrong": w, "kept": k}
+
+
+def selftest_backproject(calib_record, H, W, n, seed=1, d_lo=0.5, d_hi=120.0, device="cuda:0"):
+    """-> max |float32 back-projection - fp64| / bound over n random pixels under one 48-float calibration record."""
+    cal = torch.as_tensor(np.asarray(calib_record, np.float32).reshape(CALIB_FLOATS)).to(device).contiguous()
+    scratch = torch.zeros(16, dtype=torch.float32, device=device)
+    out = torch.zeros(1, dtype=torch.float64, device=device)
+    rc = _lib.lib().dfu3d_selftest_backproject(_chk(cal, "calib", torch.float32, numel=CALIB_FLOATS), int(H), int(W),
+                                               int(n), int(seed), float(d_lo), float(d_hi),
+                                               _chk(scratch, "scratch", torch.float32, numel=16),
+                                               _chk(out, "out", torch.float64, numel=1), _stream())
+    _lib.check(rc, "dfu3d_selftest_backproject")
+    return float(out.item())
 
 
 def range_cluster(px, py, seg_base, seg_cnt, S, R0, Rd, label, pool_cap, sx=None, sy=None, si=None):

@@ -203,7 +203,9 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
  * Optional (NULL to skip), for the one-pass radius filter below:
  *   rad_a / rad_b fp64 (S): the filter radii of the LiDAR / pseudo lists;
  *   shadow: DFU3D_SHADOW_BYTES(pool_cap), the float32 shadow the filter streams (x, y, z, list | radius);
- *   base_ab / cnt_ab / rad_ab (2S each): the joint segment table, s < S = LiDAR lists, S+s = pseudo lists. */
+ *   base_ab / cnt_ab / rad_ab (2S each): the joint segment table, s < S = LiDAR lists, S+s = pseudo lists.
+ * Scratch: chunk_cnt int32 (dfu3d_segments_scratch_words): member counts per (view, 8192-item chunk, instance). */
+int64_t dfu3d_segments_scratch_words(int32_t V, int32_t a_cap, int32_t b_cap);
 int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
                          const double *a_y, const double *a_z,
                          const int32_t *a_n, int32_t a_cap,
@@ -216,7 +218,7 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
                          int64_t *base_b, int32_t *cnt_b, uint32_t *status,
                          const double *rad_a, const double *rad_b, void *shadow,
                          int64_t *base_ab, int32_t *cnt_ab, double *rad_ab,
-                         void *stream);
+                         int32_t *chunk_cnt, void *stream);
 
 /* ---- a10: Open3D remove_radius_outlier (my_loader.py:581-599) --------------
  * In-place, order-preserving: keeps point i of segment s iff
@@ -258,7 +260,8 @@ int dfu3d_stat_filter(double *px, double *py, double *pz,
  * Keeps query point i of segment B iff min_j |q_i - a_j| < C over segment A
  * (strict; skipped -- all kept -- when either set is empty), then moves the
  * survivors to directly follow segment A: on return the instance's points are
- * [base_a[s], base_a[s] + cnt_a[s] + cnt_b[s]) and base_b[s] is updated. */
+ * [base_a[s], base_a[s] + cnt_a[s] + cnt_b[s]) and base_b[s] is updated.
+ * Scratch: tile_off int32 (2S+2: the query-tile lists of the two builds of the kernel), flags uint8 (pool_cap). */
 int dfu3d_ballquery_fuse(double *px, double *py, double *pz,
                          const int64_t *base_a, const int32_t *cnt_a,
                          int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
@@ -325,14 +328,23 @@ int dfu3d_nms_normal_bev(const float *boxes, int32_t n, float thresh, uint64_t *
                          int64_t *keep, int32_t *num_keep, void *stream);
 
 /* ---- self test of the two-tier bin classification ---------------------------
- * dfu3d_backproject_bin decides a pixel's spherical bin from fp32 angle
- * estimates when they are farther from every bin edge than a bound on their
- * error, and in fp64 otherwise.  This entry point measures, over n pseudo-random
- * points (|x|,|y| <= range_xy, z in [z_lo, z_hi]; every third one 50x closer),
- * out2[0] = max |theta_fp32 - theta_fp64| / bound_theta, out2[1] likewise for phi
- * (device doubles).  Values below 1 mean the bounds hold on this device. */
-int dfu3d_selftest_angles(int64_t n, uint64_t seed, double range_xy, double z_lo,
-                          double z_hi, double *out2, void *stream);
+ * dfu3d_backproject_bin decides a pixel's spherical bin in float32 when every float32 estimate is farther from
+ * every boundary involved than a bound on its error, and in fp64 otherwise.  This entry point runs both
+ * classifications over n pseudo-random pixels of an H x W image with depths in [d_lo, d_hi) (every fourth one
+ * 50x closer) under the ONE calibration record `calib` and the bin geometry `geom` (host pointer, after
+ * dfu3d_bin_table_geometry): out4 (device) = { pixels tried, undecided in float32, DISAGREEMENTS among the decided
+ * (bin or voxel key), kept by float32 }.  out4[2] must be 0.  scratch: DFU3D_SELFTEST_SCRATCH_BYTES, 16-byte
+ * aligned. */
+#define DFU3D_SELFTEST_SCRATCH_BYTES (64 + 16 * (65536 + 16384) + 64)
+int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
+                            int32_t key_axis, int64_t n, uint64_t seed, double d_lo, double d_hi,
+                            void *scratch, uint64_t *out4, void *stream);
+/* The same classification starts from a float32 back-projection of the pixel (nine FMAs) with a bound on its
+ * error.  This entry point measures, over n pseudo-random pixels of an H x W image with depths in [d_lo, d_hi)
+ * (every fourth one 50x closer) under the ONE calibration record `calib`, out1[0] = max over pixels and
+ * coordinates of |float32 estimate - fp64 back-projection| / bound.  scratch64: 64 bytes of device scratch. */
+int dfu3d_selftest_backproject(const float *calib, int32_t H, int32_t W, int64_t n, uint64_t seed,
+                               double d_lo, double d_hi, void *scratch64, double *out1, void *stream);
 
 /* ---- a13: _adoptive_range_segmentation (rectangle_fitting.py:161-191) ------
  * label[seg_base[s] + i] = smallest in-segment index of the cluster that

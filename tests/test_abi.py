@@ -101,7 +101,7 @@ def test_sizes_struct_layout_and_workspace_bytes(tmp_path):
     z.V, z.H, z.W, z.max_inst, z.cap_n, z.cap_vox, z.cap_rows, z.max_points_per_voxel = 96, 900, 1600, 8, 34720, 1 << 18, 6144, 100
     z.pool_cap, z.table_entries, z.dense, z.stat_filter = 96 << 17, 824 * 1573, 1, 0
     got = [L.dfu3d_workspace_bytes(s, ctypes.byref(z)) for s in range(11)]
-    assert got[0] == 0 and got[4] == 0 and all(g > 0 for i, g in enumerate(got) if i not in (0, 4))
+    assert got[0] == 0 and all(g > 0 for i, g in enumerate(got) if i != 0)
     assert all(g % 256 == 0 for g in got)
     assert got[5] >= 16 * z.pool_cap + z.pool_cap + 4 * z.pool_cap            # shadow (+ boxes) + flags + queue
     assert L.dfu3d_workspace_bytes(11, ctypes.byref(z)) == -1 and L.dfu3d_workspace_bytes(5, None) == -1

@@ -64,12 +64,43 @@ def _clustered_points(rng, n, spread=1.0, outliers=0.05):
     return p
 
 
-def test_fp32_angle_bounds_hold_on_this_device(st):
-    """The two-tier bin classification trusts fp32 acosf/atanf only outside an error bound; measure the real
-    error against fp64 on 2e8 points (LiDAR-like ranges and close-in points) -- it must stay under half the bound."""
-    for seed, rxy, zlo, zhi in ((1, 100.0, -6.0, 1.0), (2, 5.0, -3.0, 1.0), (3, 60.0, -0.2, 0.2)):
-        t, p = st.selftest_angles(70_000_000, seed, rxy, zlo, zhi)
-        assert 0.0 < t < 0.5 and 0.0 < p < 0.5, (seed, t, p)
+def test_float32_tier_never_disagrees_with_fp64(st):
+    """Tier 1 of the bin classification (float32 back-projection, edge tables in cos / tan space) takes a decision only
+    outside its error bounds.  Run it against the fp64 classification on 4e7 random pixels per case (six synthetic
+    cameras, product geometry and two odd ones, both key axes, depths from centimetres to 95 m): not one decided pixel
+    may differ in bin or voxel key, and tier 1 must decide nearly all of them."""
+    from dfu3d_amd import synth
+    rng = np.random.default_rng(0)
+    geoms = [st.make_geom(),                                                       # the product's la_sampling grid
+             st.make_geom(theta_min=0.3, z_max=3.0, vsize=(200.0, 0.0137, 0.0071), vgrid=(1, 800, 1500)),
+             st.make_geom(theta_min=1.2, z_max=0.5, vsize=(200.0, 0.0005, 0.0005), vgrid=(1, 20000, 20000))]
+    total = 0
+    for gi, (geom, _) in enumerate(geoms):
+        for H, W in ((900, 1600), (180, 320)):
+            for yaw in synth.CAM_YAWS_DEG[:: (1 if gi == 0 else 3)]:
+                cal = synth.make_calibration(yaw, H, W, rng)
+                for key_axis, (d_lo, d_hi) in ((1, (0.01, 3.0)), (2, (0.5, 95.0))):
+                    r = st.selftest_classify(cal.record(), H, W, geom, key_axis, 4_000_000, seed=int(yaw) + gi,
+                                             d_lo=d_lo, d_hi=d_hi)
+                    assert r["tried"] == 4_000_000 and r["wrong"] == 0, (gi, H, W, yaw, key_axis, r)
+                    if gi == 0 and d_hi > 90:
+                        assert r["undecided"] < 0.03 * r["tried"] and r["kept"] > 0, (H, W, yaw, r)
+                    total += r["kept"]
+    assert total > 10_000_000
+
+
+def test_fp32_backprojection_bound_holds_on_this_device(st):
+    """Tier 1 of the bin classification starts from a float32 back-projection (nine FMAs per pixel) and trusts it only
+    outside a bound on its error: measure |float32 - fp64| / bound over 3e7 pixels per camera (six synthetic cameras,
+    full 900x1600 and a small image, depths from centimetres to 120 m) -- it must stay under one half."""
+    from dfu3d_amd import synth
+    rng = np.random.default_rng(0)
+    for H, W in ((900, 1600), (180, 320)):
+        for yaw in synth.CAM_YAWS_DEG:
+            cal = synth.make_calibration(yaw, H, W, rng)
+            for d_lo, d_hi in ((0.01, 3.0), (0.5, 120.0)):
+                q = st.selftest_backproject(cal.record(), H, W, 5_000_000, seed=int(yaw) + 7, d_lo=d_lo, d_hi=d_hi)
+                assert 0.0 < q < 0.5, (H, W, yaw, d_lo, q)
 
 
 # ------------------------------------------------------------------ a10
@@ -175,7 +206,7 @@ def test_ballquery_fuse_matches_oracle(st):
     cnt_b = _t(np.array([len(b) for b in segsB], np.int32))
     tb = _t(np.array(base_b, np.int64))
     st.ballquery_fuse(px, py, pz, _t(np.array(base_a, np.int64)), cnt_a, tb, cnt_b, 0.1, S, cap,
-                      torch.zeros(S + 1, dtype=torch.int32, device=DEV),
+                      torch.zeros(2 * S + 2, dtype=torch.int32, device=DEV),
                       torch.zeros(cap, dtype=torch.uint8, device=DEV))
     torch.cuda.synchronize()
     X = torch.stack([px, py, pz], 1).cpu().numpy()
@@ -219,7 +250,7 @@ def test_masked_ballquery_equals_filter_then_fuse(st):
     cnt_b = _t(np.array([len(b) for b in segsB], np.int32))
     ta, tb = _t(np.array(base_a, np.int64)), _t(np.array(base_b, np.int64))
     radius = _t(np.array([0.6, 3.0, 0.6, 3.0, 0.6, 3.0]))
-    tile_off = torch.zeros(S + 1, dtype=torch.int32, device=DEV)
+    tile_off = torch.zeros(2 * S + 2, dtype=torch.int32, device=DEV)
     flags = torch.zeros(cap, dtype=torch.uint8, device=DEV)
     queue = torch.zeros(2 + 2 * cap, dtype=torch.int32, device=DEV)
     st.radius_filter(px, py, pz, tb, cnt_b, radius, 1, S, cap, tile_off, flags, queue,

@@ -29,13 +29,14 @@ def generate():
     from dfu3d_amd import synth, kitti_io
     from dfu3d_amd.params import NUSC_CLASSES
     img = np.zeros((H, W, 3), np.uint8)
+    dev = "cuda:0" if torch.cuda.is_available() else "cpu"       # (the CLI runs in fresh processes below)
     t0 = time.time()
     for f in range(N):
-        s = synth.make_scene(5000 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20)
+        s = synth.make_scene(5000 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20, device=dev)
         n = int(s.n_inst[0])
-        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], img, s.masks[0][:n].numpy(),
-                             s.inst_class[0][:n].numpy(), s.inst_score[0][:n].numpy(), s.inst_box[0][:n].numpy(),
-                             NUSC_CLASSES, s.depth[0].numpy())
+        kitti_io.write_frame(root, f, s.points.cpu().numpy(), s.calibs[0], img, s.masks[0][:n].cpu().numpy(),
+                             s.inst_class[0][:n].cpu().numpy(), s.inst_score[0][:n].cpu().numpy(),
+                             s.inst_box[0][:n].cpu().numpy(), NUSC_CLASSES, s.depth[0].cpu().numpy(), compress=False)
         if f % 500 == 499:
             print("generated %d frames (%.0fs)" % (f + 1, time.time() - t0), flush=True)
     return time.time() - t0
