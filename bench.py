@@ -39,12 +39,12 @@ def log(*a):
 STAGE_KERNELS = {
     "fov_filter": ["k_fov_filter"], "plane_ransac": ["k_plane_ransac"],
     "project_label": ["k_project_rows", "k_label_rows"],
-    "bp_bin": ["k_bp_bin"], "bp_amb": ["k_bp_bin_amb"], "bp_mark": ["k_bp_scan"],
+    "bp_bin": ["k_bp_bin", "k_bp_prep", "k_bp_tables"], "bp_amb": ["k_bp_bin_amb"], "bp_mark": ["k_bp_scan"],
     "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
                                           "k_bp_finalize"],
     "segments_build": ["k_seg_count", "k_seg_alloc", "k_seg_write"],
     "rf_flags": ["k_radius_flags"], "rf_resolve": ["k_radius_resolve"], "rf_compact": ["k_seg_compact_short"],
-    "ballquery_fuse": ["k_tile_scan", "k_ball_flags", "k_seg_compact"],
+    "ballquery_fuse": ["k_tile_scan_class", "k_ball_flags", "k_seg_compact"],
     "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],
     "lshape_fit": ["k_fit_gather", "k_fit_tiny", "k_fit_medium", "k_fit_big_cost", "k_fit_big_box"],
 }

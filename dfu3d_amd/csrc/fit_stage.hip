@@ -19,6 +19,9 @@ namespace {
 constexpr int CT = 512;            // threads per clustering workgroup
 constexpr int GRP = 32;            // points per summary / bounding-box group
 constexpr int BLK = 32;            // groups per block (1024 points): second pruning level
+constexpr int PAIR_SMALL = 32;     // grid clustering: cell runs up to this length are paired by a single lane
+constexpr int GRID_LONG_N = 8192;  // grid clustering: instances above this size get 1024 threads
+constexpr int GU = 4;              // grid clustering: points per thread and step of a sweep over the instance
 constexpr int SMALL_N = 4096;      // segments up to this size: 32-bit parents, 20 KB of LDS
 constexpr int LARGE_N = 61440;     // up to this size: 16-bit parents in LDS (120 KB)
 constexpr int LARGE_GRP = LARGE_N / GRP;
@@ -442,14 +445,26 @@ __device__ __forceinline__ void cell_sort(const double *X, const double *Y, int 
 template <int NC>
 struct GridGeom { double x0, y0, inv, g, Rmax; int nx, ny, ncell; bool ok; };
 
-template <int NC>
+template <int NC, int TCT>
 __device__ __forceinline__ GridGeom<NC> grid_geometry(const double *X, const double *Y, int n,
                                                       double R0, double Rd, double *s_red) {
   double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, r2 = 0.0;
-  for (int i = threadIdx.x; i < n; i += CT) {
-    const double x = X[i], y = Y[i];
-    x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
-    r2 = fmax(r2, x * x + y * y);
+  // GU points per thread and step, all loads requested before the first is used: the instance is walked by ONE
+  // workgroup, and a step per memory round trip made the largest instance (50 000 points) the tail of the kernel
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? X[i] : NAN; ys[u] = (i < n) ? Y[i] : NAN;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      if (i0 + u * TCT >= n) break;
+      const double x = xs[u], y = ys[u];
+      x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+      r2 = fmax(r2, x * x + y * y);
+    }
   }
   x0 = wave_min_d(x0); x1 = wave_max_d(x1); y0 = wave_min_d(y0); y1 = wave_max_d(y1);
   r2 = wave_max_d(r2);
@@ -457,7 +472,7 @@ __device__ __forceinline__ GridGeom<NC> grid_geometry(const double *X, const dou
   __syncthreads();
   if (lane_id() == 0) { s_red[5 * w] = x0; s_red[5 * w + 1] = x1; s_red[5 * w + 2] = y0; s_red[5 * w + 3] = y1; s_red[5 * w + 4] = r2; }
   __syncthreads();
-  for (int k = 0; k < CT / 64; k++) {
+  for (int k = 0; k < TCT / 64; k++) {
     x0 = fmin(x0, s_red[5 * k]); x1 = fmax(x1, s_red[5 * k + 1]);
     y0 = fmin(y0, s_red[5 * k + 2]); y1 = fmax(y1, s_red[5 * k + 3]); r2 = fmax(r2, s_red[5 * k + 4]);
   }
@@ -505,21 +520,33 @@ __device__ __forceinline__ void cell_unite(int *par, int a, int b) {
   }
 }
 
+#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of wave 0 per phase of k_range_cluster_grid, summed over workgroups */
+__device__ unsigned long long g_grid_dbg[16];
+__device__ unsigned long long g_grid_max[8];
+#define GT_START() long long gt_t = clock64(); const long long gt_t0 = gt_t
+#define GT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_grid_dbg[k], (unsigned long long)(t_ - gt_t)); atomicMax(&g_grid_max[k], ((unsigned long long)(t_ - gt_t) << 24) | (unsigned long long)min(n, 0xFFFFFF)); gt_t = t_; } } while (0)
+#define GT_COUNT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_dbg[k], (unsigned long long)(v)); } while (0)
+#else
+#define GT_START() do {} while (0)
+#define GT_STAMP(k) do {} while (0)
+#define GT_COUNT(k, v) do {} while (0)
+#endif
+
 // -1: instance not eligible for this variant (NC_MIN < ncell <= NC handled here)
-template <int NC, int NC_MIN>
-__global__ __launch_bounds__(CT) void k_range_cluster_grid(
+template <int NC, int NC_MIN, int TCT>
+__global__ __launch_bounds__(TCT) void k_range_cluster_grid(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
     double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
-    int *__restrict__ perm_all, long long pool_cap) {
+    int *__restrict__ perm_all, long long pool_cap, int n_lo, int n_hi) {
   __shared__ int s_end[NC];          // cell -> end of its run in sorted order
   __shared__ int s_par[NC];          // union-find over cells (volatile use through pointers)
   __shared__ int s_min[NC];          // smallest original index per root cell
-  __shared__ double s_red[5 * (CT / 64)];
-  __shared__ int s_w[CT / 64];
+  __shared__ double s_red[5 * (TCT / 64)];
+  __shared__ int s_w[TCT / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
-  if (n == 0) return;
+  if (n <= n_lo || n > n_hi) return;                   // (n_lo >= 0) another launch of this kernel owns the instance
   const long long base = seg_base[s];
   const double *X = px + base, *Y = py + base;
   double *SX = sx + base, *SY = sy + base;
@@ -529,46 +556,138 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
   // leave at once instead of measuring the instance again
   int *mark = perm_all + 2 * pool_cap + base;
   if (NC_MIN > 0 && *mark) return;                     // the smaller variant did it
-  const GridGeom<NC> G = grid_geometry<NC>(X, Y, n, R0, Rd, s_red);
+  GT_START();
+  const GridGeom<NC> G = grid_geometry<NC, TCT>(X, Y, n, R0, Rd, s_red);
+  GT_STAMP(0);
   if (threadIdx.x == 0 && (NC_MIN == 0 || G.ok)) *mark = G.ok ? 1 : 0;
   if (!G.ok) return;                                   // too wide: a larger variant / the point-level kernels
   const int ncell = G.ncell;
   // ---- counting sort by cell ------------------------------------------------
-  for (int c = threadIdx.x; c < ncell; c += CT) { s_end[c] = 0; s_par[c] = c; s_min[c] = 0x7FFFFFFF; }
+  for (int c = threadIdx.x; c < ncell; c += TCT) { s_end[c] = 0; s_par[c] = c; s_min[c] = 0x7FFFFFFF; }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += CT) atomicAdd(&s_end[grid_cell(G, X[i], Y[i])], 1);
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? X[i] : 0.0; ys[u] = (i < n) ? Y[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++)
+      if (i0 + u * TCT < n) atomicAdd(&s_end[grid_cell(G, xs[u], ys[u])], 1);
+  }
   __syncthreads();
   {
-    const int per = (ncell + CT - 1) / CT;
+    const int per = (ncell + TCT - 1) / TCT;
     const int c_lo = min((int)threadIdx.x * per, ncell), c_hi = min(c_lo + per, ncell);
     int mine = 0;
     for (int c = c_lo; c < c_hi; c++) mine += s_end[c];
     int tot;
-    int run = block_excl_scan<CT / 64>(mine, s_w, tot);
+    int run = block_excl_scan<TCT / 64>(mine, s_w, tot);
     for (int c = c_lo; c < c_hi; c++) { const int h = s_end[c]; s_end[c] = run; run += h; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += CT) {
-    const double x = X[i], y = Y[i];
-    const int pos = atomicAdd(&s_end[grid_cell(G, x, y)], 1);      // s_end[c] ends as the run's end
-    SX[pos] = x;
-    SY[pos] = y;
-    perm[pos] = i;
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? X[i] : 0.0; ys[u] = (i < n) ? Y[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      if (i >= n) break;
+      const int pos = atomicAdd(&s_end[grid_cell(G, xs[u], ys[u])], 1);      // s_end[c] ends as the run's end
+      SX[pos] = xs[u];
+      SY[pos] = ys[u];
+      perm[pos] = i;
+    }
   }
   __syncthreads();
+  GT_STAMP(1);
+  GT_COUNT(8, 1); GT_COUNT(9, n); GT_COUNT(10, ncell);
   // ---- link neighbouring cells ----------------------------------------------
   const double S_HI = G.Rmax * G.Rmax * (1.0 + 1e-9);
   const double S_LO = R0 * R0 * (1.0 - 1e-12);
   const int lane = lane_id();
+  // Tight box of every cell's points, in 1/256 of the cell and rounded outward (one word per cell, kept in s_min
+  // until the labels need it): two cells whose boxes are farther apart than R_max cannot hold an adjacent pair and
+  // are never paired point by point -- those were the expensive pairs, every one of their point pairs had to fail.
+  int *s_box = s_min;                // x0 | x1 << 8 | y0 << 16 | y1 << 24; lower bytes: floor(256 u) (the box starts at
+                                     // byte/256 or before), upper bytes: ceil(256 u) - 1 (it ends at (byte+1)/256 or after)
+  for (int c = threadIdx.x; c < ncell; c += TCT) s_box[c] = (int)0x00FF00FFu;   // empty box (never looked at for an empty cell)
+  __syncthreads();
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? SX[i] : 0.0; ys[u] = (i < n) ? SY[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      if (i0 + u * TCT >= n) break;
+      const int c = grid_cell(G, xs[u], ys[u]);
+      const int cx = c % G.nx, cy = c / G.nx;
+      const double fu = (xs[u] - G.x0) * G.inv - (double)cx, fv = (ys[u] - G.y0) * G.inv - (double)cy;
+      const unsigned ulo = (unsigned)(int)fmin(fmax(floor(fu * 256.0), 0.0), 255.0);
+      const unsigned uhi = (unsigned)(int)fmin(fmax(ceil(fu * 256.0) - 1.0, 0.0), 255.0);
+      const unsigned vlo = (unsigned)(int)fmin(fmax(floor(fv * 256.0), 0.0), 255.0);
+      const unsigned vhi = (unsigned)(int)fmin(fmax(ceil(fv * 256.0) - 1.0, 0.0), 255.0);
+      // widen the cell's box to this point; after the first few points of a cell hardly any point still does
+      unsigned old = (unsigned)__hip_atomic_load(&s_box[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (true) {
+        const unsigned nw = min(old & 255u, ulo) | (max((old >> 8) & 255u, uhi) << 8) |
+                            (min((old >> 16) & 255u, vlo) << 16) | (max(old >> 24, vhi) << 24);
+        if (nw == old) break;
+        const unsigned seen = (unsigned)atomicCAS(&s_box[c], (int)old, (int)nw);
+        if (seen == old) break;
+        old = seen;
+      }
+    }
+  }
+  __syncthreads();
+  // gap between the boxes of cells (cx, cy) and (qx, qy), in cells, minus two quanta of safety; squared against R_max
+  const double box_lim = S_HI * (1.0 + 1e-6) * (G.inv * G.inv);
+  auto boxes_apart = [&](int c, int cx, int cy, int nbc, int qx, int qy) {
+    const unsigned a = (unsigned)s_box[c], b = (unsigned)s_box[nbc];
+    const int ax0 = cx * 256 + (int)(a & 255u), ax1 = cx * 256 + (int)((a >> 8) & 255u) + 1;
+    const int ay0 = cy * 256 + (int)((a >> 16) & 255u), ay1 = cy * 256 + (int)(a >> 24) + 1;
+    const int bx0 = qx * 256 + (int)(b & 255u), bx1 = qx * 256 + (int)((b >> 8) & 255u) + 1;
+    const int by0 = qy * 256 + (int)((b >> 16) & 255u), by1 = qy * 256 + (int)(b >> 24) + 1;
+    const int gx = max(max(bx0 - ax1, ax0 - bx1) - 2, 0), gy = max(max(by0 - ay1, ay0 - by1) - 2, 0);
+    const double g2 = (double)(gx * gx + gy * gy) * (1.0 / 65536.0);
+    return g2 > box_lim;
+  };
+  // A point farther than R_max from the (outward rounded) box of the other cell has no neighbour there: only the
+  // points of each cell that pass this test are paired.  Two dense groups separated by a little more than R --
+  // where every pair used to be evaluated only to fail -- leave a thin strip on either side, usually nothing.
+  struct CellBox { double x0, x1, y0, y1; };
+  auto cell_box = [&](int c) {
+    const unsigned a = (unsigned)s_box[c];
+    const int cx = c % G.nx, cy = c / G.nx;
+    CellBox B;
+    B.x0 = G.x0 + ((double)cx + (double)((int)(a & 255u) - 1) * (1.0 / 256.0)) * G.g;       // one quantum of safety
+    B.x1 = G.x0 + ((double)cx + (double)((int)((a >> 8) & 255u) + 2) * (1.0 / 256.0)) * G.g;
+    B.y0 = G.y0 + ((double)cy + (double)((int)((a >> 16) & 255u) - 1) * (1.0 / 256.0)) * G.g;
+    B.y1 = G.y0 + ((double)cy + (double)((int)(a >> 24) + 2) * (1.0 / 256.0)) * G.g;
+    return B;
+  };
+  const double reach2 = S_HI * (1.0 + 1e-6);
+  auto near_box = [&](const CellBox &B, double x, double y) {
+    const double dx = fmax(fmax(B.x0 - x, x - B.x1), 0.0), dy = fmax(fmax(B.y0 - y, y - B.y1), 0.0);
+    return dx * dx + dy * dy <= reach2;
+  };
   // half neighbourhood: 4 touching offsets, then the 8 with a one-cell gap
   const int ODX[12] = {1, -1, 0, 1, 2, -2, -1, 0, 1, 2, -2, 2};
   const int ODY[12] = {0, 1, 1, 1, 0, 2, 2, 2, 2, 2, 1, 1};
   for (int round = 0; round < 2; round++) {
     const int o_lo = round ? 4 : 0, n_off = round ? 8 : 4;
     const int items = ncell * n_off;
-    const int iters = (items + CT - 1) / CT;
+    const int iters = (items + TCT - 1) / TCT;
     for (int it = 0; it < iters; it++) {                 // uniform trip count per block
-      const int idx = it * CT + threadIdx.x;
+      const int idx = it * TCT + threadIdx.x;
       int c = 0, nb = 0;
       bool need = false;
       if (idx < items) {
@@ -579,12 +698,43 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
         if (qx >= 0 && qx < G.nx && qy < G.ny) {
           nb = qy * G.nx + qx;
           const int a0 = c ? s_end[c - 1] : 0, b0 = s_end[nb - 1];     // nb > c >= 0
-          need = (s_end[c] > a0) && (s_end[nb] > b0) &&
+          need = (s_end[c] > a0) && (s_end[nb] > b0) && !boxes_apart(c, cx, cy, nb, qx, qy) &&
                  (cell_find(s_par, c) != cell_find(s_par, nb));
         }
       }
-      // the wave serves its lanes' open pairs one at a time, all 64 lanes on the point pairs
+      // Two short runs (the usual case: a cell holds a handful of points): the lane tests its pair by itself, at
+      // most PAIR_SMALL^2 distance evaluations with an exit at the first adjacent pair -- 64 open pairs per wave
+      // in flight instead of one (the wave-cooperative path below costs three dependent memory round trips and
+      // eight fp64 wave reductions per pair, and one instance has thousands of open pairs).
+      if (need) {
+        const int a0 = c ? s_end[c - 1] : 0, a1 = s_end[c];
+        const int b0 = s_end[nb - 1], b1 = s_end[nb];
+        if (a1 - a0 <= PAIR_SMALL && b1 - b0 <= PAIR_SMALL) {
+          need = false;
+          bool found = false;
+          const CellBox BA = cell_box(c), BB = cell_box(nb);
+          for (int i = a0; i < a1 && !found; i++) {
+            const double xa = SX[i], ya = SY[i];
+            if (!near_box(BB, xa, ya)) continue;
+            const double Ra = R0 + Rd * sqrt(xa * xa + ya * ya);
+            for (int j = b0; j < b1; j++) {
+              const double xb = SX[j], yb = SY[j];
+              const double dx = xa - xb, dy = ya - yb;
+              const double sq = dx * dx + dy * dy;
+              if (sq > S_HI) continue;
+              if (sq <= S_LO) { found = true; break; }
+              const double d = sqrt(sq);                                   // rectangle_fitting.py:169
+              if (d <= Ra || d <= R0 + Rd * sqrt(xb * xb + yb * yb)) { found = true; break; }
+            }
+          }
+          if (found) cell_unite(s_par, c, nb);
+        }
+      }
+      // the wave serves its lanes' remaining open pairs one at a time, all 64 lanes on the point pairs
       unsigned long long todo = __ballot(need);
+#ifdef DFU3D_DBG_GRID_TIMING
+      if (lane == 0 && todo) atomicAdd(&g_grid_dbg[11], (unsigned long long)__popcll(todo));
+#endif
       while (todo) {
         const int src = __ffsll(todo) - 1;
         todo &= todo - 1ull;
@@ -592,35 +742,26 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
         if (cell_find(s_par, cc) == cell_find(s_par, nn)) continue;   // merged meanwhile (uniform)
         const int a0 = cc ? s_end[cc - 1] : 0, a1 = s_end[cc];
         const int b0 = s_end[nn - 1], b1 = s_end[nn];
-        // (i) tight boxes of the two runs: farther apart than R_max -> no pair can be adjacent
-        double ax0 = INFINITY, ax1 = -INFINITY, ay0 = INFINITY, ay1 = -INFINITY;
-        double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
-        for (int i = a0 + lane; i < a1; i += 64) {
-          const double x = SX[i], y = SY[i];
-          ax0 = fmin(ax0, x); ax1 = fmax(ax1, x); ay0 = fmin(ay0, y); ay1 = fmax(ay1, y);
-        }
-        for (int i = b0 + lane; i < b1; i += 64) {
-          const double x = SX[i], y = SY[i];
-          bx0 = fmin(bx0, x); bx1 = fmax(bx1, x); by0 = fmin(by0, y); by1 = fmax(by1, y);
-        }
-        ax0 = wave_min_d(ax0); ax1 = wave_max_d(ax1); ay0 = wave_min_d(ay0); ay1 = wave_max_d(ay1);
-        bx0 = wave_min_d(bx0); bx1 = wave_max_d(bx1); by0 = wave_min_d(by0); by1 = wave_max_d(by1);
-        const double gx = fmax(fmax(bx0 - ax1, ax0 - bx1), 0.0), gy = fmax(fmax(by0 - ay1, ay0 - by1), 0.0);
-        if (gx * gx + gy * gy > S_HI) continue;
-        // (ii) 64 x 64 tiles of point pairs: each lane keeps one point of the second
+        // (the cells' boxes have been compared already: `need`)
+        // 64 x 64 tiles of point pairs: each lane keeps one point of the second
         // run, the first run's points are broadcast lane by lane -- no memory traffic
         // inside a tile; leave at the first adjacent pair
         bool found = false;
+        const CellBox BA = cell_box(cc), BB = cell_box(nn);
         for (int b_lo = b0; b_lo < b1 && !found; b_lo += 64) {
           const int ib = b_lo + lane;
-          const bool vb = ib < b1;
-          const double xb = vb ? SX[ib] : 0.0, yb = vb ? SY[ib] : 0.0;
+          const double xb = (ib < b1) ? SX[ib] : 0.0, yb = (ib < b1) ? SY[ib] : 0.0;
+          const bool vb = (ib < b1) && near_box(BA, xb, yb);
+          if (!__any(vb)) continue;                                      // (uniform)
           for (int a_lo = a0; a_lo < a1 && !found; a_lo += 64) {
             const int ia = a_lo + lane;
             const double xal = (ia < a1) ? SX[ia] : 0.0, yal = (ia < a1) ? SY[ia] : 0.0;
-            const int cnt = min(64, a1 - a_lo);
+            unsigned long long am = __ballot((ia < a1) && near_box(BB, xal, yal));
             bool adj = false;
-            for (int k = 0; k < cnt; k++) {
+            int steps = 0;
+            while (am) {
+              const int k = __ffsll((long long)am) - 1;
+              am &= am - 1ull;
               const double xa = __shfl(xal, k, 64), ya = __shfl(yal, k, 64);
               const double dx = xa - xb, dy = ya - yb;
               const double sq = dx * dx + dy * dy;
@@ -632,7 +773,7 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
                         (d <= R0 + Rd * sqrt(xb * xb + yb * yb));
                 }
               }
-              if ((k & 15) == 15 && __any(adj)) break;
+              if ((++steps & 15) == 0 && __any(adj)) break;
             }
             found = __any(adj);
           }
@@ -641,14 +782,45 @@ __global__ __launch_bounds__(CT) void k_range_cluster_grid(
       }
     }
     __syncthreads();
+    GT_STAMP(2 + round);
   }
   // ---- labels: smallest original index of the component ---------------------
-  for (int i = threadIdx.x; i < n; i += CT)
-    atomicMin(&s_min[cell_find(s_par, grid_cell(G, SX[i], SY[i]))], perm[i]);
+  for (int c = threadIdx.x; c < ncell; c += TCT) s_min[c] = 0x7FFFFFFF;        // (held the cell boxes until here)
+  __syncthreads();
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+    int pm[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? SX[i] : 0.0; ys[u] = (i < n) ? SY[i] : 0.0; pm[u] = (i < n) ? perm[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++)
+      if (i0 + u * TCT < n) atomicMin(&s_min[cell_find(s_par, grid_cell(G, xs[u], ys[u]))], pm[u]);
+  }
   __syncthreads();
   int *glabel = label + base;
-  for (int i = threadIdx.x; i < n; i += CT)
-    glabel[perm[i]] = s_min[cell_find(s_par, grid_cell(G, SX[i], SY[i]))];
+  for (int i0 = threadIdx.x; i0 < n; i0 += GU * TCT) {
+    double xs[GU], ys[GU];
+    int pm[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = i0 + u * TCT;
+      xs[u] = (i < n) ? SX[i] : 0.0; ys[u] = (i < n) ? SY[i] : 0.0; pm[u] = (i < n) ? perm[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++)
+      if (i0 + u * TCT < n) glabel[pm[u]] = s_min[cell_find(s_par, grid_cell(G, xs[u], ys[u]))];
+  }
+  GT_STAMP(4);
+#ifdef DFU3D_DBG_GRID_TIMING
+  if (threadIdx.x == 0) {
+    const unsigned long long tot = (unsigned long long)(clock64() - gt_t0);
+    atomicMax(&g_grid_dbg[12], (tot << 24) | (unsigned long long)min(n, 0xFFFFFF));
+    atomicMax(&g_grid_dbg[13], ((unsigned long long)n << 32) | (tot & 0xFFFFFFFFull));
+  }
+#endif
 }
 
 __global__ __launch_bounds__(CT) void k_range_cluster_small(
@@ -1181,19 +1353,23 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
   }
 }
 
-// ---- large clusters: one WAVE per (cluster, heading), items handed out through a counter -------------
-// The members stay in global memory (a cluster's 16 B x m are read by the waves that work on its headings at the
-// same time: L2 / L1 traffic, not HBM).  A wave sweeps the members three times (extents; sums and counts of
-// E1 / E2; squared deviations -- rectangle_fitting.py:83-111) with everything per heading in registers: no LDS
-// operand, no barrier and no workgroup-wide reduction inside an item, a dozen live values per lane (the first
-// formulation scored eight headings per sweep from 512-thread workgroups: 64 accumulators per lane, two waves per
-// SIMD, 80 wave reductions and seven barriers per item).
-constexpr int BIGC_T = 256;
+// ---- large clusters: workgroup per (cluster, batch of BIGC_HB headings), items handed out through a counter ----
+// The workgroup streams the cluster's members through LDS in chunks of BIGC_CH (three sweeps: extents; sums and counts
+// of E1 / E2; squared deviations -- rectangle_fitting.py:83-111); every wave scores BIGC_HPW headings of the batch
+// against each chunk with everything per heading in registers.  No LDS operand besides the two coordinates, no
+// workgroup-wide reduction: the only barriers are the two around a chunk's load.
+// (First formulation: eight headings per sweep, every thread other points -- 64 accumulators per lane, two waves
+// per SIMD, 80 wave reductions + cross-wave sums and seven barriers per item.  A wave per heading reading the
+// members straight from global memory was tried as well: every XCD fetched every cluster, 5.4 GB per launch.)
+constexpr int BIGC_T = 512, BIGC_WAVES = BIGC_T / 64, BIGC_HPW = 2, BIGC_HB = BIGC_WAVES * BIGC_HPW;
+constexpr int BIGC_CH = 2048;
 __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restrict__ gsx,
                                                          const double *__restrict__ gsy, int n_theta,
                                                          double dtheta, double *__restrict__ fit_ws,
                                                          int cap_rows, int cap_big) {
+  __shared__ double lx[BIGC_CH], ly[BIGC_CH];
   __shared__ double s_ct[MAXTH], s_st[MAXTH];
+  __shared__ int s_item;
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
   const int nbig = min(W.counters[1], cap_big);
   if (nbig == 0) return;
@@ -1202,63 +1378,112 @@ __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restric
     s_ct[threadIdx.x] = cos(theta);
     s_st[threadIdx.x] = sin(theta);
   }
-  __syncthreads();
-  const int lane = lane_id();
-  const long long items = (long long)nbig * n_theta;
-  // Every lane adds 1 (the compiler turns that into ONE atomic of +64 per wave), so the counter runs in units of 64
-  // and the wave's item is its first lane's ticket / 64.  An atomic under `if (lane == 0)` at the head of this loop
-  // must not be used: the loop is then restructured so that the other 63 lanes spin on the old item while lane 0
-  // waits for them -- it never ends.
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int nb = (n_theta + BIGC_HB - 1) / BIGC_HB;
+  const int items = nbig * nb;
   while (true) {
-    const int ticket = atomicAdd(&W.counters[2], 1);
-    const int it = __builtin_amdgcn_readfirstlane(ticket) >> 6;
-    if (it >= items) break;                    // every wave gets here: the counter only grows
-    const int c = it / n_theta, th = it - c * n_theta;
+    __syncthreads();                           // the previous item is done with s_item and the chunk
+    if (wave == 0) {
+      // every lane of wave 0 adds 1 (ONE atomic of +64): the counter runs in units of 64.  (An atomic under
+      // `lane == 0` whose result steers the loop invites the compiler to split the loop by lane: it hangs.)
+      const int ticket = atomicAdd(&W.counters[2], 1);
+      if (lane == 0) s_item = ticket >> 6;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item >= items) break;                  // uniform; the counter only grows
+    const int c = item / nb, tb = (item - c * nb) * BIGC_HB;
     const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
     const int m = (int)dsc[3];
     const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
-    const double ct = s_ct[th], st = s_st[th], nst = -st;
-    double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
-#pragma unroll 4
-    for (int i = lane; i < m; i += 64) {
-      const double x = mx[i], y = my[i];
-      const double c1 = x * ct + y * st;
-      const double c2 = x * nst + y * ct;
-      a0 = fmin(a0, c1); a1 = fmax(a1, c1);
-      b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+    int th[BIGC_HPW];
+    double ct[BIGC_HPW], st[BIGC_HPW], nst[BIGC_HPW];
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) {
+      th[h] = tb + wave * BIGC_HPW + h;
+      const int tc = min(th[h], n_theta - 1);  // a heading past the end is scored and dropped
+      ct[h] = s_ct[tc]; st[h] = s_st[tc]; nst[h] = -st[h];
     }
-    a0 = wave_min_d(a0); a1 = wave_max_d(a1);
-    b0 = wave_min_d(b0); b1 = wave_max_d(b1);
-    double s1 = 0.0, s2 = 0.0;
-    int n1 = 0, n2 = 0;
-#pragma unroll 4
-    for (int i = lane; i < m; i += 64) {
-      const double x = mx[i], y = my[i];
-      const double c1 = x * ct + y * st;
-      const double c2 = x * nst + y * ct;
-      const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-      const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-      if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+    double a0[BIGC_HPW], a1[BIGC_HPW], b0[BIGC_HPW], b1[BIGC_HPW];
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) { a0[h] = INFINITY; a1[h] = -INFINITY; b0[h] = INFINITY; b1[h] = -INFINITY; }
+    for (int c0 = 0; c0 < m; c0 += BIGC_CH) {
+      const int cm = min(BIGC_CH, m - c0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < cm; i += BIGC_T) { lx[i] = mx[c0 + i]; ly[i] = my[c0 + i]; }
+      __syncthreads();
+      for (int i = lane; i < cm; i += 64) {
+        const double x = lx[i], y = ly[i];
+#pragma unroll
+        for (int h = 0; h < BIGC_HPW; h++) {
+          const double c1 = x * ct[h] + y * st[h];
+          const double c2 = x * nst[h] + y * ct[h];
+          a0[h] = fmin(a0[h], c1); a1[h] = fmax(a1[h], c1);
+          b0[h] = fmin(b0[h], c2); b1[h] = fmax(b1[h], c2);
+        }
+      }
     }
-    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    n1 = wave_sum_i(n1); n2 = wave_sum_i(n2);
-    const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
-    double q1 = 0.0, q2 = 0.0;
-#pragma unroll 4
-    for (int i = lane; i < m; i += 64) {
-      const double x = mx[i], y = my[i];
-      const double c1 = x * ct + y * st;
-      const double c2 = x * nst + y * ct;
-      const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-      const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-      if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
-      else { const double u = d2 - m2; q2 += u * u; }
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) {
+      a0[h] = wave_min_d(a0[h]); a1[h] = wave_max_d(a1[h]);
+      b0[h] = wave_min_d(b0[h]); b1[h] = wave_max_d(b1[h]);
     }
-    q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
-    double V1 = 0.0, V2 = 0.0;
-    if (n1) V1 = -(q1 / (double)n1);
-    if (n2) V2 = -(q2 / (double)n2);
-    if (lane == 0) W.big_cost[(size_t)c * MAXTH + th] = V1 + V2;
+    double s1[BIGC_HPW], s2[BIGC_HPW];
+    int n1[BIGC_HPW], n2[BIGC_HPW];
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) { s1[h] = 0.0; s2[h] = 0.0; n1[h] = 0; n2[h] = 0; }
+    for (int c0 = 0; c0 < m; c0 += BIGC_CH) {
+      const int cm = min(BIGC_CH, m - c0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < cm; i += BIGC_T) { lx[i] = mx[c0 + i]; ly[i] = my[c0 + i]; }
+      __syncthreads();
+      for (int i = lane; i < cm; i += 64) {
+        const double x = lx[i], y = ly[i];
+#pragma unroll
+        for (int h = 0; h < BIGC_HPW; h++) {
+          const double c1 = x * ct[h] + y * st[h];
+          const double c2 = x * nst[h] + y * ct[h];
+          const double d1 = fmin(fabs(a1[h] - c1), fabs(c1 - a0[h]));
+          const double d2 = fmin(fabs(b1[h] - c2), fabs(c2 - b0[h]));
+          if (d1 < d2) { s1[h] += d1; n1[h]++; } else { s2[h] += d2; n2[h]++; }
+        }
+      }
+    }
+    double m1[BIGC_HPW], m2[BIGC_HPW], q1[BIGC_HPW], q2[BIGC_HPW];
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) {
+      s1[h] = wave_sum_d(s1[h]); s2[h] = wave_sum_d(s2[h]);
+      n1[h] = wave_sum_i(n1[h]); n2[h] = wave_sum_i(n2[h]);
+      m1[h] = n1[h] ? s1[h] / (double)n1[h] : 0.0;
+      m2[h] = n2[h] ? s2[h] / (double)n2[h] : 0.0;
+      q1[h] = 0.0; q2[h] = 0.0;
+    }
+    for (int c0 = 0; c0 < m; c0 += BIGC_CH) {
+      const int cm = min(BIGC_CH, m - c0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < cm; i += BIGC_T) { lx[i] = mx[c0 + i]; ly[i] = my[c0 + i]; }
+      __syncthreads();
+      for (int i = lane; i < cm; i += 64) {
+        const double x = lx[i], y = ly[i];
+#pragma unroll
+        for (int h = 0; h < BIGC_HPW; h++) {
+          const double c1 = x * ct[h] + y * st[h];
+          const double c2 = x * nst[h] + y * ct[h];
+          const double d1 = fmin(fabs(a1[h] - c1), fabs(c1 - a0[h]));
+          const double d2 = fmin(fabs(b1[h] - c2), fabs(c2 - b0[h]));
+          if (d1 < d2) { const double u = d1 - m1[h]; q1[h] += u * u; }
+          else { const double u = d2 - m2[h]; q2[h] += u * u; }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < BIGC_HPW; h++) {
+      const double Q1 = wave_sum_d(q1[h]), Q2 = wave_sum_d(q2[h]);
+      double V1 = 0.0, V2 = 0.0;
+      if (n1[h]) V1 = -(Q1 / (double)n1[h]);
+      if (n2[h]) V2 = -(Q2 / (double)n2[h]);
+      if (lane == 0 && th[h] < n_theta) W.big_cost[(size_t)c * MAXTH + th[h]] = V1 + V2;
+    }
   }
 }
 
@@ -1324,13 +1549,18 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   if (!px || !py || !seg_base || !seg_cnt || !label || !sx || !sy || !si) return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0>), dim3(S), dim3(CT), 0,
+  // (an instance is walked by ONE workgroup: 1024 threads for the long ones, whose sweeps are the tail of the stage)
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 512>), dim3(S), dim3(512), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si, (long long)pool_cap);
+                     label, sx, sy, si, (long long)pool_cap, 0, GRID_LONG_N);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL>), dim3(S), dim3(CT), 0,
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si, (long long)pool_cap);
+                     label, sx, sy, si, (long long)pool_cap, GRID_LONG_N, 0x7FFFFFFF);
+  DFU3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL, 1024>), dim3(S), dim3(1024), 0,
+                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
+                     label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
   DFU3D_LAUNCH_CHECK();
   // fallback for instances wider than the largest grid: point-level union-find
   // (two LDS footprints; each kernel returns at once for segments it does not own)
@@ -1344,6 +1574,25 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
+
+#ifdef DFU3D_DBG_GRID_TIMING
+extern "C" int dfu3d_debug_grid_timing(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_grid_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_grid_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+extern "C" int dfu3d_debug_grid_max(unsigned long long *out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_grid_max), sizeof(unsigned long long) * 8) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_grid_max), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+#endif
 
 extern "C" int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap, int32_t cap_rows) {
   if (pool_cap <= 0 || cap_rows <= 0) return DFU3D_EINVAL;
@@ -1388,8 +1637,8 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
                      vc, inst_class, inst_is_car, inst_box, inst_score, n_theta, dtheta,
                      car_aspect_max, cap_rows, rows, n_rows, status, fit_ws, cap_big);
   DFU3D_LAUNCH_CHECK();
-  const long long bw = (long long)cap_big * n_theta;                    // one wave per item, at most
-  const int g2 = (int)(bw / (BIGC_T / 64) + 1 < 4096 ? bw / (BIGC_T / 64) + 1 : 4096);
+  const long long bi = (long long)cap_big * ((n_theta + BIGC_HB - 1) / BIGC_HB);   // items at most
+  const int g2 = (int)(bi < 2048 ? bi : 2048);                                    // persistent: a ticket counter hands out the items
   hipLaunchKernelGGL(k_fit_big_cost, dim3(g2), dim3(BIGC_T), 0, st, sx, sy, n_theta, dtheta,
                      fit_ws, cap_rows, cap_big);
   DFU3D_LAUNCH_CHECK();

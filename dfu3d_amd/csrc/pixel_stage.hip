@@ -53,6 +53,9 @@ constexpr int PBLK = PB * PPT;     // 1024 pixels per block
 constexpr uint32_t NOBIN = 0xFFFFFFFFu;
 constexpr uint32_t OVF_FLAG = 0x80000000u;
 
+// Five planes (structure of arrays): the atomics of the binning pass walk consecutive bins, and with one plane per
+// field a wave's 64 atomics of one instruction fall into 4-8 cache lines.  (One 32-byte record per bin was tried:
+// the voxel pass gained nothing and the binning pass went from 3.1 to 5.3 ms -- the atomic units work per line.)
 struct Table {
   unsigned long long *kmin, *combo;
   uint32_t *cnt, *first, *rep;
@@ -242,17 +245,18 @@ __global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float4 *__restrict__ 
   tab[i] = make_float4((float)edge(kn - 1), (float)edge(kn), (float)edge(kn + 1), __int_as_float((int)kn));
 }
 
-// bin of q from the axis' table, or TB_AMBIG
+// bin of q from the axis' table, or TB_AMBIG (no branches: garbage in -- NaN, an index off the table -- comes out
+// as TB_AMBIG through the comparisons)
 __device__ __forceinline__ int tab_bin(const float4 *__restrict__ tab, float q0, float inv_w, int J, float q,
                                        float delta) {
   int j = (int)((q - q0) * inv_w);
   j = min(max(j, 0), J - 1);
   const float4 e = tab[j];
   const int kn = __float_as_int(e.w);
-  if (!(q > e.x + delta)) return TB_AMBIG;
-  if (q < e.y - delta) return kn - 1;
-  if (q > e.y + delta && q < e.z - delta) return kn;
-  return TB_AMBIG;
+  const bool above = q > e.x + delta;
+  const bool low = q < e.y - delta;
+  const bool high = (q > e.y + delta) && (q < e.z - delta);
+  return (above && (low || high)) ? (low ? kn - 1 : kn) : TB_AMBIG;
 }
 
 // ---- float32 back-projection estimate ------------------------------------------------------------
@@ -319,48 +323,74 @@ __device__ __forceinline__ void backproject_f32(const FastCal &fc, int col, int 
 // dfu3d_selftest_classify() runs this function against pixel_bin() on random pixels of the real geometry and
 // calibration: the GPU tests require zero disagreements among the decided ones.
 // The exact fp64 coordinate that serves as the voxel key is computed only for pixels that are kept (want_key).
+// N pixels of one image row, straight-line code (the decisions of the N pixels are independent; written this way the
+// compiler interleaves their transcendental and table latencies and pairs their float32 arithmetic): res[k] = NOBIN
+// (certainly not binned), AMBIG (tier 2 decides) or the table index, with it / ip the window coordinates of the bin.
+template <int N>
+__device__ __forceinline__ void classify_fast(const FastCal &fc, const dfu3d_bin_geom &g, const FastGeom &fg,
+                                              const float4 *__restrict__ tab, int row, const int (&col)[N],
+                                              const float (&d)[N], uint32_t (&res)[N], int (&it)[N], int (&ip)[N]) {
+  float xf[N], yf[N], zf[N], err[N];
+  bool dead[N];
+  bool any_live = false;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    backproject_f32(fc, col[k], row, d[k], xf[k], yf[k], zf[k], err[k]);
+    const bool dok = (d[k] >= (float)g.depth_min) && (d[k] > 0.0f);      // my_loader.py:507-509
+    dead[k] = !dok || (zf[k] > fg.z_max + err[k]);                       // certainly z >= z_max (my_loader.py:540)
+    any_live = any_live || !dead[k];
+    res[k] = NOBIN; it[k] = 0; ip[k] = 0;
+  }
+  if (!any_live) return;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    bool amb = !(zf[k] < fg.z_max - err[k]);
+    const float r2 = xf[k] * xf[k] + yf[k] * yf[k] + zf[k] * zf[k];
+    const float rf = __builtin_amdgcn_sqrtf(r2);
+    const bool rok = (rf > 1e-3f) && (rf < 1e15f);
+    // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
+    const float er = 2.0f * err[k];                                      // |rf - r| <= sqrt(3) err + rounding
+    amb = amb || !rok || !(rf - er > fg.r_lo && rf + er < fg.r_hi);
+    const float ir = __builtin_amdgcn_rcpf(rf);
+    const float cz = zf[k] * ir;
+    const float s2 = 1.0f - cz * cz;
+    amb = amb || !(s2 > 1e-4f);                                          // near the poles
+    const float turn = err[k] * ir * 1.7320510f;                         // direction error: |(dx,dy,dz)| <= sqrt(3) err
+    const float dq = 1.5e-6f + 1.05f * turn;
+    const float qt = -cz;
+    const bool th_out = rok && (qt < fg.q_tmin - dq);                    // certainly theta <= theta_min (my_loader.py:175)
+    amb = amb || !(qt > fg.q_tmin + dq);
+    const int kt = tab_bin(tab, fg.tq0, fg.tinv, fg.tJ, qt, dq);
+    amb = amb || !(fabsf(xf[k]) > 8.0f * err[k] + 1e-20f);               // the sign of x decides the branch of atan(y/x)
+    const float qa = yf[k] * __builtin_amdgcn_rcpf(fabsf(xf[k]) + fabsf(yf[k]));
+    const float qp = xf[k] < 0.0f ? -qa : qa;
+    const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * rsqrtf(s2));
+    amb = amb || kt == TB_AMBIG || kp == TB_AMBIG;
+    const int itk = (amb ? g.t_lo : kt) - g.t_lo, ipk = (amb ? g.p_lo : kp) - g.p_lo;   // |kt|, |kp| <= 1e9: no wrap
+    amb = amb || itk < 0 || itk >= g.t_n || ipk < 0 || ipk >= g.p_n;
+    it[k] = itk;
+    ip[k] = ipk;
+    res[k] = (dead[k] || th_out) ? NOBIN : (amb ? AMBIG : (uint32_t)(itk * g.p_n + ipk));
+  }
+}
+
 __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc, const FastCal &fc,
                                                    const dfu3d_bin_geom &g, const FastGeom &fg,
                                                    const float4 *__restrict__ tab,
                                                    int row, int col, float d, const KeyCol &kc, bool want_key,
                                                    double &key, int &it_out, int &ip_out) {
-  if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
-  float xf, yf, zf, err;
-  backproject_f32(fc, col, row, d, xf, yf, zf, err);
-  if (zf > fg.z_max + err) return NOBIN;                          // certainly z >= z_max (my_loader.py:540)
-  if (!(zf < fg.z_max - err)) return AMBIG;
-  const float r2 = xf * xf + yf * yf + zf * zf;
-  const float rf = __builtin_amdgcn_sqrtf(r2);
-  if (!(rf > 1e-3f) || !(rf < 1e15f)) return AMBIG;
-  // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
-  const float er = 2.0f * err;                                    // |rf - r| <= sqrt(3) err + rounding
-  if (!(rf - er > fg.r_lo && rf + er < fg.r_hi)) return AMBIG;
-  const float ir = __builtin_amdgcn_rcpf(rf);
-  const float cz = zf * ir;
-  const float s2 = 1.0f - cz * cz;
-  if (!(s2 > 1e-4f)) return AMBIG;                                // near the poles
-  const float turn = err * ir * 1.7320510f;                       // direction error: |(dx,dy,dz)| <= sqrt(3) err
-  const float dq = 1.5e-6f + 1.05f * turn;
-  const float qt = -cz;
-  if (qt < fg.q_tmin - dq) return NOBIN;                          // certainly theta <= theta_min (my_loader.py:175)
-  if (!(qt > fg.q_tmin + dq)) return AMBIG;
-  const int kt = tab_bin(tab, fg.tq0, fg.tinv, fg.tJ, qt, dq);
-  if (kt == TB_AMBIG) return AMBIG;
-  if (!(fabsf(xf) > 8.0f * err + 1e-20f)) return AMBIG;           // the sign of x decides the branch of atan(y/x)
-  const float qa = yf * __builtin_amdgcn_rcpf(fabsf(xf) + fabsf(yf));
-  const float qp = xf < 0.0f ? -qa : qa;
-  const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * rsqrtf(s2));
-  if (kp == TB_AMBIG) return AMBIG;
-  // (kt - t_lo) cannot wrap: |kt| <= 1e9
-  const int it = kt - g.t_lo, ip = kp - g.p_lo;
-  if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) return AMBIG;
-  it_out = it;
-  ip_out = ip;
-  if (want_key) {
+  const int cols[1] = {col};
+  const float ds[1] = {d};
+  uint32_t res[1];
+  int it[1], ip[1];
+  classify_fast<1>(fc, g, fg, tab, row, cols, ds, res, it, ip);
+  it_out = it[0];
+  ip_out = ip[0];
+  if (want_key && res[0] < AMBIG) {
     key = pixel_to_lidar_axis(c, rc, kc, col, row, d);
     if (key == 0.0) key = 0.0;
   }
-  return (uint32_t)(it * g.p_n + ip);
+  return res[0];
 }
 
 // Pass 1 works on 2-D image tiles (TILE_W x TILE_H pixels, one float4 per
@@ -413,21 +443,24 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   if (inside) {
     const float *dv = depth + (size_t)v * HW;
     float d[PPT];
-    load4(dv + (size_t)row * W, col, W, d);
+    load4(dv + (size_t)row * W, col, W, d);          // (columns past the image come back as depth 0: not binned)
+    int cols[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) cols[k] = col + k;
+    uint32_t res[PPT];
+    classify_fast<PPT>(fc, g, fg, tab, row, cols, d, res, its, ips);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       bins[k] = NOBIN;
       keys[k] = 0.0;
-      its[k] = 0; ips[k] = 0;
-      if (col + k < W) {
-        const uint32_t b = pixel_bin_fast(c, rc, fc, g, fg, tab, row, col + k, d[k], kcol, true, keys[k],
-                                          its[k], ips[k]);
-        if (b == AMBIG) {
-          s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
-        } else {
-          bins[k] = b;
-          if (b != NOBIN) { tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]); }
-        }
+      const uint32_t b = res[k];
+      if (b == AMBIG) {
+        s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
+      } else if (b != NOBIN) {
+        bins[k] = b;
+        tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]);
+        keys[k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
+        if (keys[k] == 0.0) keys[k] = 0.0;
       }
     }
   }
@@ -446,6 +479,10 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
                       unsigned long long cm) {
       const int lt = it - t0, lp = ip - p0;
+#ifdef DFU3D_DBG_P1_NO_COMMIT         /* timing experiment only: results are wrong */
+      if (lt == 12345) s_cnt[0] = cn;
+      return;
+#endif
       if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
         const int w = lt * WIN_P + lp;
         atomicAdd(&s_cnt[w], cn);
@@ -487,6 +524,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   for (int w = threadIdx.x; w < WIN_T * WIN_P; w += PB) {
     const uint32_t cw = s_cnt[w];
     if (cw == 0u) continue;
+#ifdef DFU3D_DBG_P1_NO_FLUSH          /* timing experiment only: results are wrong */
+    continue;
+#endif
     const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
     const int64_t e = tb0 + b;
     atomicAdd(&T.cnt[e], cw);
@@ -581,6 +621,68 @@ __device__ __forceinline__ void emit_voxel(const VoxOut &o, size_t at, const Vie
   o.it_z[at] = z;
 }
 
+// what finishing a voxel needs of its view
+struct VoxCtx {
+  ViewCalib c;
+  Recip rc;
+  Table T;
+  const float *dv;
+  const void *masks;
+  int64_t tb0;
+  int mask_format, m, max_inst, HW, W, key_axis, pix_bits, cap_vox, cap_q, max_points, max_voxels;
+};
+__device__ __forceinline__ VoxCtx make_vox_ctx(const ViewCalib *calib, int v, void *table, int64_t E_total,
+                                               int64_t E_view, const void *masks, int mask_format, const int *n_inst,
+                                               int max_inst, const float *depth, int HW, int W, int key_axis,
+                                               int pix_bits, int cap_vox, int cap_q, int max_points, int max_voxels) {
+  VoxCtx X;
+  X.c = calib[v];
+  X.rc = make_recip(X.c);
+  X.T = table_view(table, E_total);
+  X.dv = depth + (size_t)v * HW;
+  X.masks = masks;
+  X.tb0 = (int64_t)v * E_view;
+  X.mask_format = mask_format;
+  X.m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
+  X.max_inst = max_inst; X.HW = HW; X.W = W; X.key_axis = key_axis; X.pix_bits = pix_bits;
+  X.cap_vox = cap_vox; X.cap_q = cap_q; X.max_points = max_points; X.max_voxels = max_voxels;
+  return X;
+}
+
+// voxel k of view v lives in bin b: representative, outputs, table entry left clean (or queued for the repair)
+__device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, int v, int k, uint32_t b,
+                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status) {
+  const Table &T = X.T;
+  const int64_t e = X.tb0 + b;
+  const uint32_t cw = T.cnt[e];
+  const uint32_t pix = (uint32_t)(T.combo[e] & ((1ull << X.pix_bits) - 1ull));
+  const int row = (int)pix / X.W, col = (int)pix - row * X.W;
+  double x, yy, z;
+  pixel_to_lidar(X.c, X.rc, col, row, X.dv[pix], x, yy, z);
+  double key = (X.key_axis == 2) ? z : yy;
+  if (key == 0.0) key = 0.0;
+  // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
+  if (cw > (uint32_t)X.max_points || ordered_key(key) != T.kmin[e]) {
+    const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
+    if (slot < X.cap_q) { q_bins[(size_t)v * X.cap_q + slot] = b; q_rank[(size_t)v * X.cap_q + slot] = k; }
+    else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
+    return;
+  }
+  if (k < X.max_voxels) {
+    const size_t at = (size_t)v * X.cap_vox + k;
+    out.vox_pix[at] = pix;
+    out.it_bits[at] = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
+    out.it_x[at] = x;
+    out.it_y[at] = yy;
+    out.it_z[at] = z;
+  }
+  // leave the table clean for the next pass (rep is only ever written by the repair)
+  T.kmin[e] = ~0ull;
+  T.combo[e] = ~0ull;
+  T.cnt[e] = 0u;
+  T.first[e] = NOBIN;
+}
+
 // ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
 constexpr int VXB = 256;
 constexpr int VX_PIECES = 64;                 // 64-pixel row pieces per workgroup = 4096 pixels
@@ -615,54 +717,25 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   }
   __syncthreads();
   const int rank0 = (int)R.wpre[(size_t)v * R.NJ + j0];
-  const Table T = table_view(table, E_total);
-  const ViewCalib c = calib[v];
+  const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
+                                key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
   const FastCal fc = fastcal[v];
-  const Recip rc = make_recip(c);
   const KeyCol kcol = load_key_col(calib + v, key_axis);
-  const int m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
-  const float *dv = depth + (size_t)v * HW;
-  const int64_t tb0 = (int64_t)v * E_view;
   bool rerr = false;
   for (int idx = threadIdx.x; idx < tot; idx += VXB) {
     const int k = rank0 + idx;
     if (k >= cap_vox) break;                       // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
     const uint32_t f = s_pix[idx];
-    // the bin of the first pixel: the same two-tier classification as in P1
+    // the bin of the first pixel: the same two-tier classification as in P1.  (Parking the undecided voxels for a
+    // second kernel doubled the occupancy of this one and made the pass slower: it runs at the memory system's
+    // rate for its scattered sector reads -- 4.3 TB/s of fetch + write traffic -- not at a latency limit.)
     double key_f;
     int it_, ip_;
     const int fr = (int)f / W, fcol = (int)f - fr * W;
-    uint32_t b = pixel_bin_fast(c, rc, fc, g, fg, tab, fr, fcol, dv[f], kcol, false, key_f, it_, ip_);
-    if (b == AMBIG) b = pixel_bin(c, rc, g, W, (int)f, dv[f], key_axis, key_f, rerr);
+    uint32_t b = pixel_bin_fast(X.c, X.rc, fc, g, fg, tab, fr, fcol, X.dv[f], kcol, false, key_f, it_, ip_);
+    if (b == AMBIG) b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    const int64_t e = tb0 + b;
-    const uint32_t cw = T.cnt[e];
-    const uint32_t pix = (uint32_t)(T.combo[e] & ((1ull << pix_bits) - 1ull));
-    const int row = (int)pix / W, col = (int)pix - row * W;
-    double x, yy, z;
-    pixel_to_lidar(c, rc, col, row, dv[pix], x, yy, z);
-    double key = (key_axis == 2) ? z : yy;
-    if (key == 0.0) key = 0.0;
-    // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
-    if (cw > (uint32_t)g.max_points_per_voxel || ordered_key(key) != T.kmin[e]) {
-      const int slot = atomicAdd(&n_q[v], 1);      // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
-      if (slot < cap_q) { q_bins[(size_t)v * cap_q + slot] = b; q_rank[(size_t)v * cap_q + slot] = k; }
-      else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
-      continue;
-    }
-    if (k < g.max_voxels) {
-      const size_t at = (size_t)v * cap_vox + k;
-      out.vox_pix[at] = pix;
-      out.it_bits[at] = masks ? mask_bits_at(masks, mask_format, v, max_inst, m, HW, (int)pix) : 0u;
-      out.it_x[at] = x;
-      out.it_y[at] = yy;
-      out.it_z[at] = z;
-    }
-    // leave the table clean for the next pass (rep is only ever written by the repair)
-    T.kmin[e] = ~0ull;
-    T.combo[e] = ~0ull;
-    T.cnt[e] = 0u;
-    T.first[e] = NOBIN;
+    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
