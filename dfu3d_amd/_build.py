@@ -55,6 +55,7 @@ VARIANTS = {
     "p1_noflush": ["-DDFU3D_DBG_P1_NO_FLUSH"],
     "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],
     "grid_timing": ["-DDFU3D_DBG_GRID_TIMING"],
+    "grid_split": ["-DDFU3D_GRID_SPLIT_LAUNCH"],
 }
 
 

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
         if (a1 - a0 <= PAIR_SMALL && b1 - b0 <= PAIR_SMALL) {
           need = false;
           bool found = false;
-          const CellBox BA = cell_box(c), BB = cell_box(nb);
+          const CellBox BB = cell_box(nb);
           for (int i = a0; i < a1 && !found; i++) {
             const double xa = SX[i], ya = SY[i];
             if (!near_box(BB, xa, ya)) continue;
@@ -1549,7 +1549,8 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   if (!px || !py || !seg_base || !seg_cnt || !label || !sx || !sy || !si) return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
-  // (an instance is walked by ONE workgroup: 1024 threads for the long ones, whose sweeps are the tail of the stage)
+  // (an instance is walked by ONE workgroup, and the longest instance is the tail of the stage: 1024 threads)
+#ifdef DFU3D_GRID_SPLIT_LAUNCH   /* measured alternative: 512 threads for the short instances in a launch of their own */
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 512>), dim3(S), dim3(512), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, GRID_LONG_N);
@@ -1558,6 +1559,12 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, GRID_LONG_N, 0x7FFFFFFF);
   DFU3D_LAUNCH_CHECK();
+#else
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(S), dim3(1024), 0,
+                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
+                     label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
+  DFU3D_LAUNCH_CHECK();
+#endif
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL, 1024>), dim3(S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);

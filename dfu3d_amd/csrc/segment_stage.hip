@@ -618,9 +618,8 @@ __global__ __launch_bounds__(256) void k_seg_compact_short(
 // few hundred LiDAR points, so its table fits 16 KB of LDS and 256-thread workgroups -- eight of them per compute
 // unit instead of two, which is what hides the dependent loads at the start of a workgroup (segment search,
 // segment facts, LiDAR points); the big build (64 KB, 1024 threads) takes the rest and the brute-force case.
-constexpr int BT_BIG = 1024, BH_HEADS_BIG = 8192, BH_MAX_BIG = 3072;      // 24 KB + 32 KB + 72 KB of LDS; 12-bit node index
-constexpr int BT_SMALL = 256, BH_HEADS_SMALL = 2048, BH_MAX_SMALL = 1024; // 8 KB + 8 KB + 24 KB of LDS
-constexpr int BQ_SMALL = 4, BQ_BIG = 2;       // queries per thread: tiles of 1024 / 2048 queries
+constexpr int BT_BIG = 1024, BH_HEADS_BIG = 8192, BH_MAX_BIG = 4096;      // 32 KB + 32 KB of LDS; 12-bit node index
+constexpr int BT_SMALL = 256, BH_HEADS_SMALL = 2048, BH_MAX_SMALL = 1024; // 8 KB + 8 KB of LDS
 
 // query tiles of the segments whose LiDAR list has lo < cnt_a <= hi entries
 __global__ __launch_bounds__(1024) void k_tile_scan_class(int S, const int *__restrict__ cnt, const int *__restrict__ cnt_a,
@@ -648,45 +647,7 @@ __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t i
   return h;
 }
 
-// find_segment for a whole workgroup in two memory round trips instead of log2(S) dependent ones: 256 evenly
-// spaced entries of tile_off go to LDS and are searched there, then the entries between the two samples that
-// bracket t.  (The binary search straight on global memory -- 14 dependent loads for S = 12288 -- was most of the
-// life of a ball-query workgroup.)  Every thread returns the segment; BT >= 256; S + 1 <= 65536.
-template <int BT>
-__device__ __forceinline__ int find_segment_wg(const int *__restrict__ tile_off, int S, int t, int *s_tab /* 256 */) {
-  const int step = (S + 256) / 256;                        // entries per sample: 256 * step >= S + 1
-  if (threadIdx.x < 256) s_tab[threadIdx.x] = tile_off[min((int)threadIdx.x * step, S)];
-  __syncthreads();
-  int lo = 0, hi = 256;                                    // largest i with s_tab[i] <= t (s_tab[0] = 0 <= t)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (s_tab[mid] <= t) lo = mid; else hi = mid;
-  }
-  const int e0 = lo * step;                                // tile_off[e0] <= t < tile_off[e0 + step] (or the end)
-  __syncthreads();
-  if ((int)threadIdx.x < step) s_tab[threadIdx.x] = tile_off[min(e0 + (int)threadIdx.x, S)];
-  __syncthreads();
-  lo = 0; hi = min(step, S - e0);                          // t < tile_off[S]: the answer is below S
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (s_tab[mid] <= t) lo = mid; else hi = mid;
-  }
-  __syncthreads();                                         // s_tab may be reused by the caller
-  return e0 + lo;
-}
-
-#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles per tile of k_ball_flags */
-__device__ unsigned long long g_ball_dbg[16];
-#define BALL_T0() const long long bt_t0 = clock64()
-#define BALL_END(path, na_) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long c_ = (unsigned long long)(clock64() - bt_t0); \
-  const int o_ = ((BT == 256) ? 0 : 4) + ((path) ? 2 : 0); atomicAdd(&g_ball_dbg[o_], 1ull); atomicAdd(&g_ball_dbg[o_ + 1], c_); \
-  atomicMax(&g_ball_dbg[8 + ((BT == 256) ? 0 : 1)], (c_ << 24) | (unsigned long long)min((na_), 0xFFFFFF)); atomicAdd(&g_ball_dbg[10 + ((BT == 256) ? 0 : 1)], (unsigned long long)(na_)); } } while (0)
-#else
-#define BALL_T0() do {} while (0)
-#define BALL_END(path, na_) do {} while (0)
-#endif
-
-template <int BT, int BH_MAX, int BH_HEADS, int QPT>
+template <int BT, int BH_MAX, int BH_HEADS>
 __global__ __launch_bounds__(BT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ base_a,
@@ -695,59 +656,45 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     uint8_t *__restrict__ flags, int masked) {
   __shared__ unsigned long long s_node[BH_MAX];
   __shared__ uint32_t s_head[BH_HEADS];
-  __shared__ double s_ax[BH_MAX], s_ay[BH_MAX], s_az[BH_MAX];   // the LiDAR points themselves: the exact test reads
-  __shared__ int s_pending;                      // LDS (a candidate cost a round trip to global memory each, one after
-                                                 // the other: 15 us per query, 140 000 cycles per tile)
-  constexpr int QT = BT * QPT;                   // queries per tile: QPT per thread, BT apart
+  __shared__ int s_pending;
   const int ntile = tile_off[S];
+  int t = blockIdx.x;
+  if (t >= ntile) return;
+  const int t_end = t + 1;
+  int s = find_segment(tile_off, S, t);
   const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
   const double Cq = C * (1.0 + 1e-6);
   const double OFF = 65536.0;                    // quantised coordinates are stored with this offset
-  // A workgroup's life is a chain of dependent memory round trips (tile -> segment -> its facts -> queries and LiDAR
-  // points -> table -> candidates); the chain is paid once per tile, so a tile carries QPT queries per thread.
-  // The grid is a fixed number of workgroups that stride over the tiles (their count is only known on the device).
-  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
-    __syncthreads();                             // the previous tile is done with the table
-    BALL_T0();
-    const int s = find_segment_wg<BT>(tile_off, S, t, (int *)s_head);   // (borrows 256 ints of s_head)
-    const int q0 = (t - tile_off[s]) * QT;
+  int hashed_s = -1;                             // segment whose LiDAR points are in the table
+  bool hash_ok = false;
+  uint32_t mask = 0;
+  for (; t < t_end; t++) {
+    while (tile_off[s + 1] <= t) s++;
+    const int q0 = (t - tile_off[s]) * BT;
     const int nq = cnt_b[s], na = cnt_a[s];
     const long long bq = base_b[s], ba = base_a[s];
+    const int q = q0 + threadIdx.x;
     // masked: flags hold the keep mask of a preceding filter that was not compacted;
     // a dropped point is not a query and stays dropped
-    bool valid[QPT];
-#pragma unroll
-    for (int u = 0; u < QPT; u++) {
-      const int q = q0 + u * BT + (int)threadIdx.x;
-      valid[u] = (q < nq) && (!masked || flags[bq + q]);
-    }
-    if (na == 0) {                       // my_loader.py:602: fuse skipped (uniform)
-#pragma unroll
-      for (int u = 0; u < QPT; u++)
-        if (valid[u]) flags[bq + q0 + u * BT + threadIdx.x] = 1;
+    const bool valid = (q < nq) && (!masked || flags[bq + q]);
+    if (na == 0) {                       // my_loader.py:602: fuse skipped
+      if (valid) flags[bq + q] = 1;
       continue;
     }
-    double x[QPT], y[QPT], z[QPT];
-#pragma unroll
-    for (int u = 0; u < QPT; u++) {
-      const long long o = bq + q0 + u * BT + threadIdx.x;
-      x[u] = 0.0; y[u] = 0.0; z[u] = 0.0;
-      if (valid[u]) { x[u] = px[o]; y[u] = py[o]; z[u] = pz[o]; }
-    }
-    bool hash_ok = false;
-    uint32_t mask = 0;
-    if (na <= BH_MAX) {                          // build the instance's table -- uniform per workgroup
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
+    if (na <= BH_MAX && hashed_s != s) {         // (re)build the table -- uniform per workgroup
       int slots = 256;
       while (slots < 2 * na) slots <<= 1;
       mask = (uint32_t)slots - 1u;
+      __syncthreads();                           // queries of the previous tile are done
       for (int i = threadIdx.x; i < slots; i += BT) s_head[i] = 0u;
       if (threadIdx.x == 0) s_pending = 0;
       __syncthreads();
       bool too_wide = false;
       for (int i = threadIdx.x; i < na; i += BT) {
-        const double axv = px[ba + i], ayv = py[ba + i], azv = pz[ba + i];
-        s_ax[i] = axv; s_ay[i] = ayv; s_az[i] = azv;
-        const double fx = floor(axv * inv) + OFF, fy = floor(ayv * inv) + OFF, fz = floor(azv * inv) + OFF;
+        const double fx = floor(px[ba + i] * inv) + OFF, fy = floor(py[ba + i] * inv) + OFF,
+                     fz = floor(pz[ba + i] * inv) + OFF;
         if (!(fx >= 64.0 && fy >= 64.0 && fz >= 64.0 && fx < 131000.0 && fy < 131000.0 && fz < 131000.0)) {
           too_wide = true;
           continue;
@@ -760,17 +707,15 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
       if (too_wide) s_pending = 1;
       __syncthreads();
       hash_ok = (s_pending == 0);
+      hashed_s = s;
     }
-    if (hash_ok) {
-#pragma unroll
-      for (int u = 0; u < QPT; u++) {
-        if (!valid[u]) continue;
-        const double qx_ = x[u], qy_ = y[u], qz_ = z[u];
-        bool found = false;
+    bool found = false;
+    if (na <= BH_MAX && hash_ok) {
+      if (valid) {
         // quantised range [q - C', q + C'] on each axis (NaN / far-away queries fail the range test)
-        const double lx = floor((qx_ - Cq) * inv) + OFF, hx = floor((qx_ + Cq) * inv) + OFF;
-        const double ly = floor((qy_ - Cq) * inv) + OFF, hy = floor((qy_ + Cq) * inv) + OFF;
-        const double lz = floor((qz_ - Cq) * inv) + OFF, hz = floor((qz_ + Cq) * inv) + OFF;
+        const double lx = floor((x - Cq) * inv) + OFF, hx = floor((x + Cq) * inv) + OFF;
+        const double ly = floor((y - Cq) * inv) + OFF, hy = floor((y + Cq) * inv) + OFF;
+        const double lz = floor((z - Cq) * inv) + OFF, hz = floor((z + Cq) * inv) + OFF;
         // stored coordinates lie in [64, 131000); a range that misses [0, 131071] entirely
         // (or is NaN / infinite) cannot contain one
         if (hx >= 0.0 && hy >= 0.0 && hz >= 0.0 && lx <= 131071.0 && ly <= 131071.0 && lz <= 131071.0) {
@@ -779,7 +724,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
           const int z0 = (int)fmax(lz, 0.0) >> 5, z1 = (int)fmin(hz, 131071.0) >> 5;
           // the query's own quantised position; a query outside the quantised range skips the
           // lower bound and tests every node of its chains exactly
-          const double fqx = floor(qx_ * inv) + OFF, fqy = floor(qy_ * inv) + OFF, fqz = floor(qz_ * inv) + OFF;
+          const double fqx = floor(x * inv) + OFF, fqy = floor(y * inv) + OFF, fqz = floor(z * inv) + OFF;
           const bool qin = fqx >= 0.0 && fqy >= 0.0 && fqz >= 0.0 && fqx <= 131071.0 && fqy <= 131071.0 && fqz <= 131071.0;
           const int qx = qin ? (int)fqx : 0, qy = qin ? (int)fqy : 0, qz = qin ? (int)fqz : 0;
           for (int uz = z0; uz <= z1 && !found; uz++)
@@ -797,7 +742,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                             ez_ = max(abs(az - qz) - 1, 0);
                   if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
                     const int j = (int)node - 1;
-                    const double ex = qx_ - s_ax[j], ey = qy_ - s_ay[j], ez = qz_ - s_az[j];
+                    const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
                     double d = ex * ex;
                     d += ey * ey;
                     d += ez * ez;
@@ -807,17 +752,14 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                 }
               }
         }
-        flags[bq + q0 + u * BT + threadIdx.x] = found ? 1 : 0;
+        flags[bq + q] = found ? 1 : 0;
       }
-      BALL_END(0, na);
       continue;
     }
     // brute force over LDS tiles (more LiDAR points than the table holds, or a huge extent)
-    constexpr int PTB = BH_MAX;                  // points per tile
-    double *sx = s_ax, *sy = s_ay, *sz = s_az;
-    bool found[QPT];
-#pragma unroll
-    for (int u = 0; u < QPT; u++) found[u] = false;
+    hashed_s = -1;                               // the tiles below overwrite the table
+    constexpr int PTB = BH_MAX / 3;              // points per tile: x | y | z in the nodes' LDS
+    double *sx = (double *)s_node, *sy = sx + PTB, *sz = sy + PTB;
     for (int j0 = 0; j0 < na; j0 += PTB) {
       const int m = min(PTB, na - j0);
       __syncthreads();
@@ -828,27 +770,20 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
         sz[i] = pz[ba + j0 + i];
       }
       __syncthreads();
-      bool open = false;
-#pragma unroll
-      for (int u = 0; u < QPT; u++) {
-        if (!valid[u] || found[u]) continue;
+      if (valid && !found) {
         for (int j = 0; j < m; j++) {
-          const double dx = x[u] - sx[j], dy = y[u] - sy[j], dz = z[u] - sz[j];
+          const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
           double d = dx * dx;
           d += dy * dy;
           d += dz * dz;
-          if (d < T) { found[u] = true; break; }
+          if (d < T) { found = true; break; }
         }
-        open = open || !found[u];
+        if (!found) s_pending = 1;
       }
-      if (open) s_pending = 1;
       __syncthreads();
       if (!s_pending) break;
     }
-#pragma unroll
-    for (int u = 0; u < QPT; u++)
-      if (valid[u]) flags[bq + q0 + u * BT + threadIdx.x] = found[u] ? 1 : 0;
-    BALL_END(1, na);
+    if (valid) flags[bq + q] = found ? 1 : 0;
   }
 }
 
@@ -1129,17 +1064,6 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   return DFU3D_OK;
 }
 
-#ifdef DFU3D_DBG_GRID_TIMING
-extern "C" int dfu3d_debug_ball_timing(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ball_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ball_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
-
 static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t *base_a,
                                     const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
                                     double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
@@ -1148,7 +1072,6 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   if (!px || !py || !pz || !base_a || !cnt_a || !base_b || !cnt_b || !tile_off || !flags)
     return DFU3D_EINVAL;
   if (S <= 0 || pool_cap <= 0) return DFU3D_EINVAL;
-  if (S > 65535) return DFU3D_ERANGE;                      // two-level tile search: 256 x 256 entries
   if (!(C > 0.0) || !(C < 1e150)) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // The reference tests sqrt(d2) < C (my_loader.py:490-493).  sqrt is monotone
@@ -1160,18 +1083,17 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   // small build: instances with at most BH_MAX_SMALL LiDAR points (and those with none: the fuse is skipped there);
   // big build: the others.  tile_off: two lists of S+1 entries.
   int32_t *tile_small = tile_off, *tile_big = tile_off + S + 1;
-  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, -1, BH_MAX_SMALL, tile_small, BT_SMALL * BQ_SMALL);
+  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, -1, BH_MAX_SMALL, tile_small, BT_SMALL);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, BH_MAX_SMALL, 0x7FFFFFFF, tile_big, BT_BIG * BQ_BIG);
+  hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, BH_MAX_SMALL, 0x7FFFFFFF, tile_big, BT_BIG);
   DFU3D_LAUNCH_CHECK();
-  const int64_t t_small = pool_cap / (BT_SMALL * BQ_SMALL) + S + 1, t_big = pool_cap / (BT_BIG * BQ_BIG) + S + 1;
-  const int g_small = (int)(t_small < 16384 ? t_small : 16384);
-  hipLaunchKernelGGL((k_ball_flags<BT_SMALL, BH_MAX_SMALL, BH_HEADS_SMALL, BQ_SMALL>), dim3(g_small), dim3(BT_SMALL), 0, st, px, py, pz,
+  const int g_small = (int)((pool_cap + BT_SMALL - 1) / BT_SMALL + S);
+  hipLaunchKernelGGL((k_ball_flags<BT_SMALL, BH_MAX_SMALL, BH_HEADS_SMALL>), dim3(g_small), dim3(BT_SMALL), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_small, flags, masked);
   DFU3D_LAUNCH_CHECK();
-  const int g_big = (int)(t_big < 4096 ? t_big : 4096);
-  hipLaunchKernelGGL((k_ball_flags<BT_BIG, BH_MAX_BIG, BH_HEADS_BIG, BQ_BIG>), dim3(g_big), dim3(BT_BIG), 0, st, px, py, pz,
+  const int g_big = (int)((pool_cap + BT_BIG - 1) / BT_BIG + S);
+  hipLaunchKernelGGL((k_ball_flags<BT_BIG, BH_MAX_BIG, BH_HEADS_BIG>), dim3(g_big), dim3(BT_BIG), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_big, flags, masked);
   DFU3D_LAUNCH_CHECK();

@@ -17,28 +17,19 @@ del scenes
 eng = PseudoBoxEngine(params, H, W, M, N_PTS, views_per_chunk=frames * CAMS, dense=True, cap_vox=1 << 18,
                       pool_per_view=1 << 17, device=dev, lanes=1, chain=True)
 L = _lib.lib()
-L.dfu3d_debug_grid_timing.restype = ctypes.c_int
 out = (ctypes.c_ulonglong * 16)()
 eng.run(batch); torch.cuda.synchronize()
 L.dfu3d_debug_grid_timing(out, 1)
-L.dfu3d_debug_ball_timing(out, 1)
 L.dfu3d_debug_grid_max(out, 1)
 eng.run(batch); torch.cuda.synchronize()
 L.dfu3d_debug_grid_timing(out, 1)
 v = list(out)
-L.dfu3d_debug_ball_timing(out, 1)
-b = list(out)
+L.dfu3d_debug_grid_max(out, 1)
+mx = list(out)
 names = ["geometry", "sort", "link touching", "link gap", "labels"]
 wg = max(v[8], 1)
 print("workgroups", v[8], "points", v[9], "cells", v[10], "wave-cooperative pair tests", v[11])
 for i, nm in enumerate(names):
-    print("%-14s %10.1f cycles/WG  (%.1f us at 2.4 GHz... clock64 ticks at 100 MHz => %.1f us)" % (nm, v[i] / wg, v[i] / wg / 2400.0, v[i] / wg / 100.0))
-print("slowest workgroup: %d cycles, n = %d;   largest instance: n = %d, %d cycles" % (v[12] >> 24, v[12] & 0xFFFFFF, v[13] >> 32, v[13] & 0xFFFFFFFF))
-for nm, o in (("small hashed", 0), ("small brute", 2), ("big hashed", 4), ("big brute", 6)):
-    n = max(b[o], 1)
-    print("ball %-13s tiles %7d  cycles/tile %10.1f" % (nm, b[o], b[o + 1] / n))
-print("ball slowest tile small: %d cycles (na %d); big: %d cycles (na %d); sum na small %d big %d" % (b[8] >> 24, b[8] & 0xFFFFFF, b[9] >> 24, b[9] & 0xFFFFFF, b[10], b[11]))
-L.dfu3d_debug_grid_max(out, 1)
-mx = list(out)
-for i, nm in enumerate(names):
-    print("max %-14s %9d cycles (n = %d)" % (nm, mx[i] >> 24, mx[i] & 0xFFFFFF))
+    print("%-14s %10.1f cycles/WG   max %9d cycles (n = %d)" % (nm, v[i] / wg, mx[i] >> 24, mx[i] & 0xFFFFFF))
+print("slowest workgroup: %d cycles, n = %d;   largest instance: n = %d, %d cycles"
+      % (v[12] >> 24, v[12] & 0xFFFFFF, v[13] >> 32, v[13] & 0xFFFFFFFF))
