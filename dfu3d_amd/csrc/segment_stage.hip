@@ -34,13 +34,15 @@ __device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
 
 
 // ---------------------------------------------------------------- build
-// A view's items are cut into chunks of SEG_CH; every (view, chunk) is one workgroup in the counting and in
-// the writing pass, and inside a chunk every WAVE owns SEG_WI consecutive items.  Lane j of a wave keeps the
-// wave's running count of instance j in a register, so neither pass has a barrier or an LDS round trip inside
-// its item loop (the first formulation stepped a whole workgroup through 1024 items at a time with two barriers
-// per step and was bound by the latency of that chain, not by its 0.2 GB of traffic).
-constexpr int SEG_WAVES = 16, SEG_WI = 512, SEG_STEPS = SEG_WI / 64;
-constexpr int SEG_CH = SEG_WAVES * SEG_WI;          // 8192 items per workgroup
+// A view's items are cut into chunks of SEG_CH; every (view, chunk) is one workgroup in the counting and in the
+// writing pass.  The workgroup walks its chunk in steps of SEG_SUB items, and inside a step every WAVE owns SEG_WI
+// consecutive items: lane j of a wave keeps the wave's count of instance j in a register, so a step costs two
+// barriers per 8192 items.  History: a workgroup per view stepping through 1024 items at a time with two barriers
+// per step was bound by the latency of that chain (0.70 ms for 0.2 GB); a workgroup per 8192 items made 12 000
+// workgroups pay the prologue (item count -> list sizes -> bases -> earlier chunks) and was slower still (1.05 ms).
+constexpr int SEG_WAVES = 16, SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
+constexpr int SEG_SUB = SEG_WAVES * SEG_WI;         // 4096 items per step of a workgroup (4 per lane: 64 VGPRs, two workgroups per CU)
+constexpr int SEG_CH = 8 * SEG_SUB;                 // 32768 items per workgroup
 static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
 
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
@@ -72,18 +74,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void k_seg_count(const uint32_t *__
   __shared__ int s_c[DFU3D_MAX_INST];
   const int v = blockIdx.y, ch = blockIdx.x;
   const int lane = lane_id();
-  const int w0 = ch * SEG_CH + (int)(threadIdx.x >> 6) * SEG_WI;
-  // every load of the workgroup is requested before the first is looked at (one memory round trip, not a chain):
-  // the bit words are read up to the capacity and cut to the view's item count afterwards
-  const int n_raw = n_item[v];
-  const int t_cap = min(cap_item, (ch + 1) * SEG_CH);
-  uint32_t b[SEG_STEPS], wany[SEG_STEPS];
-#pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++) {
-    const int t = w0 + k * 64 + lane;
-    b[k] = (t < t_cap) ? bits[(size_t)v * cap_item + t] : 0u;
-  }
-  const int n = min(n_raw, t_cap);
+  const int n = min(min(n_item[v], cap_item), (ch + 1) * SEG_CH);
   int *cc = chunk_cnt + ((size_t)v * gridDim.x + ch) * DFU3D_MAX_INST;
   if (ch * SEG_CH >= n) {                          // (uniform) nothing in this chunk
     if (threadIdx.x < DFU3D_MAX_INST) cc[threadIdx.x] = 0;
@@ -91,10 +82,17 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void k_seg_count(const uint32_t *__
   }
   if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
   __syncthreads();
+  int mine = 0;
+  for (int sub = ch * SEG_CH; sub < n; sub += SEG_SUB) {            // uniform
+    const int w0 = sub + (int)(threadIdx.x >> 6) * SEG_WI;
+    uint32_t b[SEG_STEPS], wany[SEG_STEPS];
 #pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++)
-    if (w0 + k * 64 + lane >= n) b[k] = 0u;
-  const int mine = wave_instance_counts(b, wany);
+    for (int k = 0; k < SEG_STEPS; k++) {
+      const int t = w0 + k * 64 + lane;
+      b[k] = (t < n) ? bits[(size_t)v * cap_item + t] : 0u;
+    }
+    mine += wave_instance_counts(b, wany);
+  }
   if (lane < DFU3D_MAX_INST && mine) atomicAdd(&s_c[lane], mine);
   __syncthreads();
   if (threadIdx.x < DFU3D_MAX_INST) {
@@ -160,9 +158,15 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt
 }
 
 // One workgroup per (view, chunk) writes its part of the ordered lists of all the view's instances: a list starts
-// where the earlier chunks of the view end (their counts), a wave's part of it where the earlier waves of the chunk
-// end (one barrier), and inside the wave ballots give the order.  The bit words stay in registers between the
-// counting and the writing sweep; the coordinates of all SEG_STEPS steps are requested before the first is used.
+// where the earlier chunks of the view end (their counts), a wave's part of it where the earlier waves of the step
+// end, and inside the wave ballots give the order.  The bit words stay in registers between the counting and the
+// writing sweep of a step; the coordinates of all SEG_STEPS sub-steps are requested before the first is used.
+#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of thread 0 per phase of k_seg_write, summed over workgroups */
+__device__ unsigned long long g_seg_dbg[16];
+#define SEG_T(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_seg_dbg[k], (unsigned long long)(t_ - sg_t)); sg_t = t_; } } while (0)
+#else
+#define SEG_T(k) do {} while (0)
+#endif
 constexpr int SWT = SEG_WAVES * 64;
 __global__ __launch_bounds__(SWT) void k_seg_write(
     const uint32_t *__restrict__ bits, const double *__restrict__ ix,
@@ -171,14 +175,15 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
     const long long *__restrict__ base, const int *__restrict__ cnt, const int *__restrict__ chunk_cnt,
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off) {
-  __shared__ int s_wc[SEG_WAVES][DFU3D_MAX_INST];     // per wave: items of instance j in this chunk
+  __shared__ int s_wc[SEG_WAVES][DFU3D_MAX_INST];     // per wave: items of instance j in this step
   __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items of the earlier chunks
   const int v = blockIdx.y, ch = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int w0 = ch * SEG_CH + wave * SEG_WI;
-  // every first-level load is requested before any is looked at: one memory round trip instead of a chain
-  // (item count -> list sizes -> bases -> earlier chunks -> bit words); the bit words are read up to the
-  // capacity and cut to the view's item count afterwards
+#ifdef DFU3D_DBG_GRID_TIMING
+  long long sg_t = clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[8], 1ull);
+#endif
+  // the first-level loads are requested together (one memory round trip instead of a chain)
   const int n_raw = n_item[v];
   const bool lj = lane < max_inst;                     // lane j < max_inst: the facts of instance j
   const int cj = lj ? cnt[v * max_inst + lane] : 0;    // (0 also for the lists that did not fit the pool)
@@ -188,17 +193,13 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
   const int jj = threadIdx.x & (DFU3D_MAX_INST - 1), c_first = threadIdx.x / DFU3D_MAX_INST;
   int q_first = 0;                                     // chunks 0..31 in one go, the rest (if any) in the loop below
   if (c_first < ch) q_first = cc[(size_t)c_first * DFU3D_MAX_INST + jj];
-  const int t_cap = min(cap_item, (ch + 1) * SEG_CH);
-  uint32_t b[SEG_STEPS], wany[SEG_STEPS];
-#pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++) {
-    const int t = w0 + k * 64 + lane;
-    b[k] = (t < t_cap) ? bits[(size_t)v * cap_item + t] : 0u;
-  }
-  const int n = min(n_raw, t_cap);
-  if (ch * SEG_CH >= n) return;
+  const int n = min(min(n_raw, cap_item), (ch + 1) * SEG_CH);
+  if (ch * SEG_CH >= n) { SEG_T(0); return; }
   const uint32_t live = (uint32_t)__ballot(cj > 0);   // instances of this view with a non-empty list
   if (live == 0u) return;
+#ifdef DFU3D_DBG_GRID_TIMING
+  if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[9], 1ull);
+#endif
   const uint32_t sw = (lj && pq) ? shadow_word(seg_off + v * max_inst + lane, rj) : 0u;
   if (threadIdx.x < DFU3D_MAX_INST) s_run[threadIdx.x] = 0;
   __syncthreads();
@@ -207,43 +208,78 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
     const int q = cc[(size_t)c * DFU3D_MAX_INST + jj];
     if (q) atomicAdd(&s_run[jj], q);
   }
-#pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++) b[k] = (w0 + k * 64 + lane < n) ? (b[k] & live) : 0u;
-  double x[SEG_STEPS], y[SEG_STEPS], z[SEG_STEPS];
-#pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++) {
-    const size_t o = (size_t)v * cap_item + w0 + k * 64 + lane;
-    x[k] = 0.0; y[k] = 0.0; z[k] = 0.0;
-    if (b[k]) { x[k] = ix[o]; y[k] = iy[o]; z[k] = iz[o]; }
-  }
-  const int mine = wave_instance_counts(b, wany);
-  if (lane < DFU3D_MAX_INST) s_wc[wave][lane] = mine;
   __syncthreads();
-  if (lane < DFU3D_MAX_INST) {
-    int before = s_run[lane];
-    for (int ww = 0; ww < wave; ww++) before += s_wc[ww][lane];
-    off += before;
-  }
+  if (lane < DFU3D_MAX_INST) off += s_run[lane];       // every wave: where the chunk's part of list `lane` starts
+  SEG_T(1);
+  for (int sub = ch * SEG_CH; sub < n; sub += SEG_SUB) {            // uniform
+    const int w0 = sub + wave * SEG_WI;
+    uint32_t b[SEG_STEPS], wany[SEG_STEPS];
 #pragma unroll
-  for (int k = 0; k < SEG_STEPS; k++) {
-    for (uint32_t w = wany[k]; w; w &= w - 1u) {       // uniform per wave
-      const int j = __ffs((int)w) - 1;
-      const bool has = (b[k] >> j) & 1u;
-      const unsigned long long m = __ballot(has);
-      const long long start = __shfl(off, j, 64);
-      const uint32_t swj = (uint32_t)__shfl((int)sw, j, 64);
-      if (has) {
-        const long long d = start + __popcll(m & ((1ull << lane) - 1ull));
-        px[d] = x[k];
-        py[d] = y[k];
-        pz[d] = z[k];
-        if (pq)                                        // float32 shadow for the radius filter
-          pq[d] = make_float4((float)x[k], (float)y[k], (float)z[k], __uint_as_float(swj));
-      }
-      if (lane == j) off += __popcll(m);
+    for (int k = 0; k < SEG_STEPS; k++) {
+      const int t = w0 + k * 64 + lane;
+      b[k] = (t < n) ? (bits[(size_t)v * cap_item + t] & live) : 0u;
     }
+    double x[SEG_STEPS], y[SEG_STEPS], z[SEG_STEPS];
+#pragma unroll
+    for (int k = 0; k < SEG_STEPS; k++) {
+      const size_t o = (size_t)v * cap_item + w0 + k * 64 + lane;
+      x[k] = 0.0; y[k] = 0.0; z[k] = 0.0;
+      if (b[k]) { x[k] = ix[o]; y[k] = iy[o]; z[k] = iz[o]; }
+    }
+    const int mine = wave_instance_counts(b, wany);
+    SEG_T(2);
+#ifdef DFU3D_DBG_GRID_TIMING
+    if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[10], 1ull);
+#endif
+    if (sub > ch * SEG_CH) __syncthreads();            // the previous step's s_wc has been read by every wave
+    if (lane < DFU3D_MAX_INST) s_wc[wave][lane] = mine;
+    __syncthreads();
+    long long woff = off;                              // lane j: where THIS wave's part of list j starts in this step
+    if (lane < DFU3D_MAX_INST) {
+      int before = 0, total = 0;
+#pragma unroll
+      for (int ww = 0; ww < SEG_WAVES; ww++) {
+        const int c = s_wc[ww][lane];
+        before += (ww < wave) ? c : 0;
+        total += c;
+      }
+      woff += before;
+      off += total;
+    }
+    SEG_T(3);
+#pragma unroll
+    for (int k = 0; k < SEG_STEPS; k++) {
+      for (uint32_t w = wany[k]; w; w &= w - 1u) {     // uniform per wave
+        const int j = __ffs((int)w) - 1;
+        const bool has = (b[k] >> j) & 1u;
+        const unsigned long long m = __ballot(has);
+        const long long start = __shfl(woff, j, 64);
+        const uint32_t swj = (uint32_t)__shfl((int)sw, j, 64);
+        if (has) {
+          const long long d = start + __popcll(m & ((1ull << lane) - 1ull));
+          px[d] = x[k];
+          py[d] = y[k];
+          pz[d] = z[k];
+          if (pq)                                      // float32 shadow for the radius filter
+            pq[d] = make_float4((float)x[k], (float)y[k], (float)z[k], __uint_as_float(swj));
+        }
+        if (lane == j) woff += __popcll(m);
+      }
+    }
+    SEG_T(4);
   }
 }
+
+#ifdef DFU3D_DBG_GRID_TIMING
+extern "C" int dfu3d_debug_seg_timing(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seg_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+#endif
 
 // ---------------------------------------------------------------- tiles
 __global__ __launch_bounds__(1024) void k_tile_scan(int S, const int *__restrict__ cnt,
