@@ -40,9 +40,9 @@ __device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
 // barriers per 8192 items.  History: a workgroup per view stepping through 1024 items at a time with two barriers
 // per step was bound by the latency of that chain (0.70 ms for 0.2 GB); a workgroup per 8192 items made 12 000
 // workgroups pay the prologue (item count -> list sizes -> bases -> earlier chunks) and was slower still (1.05 ms).
-constexpr int SEG_WAVES = 16, SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
-constexpr int SEG_SUB = SEG_WAVES * SEG_WI;         // 4096 items per step of a workgroup (4 per lane: 64 VGPRs, two workgroups per CU)
-constexpr int SEG_CH = 8 * SEG_SUB;                 // 32768 items per workgroup
+constexpr int SEG_WAVES = 8, SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
+constexpr int SEG_SUB = SEG_WAVES * SEG_WI;         // 2048 items per step of a workgroup (4 per lane: 62 VGPRs, four workgroups per CU)
+constexpr int SEG_CH = 16 * SEG_SUB;                // 32768 items per workgroup
 static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
 
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
 // dst_after_base != nullptr, directly behind another segment
 // (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
 constexpr int CPT = 1024;   // threads per compaction workgroup
-constexpr int CPE = 4;      // consecutive elements per thread
+constexpr int CPE = 2;      // consecutive elements per thread (4 needed 76 VGPRs: one 1024-thread workgroup per CU)
 __global__ __launch_bounds__(CPT) void k_seg_compact(
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
