@@ -247,10 +247,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--chunk-frames", type=int, default=0, help="frames per kernel-launch chunk (0 = all frames of the step)")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="concurrent HIP streams, one chunk each (default 1: every kernel has the GPU to itself, so the "
-                         "HIP-event durations of the kernel table equal what rocprofv3 reports for the same command)")
+    ap.add_argument("--chunk-frames", type=int, default=16, help="frames per kernel-launch chunk (0 = all frames of the step)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="concurrent HIP streams, one chunk each.  Default: 4 streams x 16-frame chunks, the engine's throughput "
+                         "configuration (stages of different chunks overlap: +18 %% over one stream).  The kernel table and the "
+                         "roofline block never come from these contended launches: they are timed in extra single-stream "
+                         "passes after the timed region (see --single-stream)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="one stream, one chunk of all frames, in the timed region too: every kernel has the GPU to itself, so "
+                         "rocprofv3 --kernel-trace of THIS command reports the durations of the kernel table "
+                         "(profiles/rNN_kernel_stats_bench_single_stream.csv)")
     ap.add_argument("--sparse", action="store_true", help="depth off (hazard H20 extension)")
     ap.add_argument("--byte-masks", action="store_true",
                     help="instance masks as uint8 planes (V,M,H,W) -- the reference's np.uint8(mask) -- instead of one "
@@ -302,7 +308,9 @@ def main():
     dense = not args.sparse
     params = Params()
     frames = args.frames
-    chunk_frames = args.chunk_frames or frames
+    if args.single_stream:
+        args.lanes, args.chunk_frames = 1, 0
+    chunk_frames = min(args.chunk_frames or frames, frames)
     if frames % chunk_frames:
         raise SystemExit("--frames must be a multiple of --chunk-frames")
 
@@ -443,7 +451,10 @@ def main():
                                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
                                    "frac_of_measured_copy": round(dom["achieved_GBs"] / copy_rate, 5),
                                    "avg_ms": dom["avg_ms"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
-                                   "traffic": traffic, "traffic_source": tsrc}
+                                   "traffic": traffic, "traffic_source": tsrc,
+                                   "timing": "single-stream passes after the timed region (%d views per launch); the same "
+                                             "durations are in rocprofv3's summary of `python bench.py --single-stream` "
+                                             "(profiles/rNN_kernel_stats_bench_single_stream.csv)" % V1}
             rf = [r for r in table if r["stage"] in RF_STAGE]
             if rf:
                 ms_stage = sum(r["avg_ms"] for r in rf)

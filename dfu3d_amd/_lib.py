@@ -102,6 +102,7 @@ SIGNATURES = {
     "dfu3d_chain_workspace_bytes": (c_i64, [ctypes.POINTER(ChainCfg)]),
     "dfu3d_chain_workspace_init": (c_i32, [ctypes.POINTER(ChainCfg), _P, _P]),
     "dfu3d_pseudo_boxes": (c_i32, [ctypes.POINTER(ChainCfg)] + [_P] * 20),
+    "dfu3d_la_sampling": (c_i32, [_P, c_i32, _P, c_i32, ctypes.c_float, ctypes.c_float, _P, _P, _P, c_i64, _P]),
     "dfu3d_selftest_classify": (c_i32, [_P, c_i32, c_i32, _P, c_i32, c_i64, ctypes.c_uint64, c_f64, c_f64, _P, _P, _P]),
     "dfu3d_selftest_backproject": (c_i32, [_P, c_i32, c_i32, c_i64, ctypes.c_uint64, c_f64, c_f64, _P, _P, _P]),
     "dfu3d_lshape_fit_ws_doubles": (c_i64, [c_i64, c_i32]),

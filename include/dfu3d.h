@@ -327,6 +327,17 @@ int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
 int dfu3d_nms_normal_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
                          int64_t *keep, int32_t *num_keep, void *stream);
 
+/* ---- f-4: la_sampling of the ground-truth sampling augmentor (pcdet/datasets/augmentor/database_sampler_virtual.py:319-351)
+ * A batch of B objects: float32 rows `points` (n_points, n_cols >= 3; x y z first), object b owns rows
+ * [obj_off[b], obj_off[b+1]).  Every object is binned by (theta // vert_res, fan // hor_res) of its points' spherical
+ * coordinates (float32, NumPy's operation order and its float floor division), every bin keeps the point with the
+ * smallest theta (first on ties), bins in first-seen order; an object that would keep fewer than 5 rows is copied
+ * unchanged.  out: same shape as points (not the same buffer); object b's rows start at obj_off[b], out_cnt[b] of them.
+ * scratch: 24 bytes per point, 8-byte aligned. */
+int dfu3d_la_sampling(const float *points, int32_t n_cols, const int64_t *obj_off, int32_t B,
+                      float vert_res, float hor_res, float *out, int32_t *out_cnt, void *scratch,
+                      int64_t n_points, void *stream);
+
 /* ---- self test of the two-tier bin classification ---------------------------
  * dfu3d_backproject_bin decides a pixel's spherical bin in float32 when every float32 estimate is farther from
  * every boundary involved than a bound on its error, and in fp64 otherwise.  This entry point runs both
