@@ -583,8 +583,35 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
         const int k = __ffsll((long long)m) - 1;
         m &= m - 1ull;
         const long long c0 = (r0 + k) << (BOX_SHIFT - 6);
-        for (int u = 0; u < (1 << (BOX_SHIFT - 6)) && cnt <= nb; u++)
-          if (c0 + u != c_own) test_chunk(c0 + u);
+        // the eight chunks of the range are requested together (one memory round trip, not eight in a row: a query's
+        // candidate ranges were a chain of dependent loads, and the kernel's 0.24 ms was that chain)
+        constexpr int RC = 1 << (BOX_SHIFT - 6);
+        float4 o[RC];
+        bool in[RC];
+#pragma unroll
+        for (int u = 0; u < RC; u++) {
+          const long long g = ((c0 + u) << 6) + lane;
+          in[u] = (g >= base) && (g < end) && (c0 + u != c_own);
+          o[u] = in[u] ? pq[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < RC; u++) {
+          bool hit = false;
+          if (in[u]) {
+            const float dx = qf.x - o[u].x, dy = qf.y - o[u].y, dz = qf.z - o[u].z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            hit = d2 < lo2;
+            if (!hit && !(d2 > hi2)) {                 // too close to call in float32
+              const long long g = ((c0 + u) << 6) + lane;
+              const double ex = x - px[g], ey = y - py[g], ez = z - pz[g];
+              double d = ex * ex;
+              d += ey * ey;
+              d += ez * ez;
+              hit = d < r2;
+            }
+          }
+          cnt += __popcll(__ballot(hit));
+        }
       }
     }
     if (lane == 0) flags[i] = (cnt > nb) ? 1 : 0;
@@ -1054,7 +1081,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
-    hipLaunchKernelGGL(k_radius_resolve, dim3(2048), dim3(256), 0, st, px, py, pz, pq, boxes,
+    hipLaunchKernelGGL(k_radius_resolve, dim3(4096), dim3(256), 0, st, px, py, pz, pq, boxes,
                        (const long long *)seg_base, seg_cnt, radius, nb_points, S, (long long)pool_cap, flags, queue);
     DFU3D_LAUNCH_CHECK();
   }

@@ -103,6 +103,72 @@ def test_fp32_backprojection_bound_holds_on_this_device(st):
                 assert 0.0 < q < 0.5, (H, W, yaw, d_lo, q)
 
 
+# ------------------------------------------------------------------ a9
+def test_segments_build_orders_every_list_across_chunks_and_waves(st):
+    """Per-view bit sets -> per-instance ordered lists (my_loader.py:547-565 semantics: an item belongs to every instance
+    whose bit it carries, lists keep the item order, LiDAR list directly followed by the pseudo list).  Item counts sit
+    on the kernel's granularities (64-item ballots, 256-item wave ranges, 2048-item steps, 32768-item chunks) and next
+    to them; the float32 shadow and the joint 2S table are checked too."""
+    rng = np.random.default_rng(33)
+    M = 6
+    a_ns = [0, 1, 63, 64, 65, 255, 2049, 5000]
+    b_ns = [70001, 32768, 32769, 0, 2048, 65536, 40000, 1]
+    V = len(a_ns)
+    a_cap, b_cap = 5120, 70016
+    def items(ns, cap):
+        bits = np.zeros((V, cap), np.int32)
+        xyz = rng.normal(0, 30, (V, cap, 3))
+        for v, n in enumerate(ns):
+            b = np.zeros(n, np.int64)
+            for j in range(M):
+                b |= (rng.random(n) < (0.02 if j else 0.6)).astype(np.int64) << j
+            b[rng.random(n) < 0.3] = 0
+            bits[v, :n] = b.astype(np.int32)
+            bits[v, n:] = 0x3F                                     # stale words beyond the count must be ignored
+        return bits, xyz
+    abits, axyz = items(a_ns, a_cap)
+    bbits, bxyz = items(b_ns, b_cap)
+    S = V * M
+    total = sum(int(((abits[v, :a_ns[v]] >> j) & 1).sum() + ((bbits[v, :b_ns[v]] >> j) & 1).sum()) for v in range(V) for j in range(M))
+    cap = total + 64
+    dev = DEV
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a)).to(dev) if dt is None else torch.as_tensor(np.ascontiguousarray(a)).to(dev).to(dt)
+    px, py, pz = (torch.full((cap,), 7.0, dtype=torch.float64, device=dev) for _ in range(3))
+    base_a, base_b = torch.zeros(S, dtype=torch.int64, device=dev), torch.zeros(S, dtype=torch.int64, device=dev)
+    cnt_a, cnt_b = torch.zeros(S, dtype=torch.int32, device=dev), torch.zeros(S, dtype=torch.int32, device=dev)
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    rad_a = t(rng.uniform(0.3, 3.0, S)); rad_b = t(rng.uniform(0.3, 3.0, S))
+    shadow = torch.zeros(st.shadow_floats(cap), dtype=torch.float32, device=dev)
+    base_ab = torch.zeros(2 * S, dtype=torch.int64, device=dev)
+    cnt_ab = torch.zeros(2 * S, dtype=torch.int32, device=dev)
+    rad_ab = torch.zeros(2 * S, dtype=torch.float64, device=dev)
+    st.segments_build(t(abits.reshape(-1)), t(axyz[..., 0].reshape(-1)), t(axyz[..., 1].reshape(-1)), t(axyz[..., 2].reshape(-1)),
+                      t(np.array(a_ns, np.int32)), a_cap,
+                      t(bbits.reshape(-1)), t(bxyz[..., 0].reshape(-1)), t(bxyz[..., 1].reshape(-1)), t(bxyz[..., 2].reshape(-1)),
+                      t(np.array(b_ns, np.int32)), b_cap, V, M, cap, cursor, px, py, pz, base_a, cnt_a, base_b, cnt_b, status,
+                      rad_a=rad_a, rad_b=rad_b, shadow=shadow, base_ab=base_ab, cnt_ab=cnt_ab, rad_ab=rad_ab)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and int(cursor.item()) == total
+    P = torch.stack([px, py, pz], 1).cpu().numpy()
+    sh = shadow[:4 * cap].view(-1, 4).cpu().numpy()
+    ba, ca, bb, cb = base_a.cpu().numpy(), cnt_a.cpu().numpy(), base_b.cpu().numpy(), cnt_b.cpu().numpy()
+    assert np.array_equal(base_ab.cpu().numpy(), np.concatenate([ba, bb])) and np.array_equal(cnt_ab.cpu().numpy(), np.concatenate([ca, cb]))
+    run = 0
+    for v in range(V):
+        for j in range(M):
+            s = v * M + j
+            ea = axyz[v, :a_ns[v]][((abits[v, :a_ns[v]] >> j) & 1) == 1]
+            eb = bxyz[v, :b_ns[v]][((bbits[v, :b_ns[v]] >> j) & 1) == 1]
+            assert (ca[s], cb[s]) == (len(ea), len(eb)), (v, j)
+            assert ba[s] == run and bb[s] == run + len(ea)          # dense pool, A directly followed by B
+            assert np.array_equal(P[ba[s]:ba[s] + ca[s]], ea) and np.array_equal(P[bb[s]:bb[s] + cb[s]], eb), (v, j)
+            assert np.array_equal(sh[bb[s]:bb[s] + cb[s], :3], eb.astype(np.float32))
+            seg_word = sh[bb[s]:bb[s] + cb[s], 3].view(np.uint32) >> 16
+            assert (seg_word == S + s).all()
+            run += len(ea) + len(eb)
+
+
 # ------------------------------------------------------------------ a10
 def test_radius_filter_matches_oracle(st):
     rng = np.random.default_rng(10)
