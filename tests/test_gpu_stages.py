@@ -371,6 +371,14 @@ def _cluster_cases(rng):
     cases.append(two[rng.permutation(len(two))])                 # two dense blobs, interleaved
     cases.append(np.concatenate([rng.normal(0, 2.0, (29000, 2)), rng.uniform(-200, 200, (600, 2))]))  # 16-bit LDS parents
     cases.append(np.concatenate([rng.normal(0, 3.0, (61000, 2)), rng.uniform(-300, 300, (700, 2))]))  # parents in global memory
+    # two dense bands whose closest pair is one bridge at a gap around R (3.0 + 0.001 |p| = 3.0104 there): every cell pair
+    # across the gap passes the box test and must be decided point by point (strip pruning), on either side of R
+    for gap in (3.0, 3.0100, 3.01040, 3.01044, 3.01048, 3.0106, 3.02, 3.3):
+        a = np.stack([rng.uniform(0, 20, 3000), rng.uniform(-0.5, -0.02, 3000)], 1)
+        b = np.stack([rng.uniform(0, 20, 3000), gap + rng.uniform(0.02, 0.5, 3000)], 1)
+        bridge = np.array([[10.0, 0.0], [10.0, gap]])
+        pts = np.concatenate([a, b, bridge])
+        cases.append(pts[rng.permutation(len(pts))])
     return cases
 
 
