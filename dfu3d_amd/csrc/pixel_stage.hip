@@ -685,7 +685,7 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
 
 // ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
 constexpr int VXB = 256;
-constexpr int VX_PIECES = 64;                 // 64-pixel row pieces per workgroup = 4096 pixels
+constexpr int VX_PIECES = 64;                 // rows of a workgroup's 64-pixel-wide tile = 4096 pixels
 __global__ __launch_bounds__(VXB) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
     const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
@@ -693,19 +693,26 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
     uint32_t *__restrict__ status) {
   __shared__ uint32_t s_pix[VX_PIECES * 64];
+  __shared__ int s_rank[VX_PIECES * 64];
   __shared__ int s_w[VXB / 64];
   const int v = blockIdx.y;
-  const int j0 = blockIdx.x * VX_PIECES;
-  if (j0 >= R.NJ) return;
-  // every thread takes a quarter (16 pixels) of a row piece; the list comes out in raster order
-  const int piece = j0 + (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
+  // A workgroup takes a 64-pixel-wide, VX_PIECES-row-high tile of the image, not a run of VX_PIECES row pieces of one
+  // row: the bins of a table line (8 consecutive phi bins) have their first pixels on two or three neighbouring
+  // rows, and with row strips those rows belonged to workgroups on different XCDs, each of which fetched (and
+  // partially rewrote) the line for itself -- 165 B fetched per voxel where the sectors touched add up to 60.
+  // The voxel's place in first-seen (raster) order does not depend on who handles it: prefix of its row piece +
+  // set bits before it in the piece.
+  const int tx = blockIdx.x % R.tiles_x, ty = blockIdx.x / R.tiles_x;
+  const int H = R.NJ / R.tiles_x;
+  // every thread takes a quarter (16 pixels) of a row piece
+  const int y = ty * VX_PIECES + (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
   uint32_t m16 = 0u;
-  int y = 0, x0 = 0;
-  if (piece < R.NJ) {
-    y = piece / R.tiles_x;
-    const int tx = piece - y * R.tiles_x;
-    x0 = tx * 64 + quarter * 16;
-    m16 = (uint32_t)(row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx) >> (16 * quarter)) & 0xFFFFu;
+  int x0 = tx * 64 + quarter * 16, rank_q = 0;
+  if (y < H) {
+    const unsigned long long word = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
+    m16 = (uint32_t)(word >> (16 * quarter)) & 0xFFFFu;
+    if (m16) rank_q = (int)R.wpre[(size_t)v * R.NJ + (size_t)y * R.tiles_x + tx] +
+                      __popcll(word & ((1ull << (16 * quarter)) - 1ull));
   }
   int tot;
   int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);
@@ -713,18 +720,18 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   while (m16) {
     const int bpos = __ffs((int)m16) - 1;
     m16 &= m16 - 1u;
-    s_pix[off++] = (uint32_t)(y * W + x0 + bpos);
+    s_pix[off] = (uint32_t)(y * W + x0 + bpos);
+    s_rank[off++] = rank_q++;
   }
   __syncthreads();
-  const int rank0 = (int)R.wpre[(size_t)v * R.NJ + j0];
   const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
                                 key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
   const FastCal fc = fastcal[v];
   const KeyCol kcol = load_key_col(calib + v, key_axis);
   bool rerr = false;
   for (int idx = threadIdx.x; idx < tot; idx += VXB) {
-    const int k = rank0 + idx;
-    if (k >= cap_vox) break;                       // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
+    const int k = s_rank[idx];
+    if (k >= cap_vox) continue;                    // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
     const uint32_t f = s_pix[idx];
     // the bin of the first pixel: the same two-tier classification as in P1.  (Parking the undecided voxels for a
     // second kernel doubled the occupancy of this one and made the pass slower: it runs at the memory system's
@@ -1155,7 +1162,7 @@ extern "C" int dfu3d_backproject_bin(
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-    hipLaunchKernelGGL(k_bp_vox, dim3((NJ + VX_PIECES - 1) / VX_PIECES, V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
+    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
                        fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
                        cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status);
     DFU3D_LAUNCH_CHECK();
