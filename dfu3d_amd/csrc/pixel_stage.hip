@@ -400,14 +400,16 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 // atomics per touched bin instead of one per pixel (6x fewer for dense depth).
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
+constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
+                                                   // the window set-up, its flush and the reductions are paid once per 2048 pixels
 __global__ __launch_bounds__(PB) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const FastCal *__restrict__ fastcal, const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
-    int tiles_x, int key_axis,
+    int tiles_x, int tiles_y, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
     int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
-  __shared__ uint32_t s_bits[32];                 // this tile's piece of the first-pixel bit map
-  __shared__ uint32_t s_amb[PBLK];
+  __shared__ uint32_t s_bits[32 * RPT];           // this workgroup's piece of the first-pixel bit map (RPT bit-map tiles)
+  __shared__ uint32_t s_amb[PBLK * RPT];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
   __shared__ int s_namb, s_base, s_t0, s_p0;
@@ -419,28 +421,34 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const KeyCol kcol = load_key_col(calib + v, key_axis);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int row = ty * TILE_H + (threadIdx.x >> 4);
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;     // ty counts RPT bit-map tile rows
+  const int row0 = ty * (RPT * TILE_H) + (threadIdx.x >> 4);
   const int col = tx * TILE_W + (threadIdx.x & 15) * PPT;
   if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
-  if (threadIdx.x < 32) s_bits[threadIdx.x] = 0u;
+  if (threadIdx.x < 32 * RPT) s_bits[threadIdx.x] = 0u;
   uint32_t *bitmap_v = bitmap + (size_t)v * BW;
-  // pixel f of THIS tile became a bin's first pixel; oldf is what it displaced
+  // pixel f of THIS workgroup's tile became a bin's first pixel; oldf is what it displaced
   auto new_first = [&](uint32_t f, uint32_t oldf) {
     const int fr = (int)f / W, fc = (int)f - fr * W;
-    const int local = (fr - ty * TILE_H) * TILE_W + (fc - tx * TILE_W);
+    const int local = (fr - ty * (RPT * TILE_H)) * TILE_W + (fc - tx * TILE_W);
     atomicOr(&s_bits[local >> 5], 1u << (local & 31));
     if (oldf != NOBIN) toggle_first_bit(bitmap_v, W, tiles_x, oldf);
   };
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
-  uint32_t bins[PPT];
-  double keys[PPT];
-  int its[PPT], ips[PPT];
-  const bool inside = (row < H) && (col < W);
-  const int base = row * W + col;
+  uint32_t bins[RPT][PPT];
+  double keys[RPT][PPT];
+  int its[RPT][PPT], ips[RPT][PPT];
+  bool inside[RPT];
   int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
-  if (inside) {
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int row = row0 + r * TILE_H;
+    inside[r] = (row < H) && (col < W);
+#pragma unroll
+    for (int k = 0; k < PPT; k++) { bins[r][k] = NOBIN; keys[r][k] = 0.0; its[r][k] = 0; ips[r][k] = 0; }
+    if (!inside[r]) continue;
+    const int base = row * W + col;
     const float *dv = depth + (size_t)v * HW;
     float d[PPT];
     load4(dv + (size_t)row * W, col, W, d);          // (columns past the image come back as depth 0: not binned)
@@ -448,19 +456,17 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
 #pragma unroll
     for (int k = 0; k < PPT; k++) cols[k] = col + k;
     uint32_t res[PPT];
-    classify_fast<PPT>(fc, g, fg, tab, row, cols, d, res, its, ips);
+    classify_fast<PPT>(fc, g, fg, tab, row, cols, d, res, its[r], ips[r]);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
-      bins[k] = NOBIN;
-      keys[k] = 0.0;
       const uint32_t b = res[k];
       if (b == AMBIG) {
         s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
       } else if (b != NOBIN) {
-        bins[k] = b;
-        tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]);
-        keys[k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
-        if (keys[k] == 0.0) keys[k] = 0.0;
+        bins[r][k] = b;
+        tmin = min(tmin, its[r][k]); pmin = min(pmin, ips[r][k]);
+        keys[r][k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
+        if (keys[r][k] == 0.0) keys[r][k] = 0.0;
       }
     }
   }
@@ -474,43 +480,46 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
-  if (inside) {
-    // runs of equal bins among the thread's four consecutive pixels are merged first
-    auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
-                      unsigned long long cm) {
-      const int lt = it - t0, lp = ip - p0;
+  // runs of equal bins among a thread's four consecutive pixels are merged first
+  auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
+                    unsigned long long cm) {
+    const int lt = it - t0, lp = ip - p0;
 #ifdef DFU3D_DBG_P1_NO_COMMIT         /* timing experiment only: results are wrong */
-      if (lt == 12345) s_cnt[0] = cn;
-      return;
+    if (lt == 12345) s_cnt[0] = cn;
+    return;
 #endif
-      if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
-        const int w = lt * WIN_P + lp;
-        atomicAdd(&s_cnt[w], cn);
-        atomicMin(&s_first[w], f);
-        atomicMin(&s_kmin[w], ok);
-        atomicMin(&s_combo[w], cm);
-      } else {                                                    // outside the window: direct
-        const int64_t e = tb0 + b;
-        atomicAdd(&T.cnt[e], cn);
-        const uint32_t oldf = atomicMin(&T.first[e], f);
-        atomicMin(&T.kmin[e], ok);
-        atomicMin(&T.combo[e], cm);
-        if (oldf > f) new_first(f, oldf);
-      }
-    };
+    if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
+      const int w = lt * WIN_P + lp;
+      atomicAdd(&s_cnt[w], cn);
+      atomicMin(&s_first[w], f);
+      atomicMin(&s_kmin[w], ok);
+      atomicMin(&s_combo[w], cm);
+    } else {                                                    // outside the window: direct
+      const int64_t e = tb0 + b;
+      atomicAdd(&T.cnt[e], cn);
+      const uint32_t oldf = atomicMin(&T.first[e], f);
+      atomicMin(&T.kmin[e], ok);
+      atomicMin(&T.combo[e], cm);
+      if (oldf > f) new_first(f, oldf);
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    if (!inside[r]) continue;
+    const int base = (row0 + r * TILE_H) * W + col;
     uint32_t rb = NOBIN, rcn = 0u, rfirst = 0u;
     unsigned long long rk = ~0ull, rcm = ~0ull;
     int rit = 0, rip = 0;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
-      const uint32_t b = bins[k];
+      const uint32_t b = bins[r][k];
       if (b != rb) {
         if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
         rb = b; rcn = 0u; rk = ~0ull; rcm = ~0ull;
-        rfirst = (uint32_t)(base + k); rit = its[k]; rip = ips[k];
+        rfirst = (uint32_t)(base + k); rit = its[r][k]; rip = ips[r][k];
       }
       if (b != NOBIN) {
-        const unsigned long long ok = ordered_key(keys[k]);
+        const unsigned long long ok = ordered_key(keys[r][k]);
         const unsigned long long cm = combo_word(ok, (uint32_t)(base + k), pix_bits);
         rcn++;
         rk = ok < rk ? ok : rk;
@@ -536,8 +545,13 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     if (oldf > s_first[w]) new_first(s_first[w], oldf);
   }
   __syncthreads();
-  // the tile's own bits: one contiguous 128-byte wave atomic (XOR: other tiles may already have toggled here)
-  if (threadIdx.x < 32 && s_bits[threadIdx.x]) atomicXor(&bitmap_v[blockIdx.x * 32 + threadIdx.x], s_bits[threadIdx.x]);
+  // the workgroup's own bits: contiguous 128-byte wave atomics, one per bit-map tile (XOR: other tiles may already
+  // have toggled here)
+  if (threadIdx.x < 32 * RPT && s_bits[threadIdx.x]) {
+    const int sub = threadIdx.x >> 5;                             // which of the RPT bit-map tiles
+    if (ty * RPT + sub < tiles_y)
+      atomicXor(&bitmap_v[((size_t)(ty * RPT + sub) * tiles_x + tx) * 32 + (threadIdx.x & 31)], s_bits[threadIdx.x]);
+  }
   const int na = s_namb;
   if (na == 0) return;
   if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
@@ -1147,8 +1161,8 @@ extern "C" int dfu3d_backproject_bin(
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 255) / 256), dim3(256), 0, st, *geom, fg, (float4 *)tab);
     DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * tiles_y, V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
-                       fg, W, H, tiles_x, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
+    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
+                       fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
                        bitmap, BW);
     DFU3D_LAUNCH_CHECK();
   }
