@@ -1035,33 +1035,51 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
 
   // ordered list of cluster roots, and in the same sweep the max z over ALL instance points
-  // (my_loader.py:647-648)
+  // (my_loader.py:647-648).  Every wave owns a contiguous range of the instance: it counts its roots, one hand-off
+  // orders the waves, a second sweep writes them -- no barrier inside the sweeps (a workgroup-wide rank per 512 points
+  // made the longest instance, 100 steps of two barriers, the duration of this kernel).
+  const int R = (((n + FW - 1) / FW) + 63) & ~63;          // points per wave, a multiple of 64
+  const int r0 = min(n, wave * R), r1 = min(n, r0 + R);
   double zm = -INFINITY;
-  int nroots = 0;
-  for (int t0 = 0; t0 < n; t0 += FT) {
-    const int i = t0 + threadIdx.x;
-    bool f = false;
-    if (i < n) {
-      f = (label[base + i] == i);
-      zm = fmax(zm, pz[base + i]);
+  int mine = 0;
+  for (int c = r0; c < r1; c += 64 * GU) {
+    int L[GU];
+    double zz[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = c + u * 64 + lane;
+      L[u] = (i < r1) ? label[base + i] : -1;
+      zz[u] = (i < r1) ? pz[base + i] : -INFINITY;
     }
-    int tot;
-    const int r = block_rank<FW>(f, s_w, tot);
-    if (f) sroot[base + nroots + r] = i;
-    nroots += tot;
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = c + u * 64 + lane;
+      mine += __popcll(__ballot(i < r1 && L[u] == i));
+      zm = fmax(zm, zz[u]);
+    }
   }
   zm = wave_max_d(zm);
-  if (lane == 0) s_red[wave] = zm;
+  if (lane == 0) { s_red[wave] = zm; s_w[wave] = mine; }
   __syncthreads();
   double zmax = s_red[0];
+  int nroots = 0, my_off = 0;
 #pragma unroll
-  for (int w = 1; w < FW; w++) zmax = fmax(zmax, s_red[w]);
+  for (int w = 0; w < FW; w++) {
+    zmax = fmax(zmax, s_red[w]);
+    my_off += (w < wave) ? s_w[w] : 0;
+    nroots += s_w[w];
+  }
+  for (int c = r0; c < r1; c += 64) {
+    const int i = c + lane;
+    const bool f = (i < r1) && (label[base + i] == i);
+    const unsigned long long m = __ballot(f);
+    if (f) sroot[base + my_off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    my_off += __popcll(m);
+  }
   if (threadIdx.x == 0) s_q0 = atomicAdd(&W.counters[0], nroots);
   __syncthreads();
   const int q0 = s_q0;
 
-  const int R = (((n + FW - 1) / FW) + 63) & ~63;          // points per wave, a multiple of 64
-  const int r0 = min(n, wave * R), r1 = min(n, r0 + R);
   long long goff = 0;
   for (int k0 = 0; k0 < nroots; k0 += GK) {
     const int nk = min(GK, nroots - k0);

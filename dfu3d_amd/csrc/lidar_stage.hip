@@ -2,9 +2,9 @@
 // above-plane + point->pixel label inheritance.
 //
 // One workgroup (1024 threads = 16 waves) per camera view walks the frame's
-// (N,4) float32 points in 1024-point tiles with float4 (16 B/lane) loads and
-// keeps the reference's ORDER by ballot + popcount ranks inside each wave and
-// an LDS hand-off of the 16 wave totals (ordered compaction, hazard H3).
+// (N,4) float32 points with float4 (16 B/lane) loads and keeps the reference's
+// ORDER by ballot + popcount ranks inside each wave and an LDS hand-off of the
+// 16 wave totals (ordered compaction, hazard H3).
 #include "common.hpp"
 
 namespace {
@@ -14,6 +14,11 @@ constexpr int NW = NT / 64;
 
 // ---------------------------------------------------------------- a4 FOV
 // vis_utils.py:108-123 / 152-154
+// Every wave owns a contiguous range of the frame's points (FOV_PW per pass of the workgroup): it evaluates its
+// points, keeps the FOV flags as ballot words in registers, counts them, and after ONE hand-off of the 16 wave totals
+// writes its indices behind those of the waves before it -- the order of the reference, two barriers per 16 384
+// points instead of two per 1024.
+constexpr int FOV_PW = 1024;                       // points per wave and pass
 __global__ __launch_bounds__(NT) void k_fov_filter(
     const float4 *__restrict__ pts, const int *__restrict__ pt_off,
     const int *__restrict__ view_frame, const ViewCalib *__restrict__ calib,
@@ -25,22 +30,45 @@ __global__ __launch_bounds__(NT) void k_fov_filter(
   const int p0 = pt_off[f];
   const int n = pt_off[f + 1] - p0;
   const ViewCalib c = calib[v];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
   int running = 0;
-  for (int base = 0; base < n; base += NT) {
-    const int i = base + threadIdx.x;
-    bool ok = false;
-    if (i < n) {
-      const float4 p = pts[p0 + i];
-      float r[3], u, w, d;
-      lidar_to_rect_f32(c.M43, p.x, p.y, p.z, r);
-      rect_to_img_f32(c.P2, r, u, w, d);
-      ok = (u >= 0.0f) && (u < fovW) && (w >= 0.0f) && (w < fovH) && (d >= 0.0f);
+  for (int base = 0; base < n; base += NW * FOV_PW) {          // uniform
+    const int w0 = base + wave * FOV_PW;
+    unsigned long long flags[FOV_PW / 64];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < FOV_PW / 64; k++) {
+      const int i = w0 + k * 64 + lane;
+      bool ok = false;
+      if (i < n) {
+        const float4 p = pts[p0 + i];
+        float r[3], u, w, d;
+        lidar_to_rect_f32(c.M43, p.x, p.y, p.z, r);
+        rect_to_img_f32(c.P2, r, u, w, d);
+        ok = (u >= 0.0f) && (u < fovW) && (w >= 0.0f) && (w < fovH) && (d >= 0.0f);
+      }
+      flags[k] = __ballot(ok);
+      mine += __popcll(flags[k]);
     }
-    int tot;
-    const int r = block_rank<NW>(ok, s_w, tot);
-    if (ok) {
-      const int pos = running + r;
-      if (pos < capN) fov_idx[(size_t)v * capN + pos] = i;
+    __syncthreads();                                           // the previous pass has read s_w
+    if (lane == 0) s_w[wave] = mine;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ww++) {
+      const int cw = s_w[ww];
+      before += (ww < wave) ? cw : 0;
+      tot += cw;
+    }
+    int pos = running + before;
+#pragma unroll
+    for (int k = 0; k < FOV_PW / 64; k++) {
+      const unsigned long long m = flags[k];
+      if ((m >> lane) & 1ull) {
+        const int q = pos + __popcll(m & ((1ull << lane) - 1ull));
+        if (q < capN) fov_idx[(size_t)v * capN + q] = w0 + k * 64 + lane;
+      }
+      pos += __popcll(m);
     }
     running += tot;
   }
