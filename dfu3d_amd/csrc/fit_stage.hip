@@ -1004,7 +1004,7 @@ __host__ __device__ inline FitWs fit_ws_view(double *ws, int cap_rows, int cap_b
 // range of the instance's points, counts its members per cluster, and after one
 // scan writes them behind the members of the waves before it -- no barrier inside
 // the sweeps, O(n) per GK clusters instead of O(n) per cluster.
-constexpr int GK = 64;
+constexpr int GK = 512;            // clusters per counting-sort pass (= FT: one thread per cluster in the hand-offs)
 
 __device__ __forceinline__ int rank_in(const int *roots, int nk, int L) {   // roots ascending, L present
   int lo = 0, hi = nk - 1;
@@ -1089,20 +1089,27 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
     __syncthreads();
     const int lo_root = s_roots[0], hi_root = s_roots[nk - 1];
     // counts per (wave, cluster)
-    for (int c = r0; c < r1; c += 64) {
-      const int i = c + lane;
-      int key = -1;
-      if (i < r1) {
-        const int L = label[base + i];
-        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
+    for (int c0 = r0; c0 < r1; c0 += 64 * GU) {              // GU steps' labels requested before the first is used
+      int Ls[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int i = c0 + u * 64 + lane;
+        Ls[u] = (i < r1) ? label[base + i] : -1;
       }
-      unsigned long long rem = __ballot(key >= 0);
-      while (rem) {
-        const int src = __ffsll((long long)rem) - 1;
-        const int k = __shfl(key, src, 64);
-        const unsigned long long m = __ballot(key == k);
-        if (lane == src) s_cnt[wave][k] += __popcll(m);
-        rem &= ~m;
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        if (c0 + u * 64 >= r1) break;
+        const int L = Ls[u];
+        int key = -1;
+        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
+        unsigned long long rem = __ballot(key >= 0);
+        while (rem) {
+          const int src = __ffsll((long long)rem) - 1;
+          const int k = __shfl(key, src, 64);
+          const unsigned long long m = __ballot(key == k);
+          if (lane == src) s_cnt[wave][k] += __popcll(m);
+          rem &= ~m;
+        }
       }
     }
     __syncthreads();
@@ -1113,36 +1120,47 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
       s_tot[threadIdx.x] = t;
     }
     __syncthreads();
-    if (wave == 0) {                                         // exclusive over the clusters
-      const int v = (lane < nk) ? s_tot[lane] : 0;
-      const int inc = wave_incl_scan(v);
-      if (lane < nk) s_off[lane] = inc - v;
-      if (lane == 63) s_total = inc;
+    {                                                        // exclusive over the clusters
+      int tot;
+      const int ex = block_excl_scan<FW>(((int)threadIdx.x < nk) ? s_tot[threadIdx.x] : 0, s_w, tot);
+      if ((int)threadIdx.x < nk) s_off[threadIdx.x] = ex;
+      if (threadIdx.x == 0) s_total = tot;
     }
     __syncthreads();
     // stable scatter
-    for (int c = r0; c < r1; c += 64) {
-      const int i = c + lane;
-      int key = -1;
-      double x = 0.0, y = 0.0;
-      if (i < r1) {
-        const int L = label[base + i];
-        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
-        if (key >= 0) { x = px[base + i]; y = py[base + i]; }
+    for (int c0 = r0; c0 < r1; c0 += 64 * GU) {
+      int keys[GU];
+      double xs[GU], ys[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int i = c0 + u * 64 + lane;
+        const int L = (i < r1) ? label[base + i] : -1;
+        keys[u] = (L >= lo_root && L <= hi_root) ? rank_in(s_roots, nk, L) : -1;
       }
-      unsigned long long rem = __ballot(key >= 0);
-      while (rem) {
-        const int src = __ffsll((long long)rem) - 1;
-        const int k = __shfl(key, src, 64);
-        const unsigned long long m = __ballot(key == k);
-        const int cur = s_cnt[wave][k];
-        if (key == k) {
-          const long long d = base + goff + s_off[k] + cur + __popcll(m & ((1ull << lane) - 1ull));
-          gsx[d] = x;
-          gsy[d] = y;
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int i = c0 + u * 64 + lane;
+        xs[u] = 0.0; ys[u] = 0.0;
+        if (keys[u] >= 0) { xs[u] = px[base + i]; ys[u] = py[base + i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        if (c0 + u * 64 >= r1) break;
+        const int key = keys[u];
+        unsigned long long rem = __ballot(key >= 0);
+        while (rem) {
+          const int src = __ffsll((long long)rem) - 1;
+          const int k = __shfl(key, src, 64);
+          const unsigned long long m = __ballot(key == k);
+          const int cur = s_cnt[wave][k];
+          if (key == k) {
+            const long long d = base + goff + s_off[k] + cur + __popcll(m & ((1ull << lane) - 1ull));
+            gsx[d] = xs[u];
+            gsy[d] = ys[u];
+          }
+          if (lane == src) s_cnt[wave][k] = cur + __popcll(m);
+          rem &= ~m;
         }
-        if (lane == src) s_cnt[wave][k] = cur + __popcll(m);
-        rem &= ~m;
       }
     }
     // descriptors
