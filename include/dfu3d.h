@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 110          /* 0.1.1 */
+#define DFU3D_VERSION 120          /* 0.1.2 */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
