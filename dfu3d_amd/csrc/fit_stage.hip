@@ -717,14 +717,24 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
             const double xa = SX[i], ya = SY[i];
             if (!near_box(BB, xa, ya)) continue;
             const double Ra = R0 + Rd * sqrt(xa * xa + ya * ya);
-            for (int j = b0; j < b1; j++) {
-              const double xb = SX[j], yb = SY[j];
-              const double dx = xa - xb, dy = ya - yb;
-              const double sq = dx * dx + dy * dy;
-              if (sq > S_HI) continue;
-              if (sq <= S_LO) { found = true; break; }
-              const double d = sqrt(sq);                                   // rectangle_fitting.py:169
-              if (d <= Ra || d <= R0 + Rd * sqrt(xb * xb + yb * yb)) { found = true; break; }
+            for (int j0 = b0; j0 < b1 && !found; j0 += 4) {                // four points of the other run per round trip
+              double xb4[4], yb4[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int j = min(j0 + u, b1 - 1);
+                xb4[u] = SX[j]; yb4[u] = SY[j];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                if (j0 + u >= b1) break;
+                const double xb = xb4[u], yb = yb4[u];
+                const double dx = xa - xb, dy = ya - yb;
+                const double sq = dx * dx + dy * dy;
+                if (sq > S_HI) continue;
+                if (sq <= S_LO) { found = true; break; }
+                const double d = sqrt(sq);                                 // rectangle_fitting.py:169
+                if (d <= Ra || d <= R0 + Rd * sqrt(xb * xb + yb * yb)) { found = true; break; }
+              }
             }
           }
           if (found) cell_unite(s_par, c, nb);

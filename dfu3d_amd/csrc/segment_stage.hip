@@ -790,30 +790,49 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
           const double fqx = floor(x * inv) + OFF, fqy = floor(y * inv) + OFF, fqz = floor(z * inv) + OFF;
           const bool qin = fqx >= 0.0 && fqy >= 0.0 && fqz >= 0.0 && fqx <= 131071.0 && fqy <= 131071.0 && fqz <= 131071.0;
           const int qx = qin ? (int)fqx : 0, qy = qin ? (int)fqy : 0, qz = qin ? (int)fqz : 0;
-          for (int uz = z0; uz <= z1 && !found; uz++)
-            for (int uy = y0; uy <= y1 && !found; uy++)
-              for (int ux = x0; ux <= x1 && !found; ux++) {
-                uint32_t node = s_head[bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz) & mask];
-                while (node) {
-                  const unsigned long long wv = s_node[node - 1u];
-                  const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
-                            az = (int)((wv >> 34) & 0x1FFFFull);
-                  // each quantised difference is within 1 (+3e-11) unit of the true one, so the
-                  // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
-                  // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
-                  const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
-                            ez_ = max(abs(az - qz) - 1, 0);
-                  if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
-                    const int j = (int)node - 1;
-                    const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
-                    double d = ex * ex;
-                    d += ey * ey;
-                    d += ez * ez;
-                    if (d < T) { found = true; break; }      // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
-                  }
-                  node = (uint32_t)(wv >> 51);
-                }
+          // walk a chain from `node`, whose word `wv` the caller has read already
+          auto walk_from = [&](uint32_t node, unsigned long long wv) {
+            while (true) {
+              const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
+                        az = (int)((wv >> 34) & 0x1FFFFull);
+              // each quantised difference is within 1 (+3e-11) unit of the true one, so the
+              // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
+              // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
+              const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
+                        ez_ = max(abs(az - qz) - 1, 0);
+              if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
+                const int j = (int)node - 1;
+                const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
+                double d = ex * ex;
+                d += ey * ey;
+                d += ez * ez;
+                if (d < T) { found = true; return; }         // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
               }
+              node = (uint32_t)(wv >> 51);
+              if (!node) return;
+              wv = s_node[node - 1u];
+            }
+          };
+          auto walk = [&](uint32_t node) { if (node) walk_from(node, s_node[node - 1u]); };
+          if (x1 - x0 <= 1 && y1 - y0 <= 1 && z1 - z0 <= 1) {
+            // the usual case, at most 2 x 2 x 2 cells: all eight heads are read before the first chain is walked
+            // (one LDS round trip instead of eight in a row -- most cells are empty, the reads were the cost)
+            uint32_t heads[8];
+#pragma unroll
+            for (int cidx = 0; cidx < 8; cidx++) {
+              const int ux = x0 + (cidx & 1), uy = y0 + ((cidx >> 1) & 1), uz = z0 + (cidx >> 2);
+              const bool there = ux <= x1 && uy <= y1 && uz <= z1;
+              heads[cidx] = there ? s_head[bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz) & mask] : 0u;
+            }
+#pragma unroll
+            for (int cidx = 0; cidx < 8; cidx++)               // (reading the chains' first nodes ahead as well gained nothing)
+              if (!found) walk(heads[cidx]);
+          } else {
+            for (int uz = z0; uz <= z1 && !found; uz++)
+              for (int uy = y0; uy <= y1 && !found; uy++)
+                for (int ux = x0; ux <= x1 && !found; ux++)
+                  walk(s_head[bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz) & mask]);
+          }
         }
         flags[bq + q] = found ? 1 : 0;
       }
