@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
     for (int i = threadIdx.x; i < FW * GK; i += FT) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     const int lo_root = s_roots[0], hi_root = s_roots[nk - 1];
+    int memo_L = -2, memo_key = -1;                          // the lane's last successful search (labels are >= 0)
     // counts per (wave, cluster)
     for (int c0 = r0; c0 < r1; c0 += 64 * GU) {              // GU steps' labels requested before the first is used
       int Ls[GU];
@@ -1111,7 +1112,8 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
         if (c0 + u * 64 >= r1) break;
         const int L = Ls[u];
         int key = -1;
-        if (L >= lo_root && L <= hi_root) key = rank_in(s_roots, nk, L);
+        if (L == memo_L) key = memo_key;                       // (most points sit in one cluster: no search)
+        else if (L >= lo_root && L <= hi_root) { key = rank_in(s_roots, nk, L); memo_L = L; memo_key = key; }
         unsigned long long rem = __ballot(key >= 0);
         while (rem) {
           const int src = __ffsll((long long)rem) - 1;
@@ -1145,7 +1147,9 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
       for (int u = 0; u < GU; u++) {
         const int i = c0 + u * 64 + lane;
         const int L = (i < r1) ? label[base + i] : -1;
-        keys[u] = (L >= lo_root && L <= hi_root) ? rank_in(s_roots, nk, L) : -1;
+        if (L == memo_L) keys[u] = memo_key;
+        else if (L >= lo_root && L <= hi_root) { keys[u] = rank_in(s_roots, nk, L); memo_L = L; memo_key = keys[u]; }
+        else keys[u] = -1;
       }
 #pragma unroll
       for (int u = 0; u < GU; u++) {
