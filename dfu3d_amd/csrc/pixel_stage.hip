@@ -668,15 +668,20 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
                                            uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status) {
   const Table &T = X.T;
   const int64_t e = X.tb0 + b;
+  // the three planes of the entry are requested together, and so are the two reads that hang on the representative
+  // pixel (its depth and its mask word): four dependent round trips per voxel instead of six
   const uint32_t cw = T.cnt[e];
-  const uint32_t pix = (uint32_t)(T.combo[e] & ((1ull << X.pix_bits) - 1ull));
+  const unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
+  const uint32_t pix = (uint32_t)(e_combo & ((1ull << X.pix_bits) - 1ull));
   const int row = (int)pix / X.W, col = (int)pix - row * X.W;
+  const float d_pix = X.dv[pix];
+  const uint32_t m_bits = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
   double x, yy, z;
-  pixel_to_lidar(X.c, X.rc, col, row, X.dv[pix], x, yy, z);
+  pixel_to_lidar(X.c, X.rc, col, row, d_pix, x, yy, z);
   double key = (X.key_axis == 2) ? z : yy;
   if (key == 0.0) key = 0.0;
   // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
-  if (cw > (uint32_t)X.max_points || ordered_key(key) != T.kmin[e]) {
+  if (cw > (uint32_t)X.max_points || ordered_key(key) != e_kmin) {
     const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
     if (slot < X.cap_q) { q_bins[(size_t)v * X.cap_q + slot] = b; q_rank[(size_t)v * X.cap_q + slot] = k; }
     else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
@@ -685,7 +690,7 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
   if (k < X.max_voxels) {
     const size_t at = (size_t)v * X.cap_vox + k;
     out.vox_pix[at] = pix;
-    out.it_bits[at] = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
+    out.it_bits[at] = m_bits;
     out.it_x[at] = x;
     out.it_y[at] = yy;
     out.it_z[at] = z;
