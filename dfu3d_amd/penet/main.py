@@ -8,6 +8,7 @@ DepthAnything are input providers outside this path) and adds
 (my_loader_KittiPandasetWaymo.py:1083-1090); with torchrun every rank takes
 frames rank, rank+world, ... and writes its own label files."""
 import argparse
+import json
 import os
 import sys
 import time
@@ -37,7 +38,11 @@ def build_parser():
     ap.add_argument('--label-out', default=None, help='default <detpath>/label_2')
     ap.add_argument('--start', type=int, default=0)
     ap.add_argument('--end', type=int, default=None)
-    ap.add_argument('--skip-existing', action='store_true')
+    ap.add_argument('--skip-existing', action='store_true',
+                    help='restart: skip frames whose label file exists or that a frames.rank*.jsonl of an earlier run lists')
+    ap.add_argument('--keep-going', action='store_true',
+                    help='one-frame-at-a-time path: a frame whose inputs cannot be read is logged (frames.rank*.jsonl, '
+                         '"error") and skipped instead of ending the run')
     ap.add_argument('--batch-frames', type=int, default=16,
                     help='frames per engine call (0: one view at a time through save_depth_as_points)')
     ap.add_argument('--no-virtual-points', action='store_true',
@@ -79,7 +84,20 @@ def main(argv=None):
     t0 = time.time()
     n_assigned = len(mine)
     if args.skip_existing:
-        mine = [s for s in mine if not os.path.exists(os.path.join(label_out, s + '.txt'))]
+        done = set()
+        if os.path.isdir(label_out):
+            for fn in os.listdir(label_out):                    # per-frame logs of earlier runs (any rank count)
+                if fn.startswith('frames.rank') and fn.endswith('.jsonl'):
+                    with open(os.path.join(label_out, fn)) as f:
+                        for line in f:
+                            try:
+                                rec = json.loads(line)
+                            except ValueError:
+                                continue                         # a line cut off by the crash we are restarting from
+                            if 'error' not in rec:
+                                done.add(rec.get('frame'))
+        mine = [s for s in mine if s not in done and not os.path.exists(os.path.join(label_out, s + '.txt'))]
+    errors = []
     frame_index = {s: i for i, s in enumerate(frames)}     # global index of a frame = its place in the sorted list
     rows_log = []                                           # (stem, engine rows) of every frame this rank labelled
     if args.batch_frames > 0:
@@ -99,16 +117,30 @@ def main(argv=None):
     for k, idx in enumerate(mine):
         if args.skip_existing and os.path.exists(os.path.join(label_out, idx + '.txt')):
             continue
-        depth = np.load(os.path.join(depth_dir, idx + '.npy')).astype(np.float32)
         from .vis_utils import load_seg_npz
-        _, r = save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
-                                    seg_provider=(lambda path, _i=idx: load_seg_npz(args.detpath, _i, args.seg_dir)),
-                                    device="cuda:%d" % (local if world > 1 else 0), return_rows=True)
+        try:
+            depth = np.load(os.path.join(depth_dir, idx + '.npy')).astype(np.float32)
+            _, r = save_depth_as_points(depth, idx, args.detpath, label_root=label_out,
+                                        seg_provider=(lambda path, _i=idx: load_seg_npz(args.detpath, _i, args.seg_dir)),
+                                        device="cuda:%d" % (local if world > 1 else 0), return_rows=True)
+        except (OSError, ValueError, KeyError) as e:             # unreadable / malformed input files of this frame
+            if not args.keep_going:
+                raise
+            errors.append((idx, "%s: %s" % (type(e).__name__, e)))
+            continue
         rows_log.append((idx, r))
         if rank == 0 and (k + 1) % 10 == 0:
             print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))
     if rpool is not None:
         rpool.close()
+    # per-frame log of this rank (JSONL per frame; also the done-list --skip-existing reads)
+    os.makedirs(label_out, exist_ok=True)
+    with open(os.path.join(label_out, 'frames.rank%d.jsonl' % rank), 'a') as f:
+        for stem, r in rows_log:
+            f.write(json.dumps({"frame": stem, "frame_idx": frame_index[stem], "rank": rank,
+                                "boxes": int(np.asarray(r).reshape(-1, 24).shape[0])}) + "\n")
+        for stem, msg in errors:
+            f.write(json.dumps({"frame": stem, "frame_idx": frame_index[stem], "rank": rank, "error": msg}) + "\n")
     # the one collective of the path: variable-length all-gather of the box rows, each carrying its
     # global frame index; rank 0 writes the manifest of the run next to the label files
     import torch

@@ -116,8 +116,22 @@ def test_cli_on_kitti_directory_matches_oracle(tmp_path):
         vp = np.load(os.path.join(root, "velodyne_depth", "%06d.npy" % f))
         assert vp.dtype == np.float16 and vp.shape == exp[f].all_points.shape
         assert np.array_equal(vp, exp[f].all_points.astype(np.float16))
-    # a second run with --skip-existing leaves the files alone
+    # per-frame log of the run: one line per labelled frame with its global index and box count
+    import json
+    log = os.path.join(root, "label_2", "frames.rank0.jsonl")
+    recs = [json.loads(l) for l in open(log)]
+    assert [r["frame"] for r in recs] == ["000000", "000001"] and [r["frame_idx"] for r in recs] == [0, 1]
+    assert [r["boxes"] for r in recs] == [len(exp[0].rows), len(exp[1].rows)]
+    # a second run with --skip-existing leaves the files alone (and logs nothing: nothing was labelled)
     assert cli.main(["--detpath", root, "--skip-existing", "--conf_files", "x.yaml"]) == 0
+    assert len(open(log).readlines()) == 2
+    # the done-list alone is enough for a restart: label file gone, frame listed -> not redone
+    saved = open(os.path.join(root, "label_2", "000001.txt")).read()
+    os.remove(os.path.join(root, "label_2", "000001.txt"))
+    assert cli.main(["--detpath", root, "--skip-existing", "--conf_files", "x.yaml"]) == 0
+    assert not os.path.exists(os.path.join(root, "label_2", "000001.txt"))
+    with open(os.path.join(root, "label_2", "000001.txt"), "w") as fh:
+        fh.write(saved)
     # the one-view-at-a-time path (save_depth_as_points) writes the same files as the batched one
     import shutil
     keep = {}
@@ -129,6 +143,14 @@ def test_cli_on_kitti_directory_matches_oracle(tmp_path):
     for f in range(2):
         assert open(os.path.join(root, "label_2", "%06d.txt" % f)).read() == keep[f][0]
         assert np.array_equal(np.load(os.path.join(root, "velodyne_depth", "%06d.npy" % f)), keep[f][1])
+    # --keep-going: a frame with an unreadable depth file is logged and skipped, the other one is labelled
+    shutil.rmtree(os.path.join(root, "label_2"))
+    with open(os.path.join(root, "depth_2", "000000.npy"), "wb") as fh:
+        fh.write(b"not a numpy file")
+    assert cli.main(["--detpath", root, "--batch-frames", "0", "--keep-going", "--conf_files", "x.yaml"]) == 0
+    recs = [json.loads(l) for l in open(os.path.join(root, "label_2", "frames.rank0.jsonl"))]
+    assert [("error" in r, r["frame"]) for r in recs] == [(False, "000001"), (True, "000000")]
+    assert open(os.path.join(root, "label_2", "000001.txt")).read() == keep[1][0]
 
 
 def test_batched_labeler_many_frames_partial_batch(tmp_path):
