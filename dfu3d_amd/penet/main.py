@@ -38,8 +38,10 @@ def build_parser():
     ap.add_argument('--label-out', default=None, help='default <detpath>/label_2')
     ap.add_argument('--start', type=int, default=0)
     ap.add_argument('--end', type=int, default=None)
-    ap.add_argument('--skip-existing', action='store_true',
-                    help='restart: skip frames whose label file exists or that a frames.rank*.jsonl of an earlier run lists')
+    ap.add_argument('--skip-existing', action='store_true', help='restart: skip frames whose label file exists')
+    ap.add_argument('--resume', action='store_true',
+                    help='restart from the per-frame logs: skip frames that a frames.rank*.jsonl of an earlier run lists '
+                         'as done (any rank count), and those whose label file exists')
     ap.add_argument('--keep-going', action='store_true',
                     help='one-frame-at-a-time path: a frame whose inputs cannot be read is logged (frames.rank*.jsonl, '
                          '"error") and skipped instead of ending the run')
@@ -83,9 +85,11 @@ def main(argv=None):
     label_out = args.label_out or os.path.join(args.detpath, 'label_2')
     t0 = time.time()
     n_assigned = len(mine)
+    if args.resume:
+        args.skip_existing = True
     if args.skip_existing:
         done = set()
-        if os.path.isdir(label_out):
+        if args.resume and os.path.isdir(label_out):
             for fn in os.listdir(label_out):                    # per-frame logs of earlier runs (any rank count)
                 if fn.startswith('frames.rank') and fn.endswith('.jsonl'):
                     with open(os.path.join(label_out, fn)) as f:

@@ -128,7 +128,7 @@ def test_cli_on_kitti_directory_matches_oracle(tmp_path):
     # the done-list alone is enough for a restart: label file gone, frame listed -> not redone
     saved = open(os.path.join(root, "label_2", "000001.txt")).read()
     os.remove(os.path.join(root, "label_2", "000001.txt"))
-    assert cli.main(["--detpath", root, "--skip-existing", "--conf_files", "x.yaml"]) == 0
+    assert cli.main(["--detpath", root, "--resume", "--conf_files", "x.yaml"]) == 0
     assert not os.path.exists(os.path.join(root, "label_2", "000001.txt"))
     with open(os.path.join(root, "label_2", "000001.txt"), "w") as fh:
         fh.write(saved)
