@@ -1413,6 +1413,7 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
 // members straight from global memory was tried as well: every XCD fetched every cluster, 5.4 GB per launch.)
 constexpr int BIGC_T = 512, BIGC_WAVES = BIGC_T / 64, BIGC_HPW = 2, BIGC_HB = BIGC_WAVES * BIGC_HPW;
 constexpr int BIGC_CH = 2048;
+constexpr int BIGC_LONG = 16384, BIGC_MID = 6144;   // size classes of the scheduling rounds
 __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restrict__ gsx,
                                                          const double *__restrict__ gsy, int n_theta,
                                                          double dtheta, double *__restrict__ fit_ws,
@@ -1440,11 +1441,17 @@ __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restric
       if (lane == 0) s_item = ticket >> 6;
     }
     __syncthreads();
-    const int item = s_item;
-    if (item >= items) break;                  // uniform; the counter only grows
+    const int ticket_item = s_item;
+    if (ticket_item >= 3 * items) break;       // uniform; the counter only grows
+    // Three rounds of tickets, longest clusters first: an item of a 50 000-point cluster runs for a good part of this
+    // kernel's duration and must not be among the last to start (1.20 -> 0.94 ms; giving the long clusters finer items
+    // as well -- one heading per wave -- gained nothing more).
+    const int round = ticket_item / items;
+    const int item = ticket_item - round * items;
     const int c = item / nb, tb = (item - c * nb) * BIGC_HB;
     const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
     const int m = (int)dsc[3];
+    if ((m > BIGC_LONG ? 0 : (m > BIGC_MID ? 1 : 2)) != round) continue;   // (uniform) not this round's
     const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
     int th[BIGC_HPW];
     double ct[BIGC_HPW], st[BIGC_HPW], nst[BIGC_HPW];
