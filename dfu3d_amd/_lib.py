@@ -58,6 +58,11 @@ class ChainCfg(ctypes.Structure):
     ]
 
 
+class EvalCombo(ctypes.Structure):
+    """dfu3d_eval_combo (include/dfu3d.h)."""
+    _fields_ = [("cls", c_i32), ("difficulty", c_i32), ("min_overlap", c_f64)]
+
+
 _P = c_void_p
 # argument lists mirror include/dfu3d.h exactly (pointers as void*)
 SIGNATURES = {
@@ -98,6 +103,9 @@ SIGNATURES = {
     "dfu3d_nms_normal_bev": (c_i32, [_P, c_i32, ctypes.c_float, _P, _P, _P, _P]),
     "dfu3d_boxes_bev_paired": (c_i32, [_P, _P, c_i32, _P, c_i32, _P]),
     "dfu3d_rotate_iou_eval": (c_i32, [_P, c_i32, _P, c_i32, _P, c_i32, _P]),
+    "dfu3d_eval_overlaps": (c_i32, [c_i32, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, c_i64, _P]),
+    "dfu3d_eval_match_scores": (c_i32, [c_i32, c_i32, c_i32] + [_P] * 15 + [c_i32, c_i64, _P, _P, _P]),
+    "dfu3d_eval_match_stats": (c_i32, [c_i32, c_i32, c_i32] + [_P] * 15 + [c_i32, _P, _P, c_i32, c_i32, _P, _P, _P]),
     "dfu3d_workspace_bytes": (c_i64, [c_i32, ctypes.POINTER(Sizes)]),
     "dfu3d_chain_workspace_bytes": (c_i64, [ctypes.POINTER(ChainCfg)]),
     "dfu3d_chain_workspace_init": (c_i32, [ctypes.POINTER(ChainCfg), _P, _P]),

@@ -392,6 +392,98 @@ def rotate_iou_eval(boxes, query_boxes, criterion=-1):
     return out
 
 
+EVAL_MAX_DET = 2048          # DFU3D_EVAL_MAX_DET: detections per frame the evaluator takes
+
+
+class EvalFrames:
+    """All frames of an evaluation as flat CUDA tensors (see include/dfu3d.h, "f-3, AP evaluation"): offsets int64
+    (F+1), per-box float64 bbox (.,4), cam (.,7), alpha, score, truncated and int32 code, dontcare, occluded."""
+
+    FIELDS_GT = ("gt_code", "gt_dontcare", "gt_bbox", "gt_alpha", "gt_occluded", "gt_truncated")
+    FIELDS_DT = ("dt_code", "dt_bbox", "dt_alpha", "dt_score")
+
+    def __init__(self, **t):
+        self.__dict__.update(t)
+        self.F = int(self.gt_off.numel()) - 1
+        self.n_gt, self.n_dt = int(self.gt_code.numel()), int(self.dt_code.numel())
+
+    def _box_args(self):
+        G, D = self.n_gt, self.n_dt
+        f64, i32 = torch.float64, torch.int32
+        return [_chk(self.gt_code, "gt_code", i32, numel=G), _chk(self.gt_dontcare, "gt_dontcare", i32, numel=G),
+                _chk(self.gt_bbox, "gt_bbox", f64, numel=4 * G), _chk(self.gt_alpha, "gt_alpha", f64, numel=G),
+                _chk(self.gt_occluded, "gt_occluded", i32, numel=G), _chk(self.gt_truncated, "gt_truncated", f64, numel=G),
+                _chk(self.dt_code, "dt_code", i32, numel=D), _chk(self.dt_bbox, "dt_bbox", f64, numel=4 * D),
+                _chk(self.dt_alpha, "dt_alpha", f64, numel=D), _chk(self.dt_score, "dt_score", f64, numel=D)]
+
+    def _off_args(self):
+        F = self.F
+        return [_chk(self.gt_off, "gt_off", torch.int64, numel=F + 1), _chk(self.dt_off, "dt_off", torch.int64, numel=F + 1),
+                _chk(self.ov_off, "ov_off", torch.int64, numel=F + 1)]
+
+
+def eval_overlaps(fr: EvalFrames, metric):
+    """-> float64 (n_pairs): overlap of detection j with ground truth i of frame f at ov_off[f] + i * D_f + j."""
+    ov = torch.zeros(max(fr.n_pairs, 1), dtype=torch.float64, device=fr.gt_off.device)
+    if fr.n_pairs:
+        rc = _lib.lib().dfu3d_eval_overlaps(
+            int(metric), fr.F, *fr._off_args(), _chk(fr.gt_bbox, "gt_bbox", torch.float64, numel=4 * fr.n_gt),
+            _chk(fr.dt_bbox, "dt_bbox", torch.float64, numel=4 * fr.n_dt),
+            _chk(fr.gt_cam, "gt_cam", torch.float64, numel=7 * fr.n_gt),
+            _chk(fr.dt_cam, "dt_cam", torch.float64, numel=7 * fr.n_dt), _chk(ov, "ov", torch.float64, numel=fr.n_pairs),
+            fr.n_pairs, _stream())
+        _lib.check(rc, "dfu3d_eval_overlaps")
+    return ov
+
+
+def _combo_tensor(combos, device):
+    """[(class index, difficulty, min_overlap)] -> the dfu3d_eval_combo array as a CUDA byte tensor."""
+    arr = (_lib.EvalCombo * len(combos))()
+    for k, (c, d, mo) in enumerate(combos):
+        if int(d) < 0:
+            raise Dfu3dError("difficulty must be >= 0")
+        arr[k].cls, arr[k].difficulty, arr[k].min_overlap = int(c), int(d), float(mo)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def eval_match_scores(fr: EvalFrames, ov, metric, combos):
+    """First pass of eval_class for every cell of `combos` -> (matched float64 (n_combo, n_gt) NaN-padded per frame,
+    n_valid int32 (n_combo, F))."""
+    dev = fr.gt_off.device
+    C = len(combos)
+    matched = torch.full((C, max(fr.n_gt, 1)), float("nan"), dtype=torch.float64, device=dev)
+    n_valid = torch.zeros((C, fr.F), dtype=torch.int32, device=dev)
+    cb = _combo_tensor(combos, dev)
+    rc = _lib.lib().dfu3d_eval_match_scores(
+        int(metric), fr.F, fr.max_dt, *fr._off_args(), _chk(ov, "ov", torch.float64, min_numel=max(fr.n_pairs, 1)),
+        *fr._box_args(), _chk(cb, "combos", torch.uint8, numel=16 * C), C, fr.n_gt,
+        _chk(matched, "matched", torch.float64, min_numel=C * fr.n_gt), _chk(n_valid, "n_valid", torch.int32, numel=C * fr.F),
+        _stream())
+    _lib.check(rc, "dfu3d_eval_match_scores")
+    return matched[:, :fr.n_gt], n_valid
+
+
+def eval_match_stats(fr: EvalFrames, ov, metric, combos, thresholds, n_thresh, compute_aos=False):
+    """Second pass: thresholds float64 (n_combo, T), n_thresh int32 (n_combo) -> (pr int64 (n_combo, T, 3) = tp, fp, fn
+    over all frames, sim float64 (n_combo, F, T) or None)."""
+    dev = fr.gt_off.device
+    C, T = int(thresholds.shape[0]), int(thresholds.shape[1])
+    if C != len(combos) or T < 1:
+        raise Dfu3dError("thresholds must be (n_combo, T >= 1)")
+    pr = torch.zeros((C, T, 3), dtype=torch.int64, device=dev)
+    sim = torch.zeros((C, fr.F, T), dtype=torch.float64, device=dev) if compute_aos else None
+    cb = _combo_tensor(combos, dev)
+    rc = _lib.lib().dfu3d_eval_match_stats(
+        int(metric), fr.F, fr.max_dt, *fr._off_args(), _chk(ov, "ov", torch.float64, min_numel=max(fr.n_pairs, 1)),
+        *fr._box_args(), _chk(cb, "combos", torch.uint8, numel=16 * C), C,
+        _chk(thresholds, "thresholds", torch.float64, numel=C * T), _chk(n_thresh, "n_thresh", torch.int32, numel=C), T,
+        1 if compute_aos else 0, _chk(pr, "pr", torch.int64, numel=C * T * 3),
+        _chk(sim, "sim", torch.float64, numel=C * fr.F * T) if compute_aos else None, _stream())
+    _lib.check(rc, "dfu3d_eval_match_stats")
+    return pr, sim
+
+
 def nms_bev(boxes, thresh, normal=False):
     """boxes (N,7) float32 CUDA sorted by descending score -> (keep int64 (N,), number kept)."""
     n = int(boxes.shape[0])

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 120          /* 0.1.2 */
+#define DFU3D_VERSION 130          /* 0.1.3 */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -326,6 +326,52 @@ int dfu3d_nms_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
                   int64_t *keep, int32_t *num_keep, void *stream);
 int dfu3d_nms_normal_bev(const float *boxes, int32_t n, float thresh, uint64_t *mask,
                          int64_t *keep, int32_t *num_keep, void *stream);
+
+/* ---- f-3, AP evaluation: the KITTI evaluator of pcdet/datasets/kitti/kitti_object_eval_python/eval.py -----------
+ * (reached from kitti_dataset.py:421-431 `evaluation`).  All frames of a split are ONE batch: ground truths and
+ * detections are flat arrays with per-frame offsets gt_off / dt_off (F+1, int64).  Per box: bbox float64 (.,4)
+ * [x1 y1 x2 y2], cam float64 (.,7) [x y z l h w ry] (location, dimensions, rotation_y), alpha, score float64;
+ * code int32 = index of the lower-cased name in the evaluator's class list (eval.py:32), 1000 + k for a name that is
+ * neutral for class k ('van' for car, 'person_sitting' for pedestrian, :47-51), -1 otherwise; gt_dontcare int32 = 1
+ * for 'DontCare' rows (:72-73); gt_occluded int32, gt_truncated float64.
+ * dfu3d_eval_overlaps: calculate_iou_partly (:336-417) restricted to pairs of the same frame.  ov float64
+ *   [ov_off[f] + i * D_f + j] for ground truth i, detection j of frame f (ov_off = prefix sums of G_f * D_f, F+1);
+ *   metric 0: 2-D boxes (image_box_overlap :95-124), 1: BEV IoU of [x z l w ry] (float32 exact polygon overlap, as
+ *   dfu3d_rotate_iou_eval), 2: volume IoU (d3_box_overlap_kernel :126-151, result rounded to float32 as there).
+ * dfu3d_eval_match_scores: compute_statistics_jit with compute_fp False, thresh 0 (:497-511) for every frame and every
+ *   cell (class, difficulty, min_overlap) of `combos`: matched float64 (n_combo, n_gt) receives, per frame, the
+ *   scores of the matched detections at the head of the frame's ground-truth slots and NaN behind them; n_valid int32
+ *   (n_combo, F) the number of counted ground truths (clean_data's num_valid_gt).
+ * dfu3d_eval_match_stats: fused_compute_statistics (:304-333): thresholds float64 (n_combo, t_stride) with n_thresh
+ *   (n_combo) valid entries each; pr int64 (n_combo, t_stride, 3) = tp, fp, fn summed over the frames (zeroed by the
+ *   call); sim float64 (n_combo, F, t_stride) = per-frame orientation similarity (0 where the reference returns -1),
+ *   required iff compute_aos.  One lane runs the reference's assignment for one threshold; a wave = the thresholds of
+ *   one frame and cell.  max_dt = largest detection count of a frame, <= 2048 (DFU3D_ERANGE beyond). */
+typedef struct dfu3d_eval_combo {
+  int32_t cls;          /* class index k (see `code`) */
+  int32_t difficulty;   /* 0 easy, 1 moderate, 2 hard; >= 3: no level rules (get_range_eval_result) */
+  double min_overlap;
+} dfu3d_eval_combo;
+#define DFU3D_EVAL_MAX_DET 2048
+int dfu3d_eval_overlaps(int32_t metric, int32_t F, const int64_t *gt_off, const int64_t *dt_off,
+                        const int64_t *ov_off, const double *gt_bbox, const double *dt_bbox,
+                        const double *gt_cam, const double *dt_cam, double *ov, int64_t n_pairs,
+                        void *stream);
+int dfu3d_eval_match_scores(int32_t metric, int32_t F, int32_t max_dt, const int64_t *gt_off,
+                            const int64_t *dt_off, const int64_t *ov_off, const double *ov,
+                            const int32_t *gt_code, const int32_t *gt_dontcare, const double *gt_bbox,
+                            const double *gt_alpha, const int32_t *gt_occluded, const double *gt_truncated,
+                            const int32_t *dt_code, const double *dt_bbox, const double *dt_alpha,
+                            const double *dt_score, const dfu3d_eval_combo *combos, int32_t n_combo,
+                            int64_t n_gt, double *matched, int32_t *n_valid, void *stream);
+int dfu3d_eval_match_stats(int32_t metric, int32_t F, int32_t max_dt, const int64_t *gt_off,
+                           const int64_t *dt_off, const int64_t *ov_off, const double *ov,
+                           const int32_t *gt_code, const int32_t *gt_dontcare, const double *gt_bbox,
+                           const double *gt_alpha, const int32_t *gt_occluded, const double *gt_truncated,
+                           const int32_t *dt_code, const double *dt_bbox, const double *dt_alpha,
+                           const double *dt_score, const dfu3d_eval_combo *combos, int32_t n_combo,
+                           const double *thresholds, const int32_t *n_thresh, int32_t t_stride,
+                           int32_t compute_aos, int64_t *pr, double *sim, void *stream);
 
 /* ---- f-4: la_sampling of the ground-truth sampling augmentor (pcdet/datasets/augmentor/database_sampler_virtual.py:319-351)
  * A batch of B objects: float32 rows `points` (n_points, n_cols >= 3; x y z first), object b owns rows

@@ -1,0 +1,225 @@
+"""Row f-3, AP evaluation on the GPU (csrc/eval_stage.hip through dfu3d_amd/pcdet_kitti/eval.py) against golden G9 --
+the outputs of the reference's own eval.py -- and against the oracle on larger seeded sets."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import eval_cases  # noqa: E402
+
+from oracle import kitti_eval_oracle as KO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G9 = np.load(os.path.join(HERE, 'golden', 'g9_kitti_eval.npz'))
+CASES = {tag: spec[3] for tag, spec in eval_cases.GOLDEN_CASES.items()}
+
+
+def golden_annos(tag, side):
+    pre = '%s/%s/' % (tag, side)
+    return eval_cases.unpack({k[len(pre):]: G9[k] for k in G9.files if k.startswith(pre)})
+
+
+def check_overlaps(E, gts, dts, metric, min_overlaps):
+    """GPU overlap blocks against the oracle's; -> True when no overlap lies within 1e-4 of a threshold in use (then the
+    assignment cannot depend on float32 noise of the rotated overlap)."""
+    ev = E._Evaluator(gts, dts)
+    got = ev.frame_overlaps(metric)
+    safe = True
+    for f in range(len(gts)):
+        want = KO.frame_overlaps(gts[f], dts[f], metric)
+        assert got[f].shape == want.shape
+        if want.size == 0:
+            continue
+        tol = 1e-14 if metric == 0 else 2e-5
+        assert np.abs(got[f] - want).max() <= tol, (f, metric, np.abs(got[f] - want).max())
+        for mo in set(np.ravel(min_overlaps).tolist()):
+            safe = safe and not (np.abs(want - mo) < 1e-4).any()
+    return ev, safe
+
+
+@pytest.mark.parametrize('tag', sorted(CASES))
+@pytest.mark.parametrize('metric', [0, 1, 2])
+def test_eval_class_reproduces_the_reference(tag, metric):
+    from dfu3d_amd.pcdet_kitti import eval as E
+    gts, dts = golden_annos(tag, 'gt'), golden_annos(tag, 'dt')
+    cls = [KO.CLASS_NAMES.index(c) for c in CASES[tag]]
+    mo = KO.official_min_overlaps()[:, :, cls]
+    aos = any(len(d['alpha']) and d['alpha'][0] != -10 for d in dts) and metric == 0
+    ev, safe = check_overlaps(E, gts, dts, metric, mo[:, metric, :])
+    assert safe, "regenerate the case: an overlap sits on a threshold"
+    r = E.eval_class(gts, dts, cls, (0, 1, 2), metric, mo, aos, _evaluator=ev)
+    for key, tol in (('recall', 1e-12), ('precision', 1e-12), ('orientation', 1e-9)):
+        want = G9['%s/metric%d/%s' % (tag, metric, key)]
+        assert r[key].shape == want.shape
+        np.testing.assert_allclose(r[key], want, rtol=0, atol=tol, equal_nan=True, err_msg=key)
+
+
+@pytest.mark.parametrize('tag', sorted(CASES))
+def test_official_result_reproduces_the_reference(tag):
+    from dfu3d_amd.pcdet_kitti import eval as E
+    gts, dts = golden_annos(tag, 'gt'), golden_annos(tag, 'dt')
+    text, got = E.get_official_eval_result(gts, dts, CASES[tag])
+    keys = [str(k) for k in G9['%s/official/keys' % tag]]
+    assert sorted(got) == keys
+    np.testing.assert_allclose([got[k] for k in keys], G9['%s/official/values' % tag], rtol=0, atol=1e-9, equal_nan=True)
+    assert text == str(G9['%s/official/text' % tag])
+
+
+def test_larger_set_matches_the_oracle_cell_by_cell():
+    from dfu3d_amd.pcdet_kitti import eval as E
+    classes = ['Car', 'Pedestrian']
+    cls = [KO.CLASS_NAMES.index(c) for c in classes]
+    mo = np.stack([np.full((3, 2), 0.7), np.full((3, 2), 0.5), np.full((3, 2), 0.3)], 0)
+    gts, dts = eval_cases.make_annos(77, 60, max_gt=12, extra_dt=10, classes=tuple(classes))
+    for metric in (0, 1, 2):
+        ev, safe = check_overlaps(E, gts, dts, metric, mo[:, metric, :])
+        r = E.eval_class(gts, dts, cls, (0, 1, 2), metric, mo, metric == 0, _evaluator=ev)
+        want = KO.eval_class(gts, dts, cls, (0, 1, 2), metric, mo, metric == 0)
+        if not safe:
+            continue                                      # an overlap within 1e-4 of a threshold: counts may differ by one
+        for key, tol in (('recall', 1e-12), ('precision', 1e-12), ('orientation', 1e-9)):
+            np.testing.assert_allclose(r[key], want[key], rtol=0, atol=tol, equal_nan=True, err_msg='%s metric %d' % (key, metric))
+    # difficulty 3 (no level rules, get_range_eval_result) on the 2-D metric
+    r = E.eval_class(gts, dts, cls, (3,), 0, mo, False)
+    want = KO.eval_class(gts, dts, cls, (3,), 0, mo, False)
+    np.testing.assert_allclose(r['precision'], want['precision'], rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_counts_and_matched_scores_per_cell():
+    """The two device passes on their own: matched scores / valid counts and tp / fp / fn against the oracle's loops."""
+    from dfu3d_amd import stages as st
+    from dfu3d_amd.pcdet_kitti import eval as E
+    gts, dts = eval_cases.make_annos(5, 25, max_gt=10, extra_dt=8, classes=('Car', 'Truck'))
+    ev = E._Evaluator(gts, dts)
+    metric = 0
+    ov = ev.overlaps(metric)
+    combos = [(0, 0, 0.5), (0, 2, 0.7), (1, 1, 0.5), (8, 1, 0.5)]
+    matched, n_valid = st.eval_match_scores(ev.fr, ov, metric, combos)
+    matched, n_valid = matched.cpu().numpy(), n_valid.cpu().numpy()
+    th = np.array([[0.0, 0.3, 0.6, 0.9]] * len(combos))
+    pr, sim = st.eval_match_stats(ev.fr, ov, metric, combos, torch.from_numpy(th).cuda(),
+                                  torch.full((len(combos),), 4, dtype=torch.int32).cuda(), True)
+    pr, sim = pr.cpu().numpy(), sim.cpu().numpy()
+    goff = ev.fr.gt_off.cpu().numpy()
+    for c, (cls, diff, mo) in enumerate(combos):
+        want_pr = np.zeros((4, 3), np.int64)
+        for f in range(len(gts)):
+            nv, ig, idt, dc = KO.clean_data(gts[f], dts[f], cls, diff)
+            assert n_valid[c, f] == nv
+            o = KO.frame_overlaps(gts[f], dts[f], metric)
+            args = (o, gts[f]['alpha'], dts[f]['bbox'], dts[f]['alpha'], dts[f]['score'], ig, idt, dc, metric, mo)
+            sc = KO.compute_statistics(*args)[4]
+            row = matched[c, goff[f]:goff[f + 1]]
+            assert np.array_equal(row[:len(sc)], np.array(sc)) and np.isnan(row[len(sc):]).all()
+            for t in range(4):
+                tp, fp, fn, s, _ = KO.compute_statistics(*args, thresh=th[c, t], compute_fp=True, compute_aos=True)
+                want_pr[t] += (tp, fp, fn)
+                assert abs(sim[c, f, t] - (s if s != -1 else 0.0)) < 1e-12
+        assert np.array_equal(pr[c], want_pr), (c, pr[c], want_pr)
+
+
+def test_overlap_blocks_orientation_and_limits():
+    from dfu3d_amd import stages as st
+    from dfu3d_amd.pcdet_kitti import eval as E
+    gts, dts = eval_cases.make_annos(9, 6, max_gt=5, extra_dt=3, classes=('Car',), empty_frames=False)
+    ov, parts, n_gt, n_dt = E.calculate_iou_partly(gts, dts, 0)
+    assert parts is None and list(n_gt) == [len(g['name']) for g in gts] and list(n_dt) == [len(d['name']) for d in dts]
+    for f in range(len(gts)):
+        assert np.abs(ov[f] - KO.image_box_overlap(gts[f]['bbox'], dts[f]['bbox'])).max(initial=0) < 1e-14
+    # a frame with more detections than the evaluator takes is refused, not truncated
+    big = {k: np.repeat(np.asarray(v)[:1], st.EVAL_MAX_DET + 1, axis=0) for k, v in dts[0].items()} if len(dts[0]['name']) \
+        else None
+    if big is not None:
+        with pytest.raises(st.Dfu3dError):
+            E.eval_class(gts[:1], [big], [0], (0,), 0, KO.official_min_overlaps()[:, :, [0]])
+    # no detections at all / no ground truth at all
+    none = [{k: np.asarray(v)[:0] for k, v in d.items()} for d in dts]
+    r = E.eval_class(gts, none, [0], (0, 1, 2), 2, KO.official_min_overlaps()[:, :, [0]])
+    assert np.all(r['precision'] == 0)
+    r = E.eval_class([{k: np.asarray(v)[:0] for k, v in g.items()} for g in gts], dts, [0], (0, 1, 2), 1,
+                     KO.official_min_overlaps()[:, :, [0]])
+    assert np.all(r['precision'] == 0)
+
+
+def test_predictions_to_result_files_to_ap(tmp_path):
+    """The loop's evaluation step end to end: LiDAR boxes -> generate_prediction_dicts -> result files -> label readers
+    -> evaluator.  Predictions equal to the ground truth score 100 at every level; shifted ones do not."""
+    from dfu3d_amd import kitti_io, synth
+    from dfu3d_amd.calibration import Calibration
+    from dfu3d_amd.pcdet_kitti import gt_database, kitti_common, kitti_dataset
+    rng = np.random.default_rng(4)
+    cal = synth.make_calibration(35.0, 900, 1600, rng)
+    cpath = os.path.join(str(tmp_path), 'calib.txt')
+    kitti_io.write_calib(cpath, cal.P2, cal.R0, cal.V2C)
+    calib = Calibration(cpath)
+    names = ['Car', 'Pedestrian']
+    frames = 30
+    batch = {'frame_id': ['%06d' % f for f in range(frames)], 'calib': [calib] * frames,
+             'image_shape': [np.array([900, 1600])] * frames}
+    preds = []
+    for f in range(frames):
+        n = 4
+        boxes = np.zeros((n, 7), np.float32)
+        depth = rng.uniform(12, 40, n)                            # in front of the camera, inside its field of view
+        cam_loc = np.stack([depth * rng.uniform(-0.25, 0.25, n), rng.uniform(1.4, 1.8, n), depth], 1).astype(np.float32)
+        boxes[:, 3:6] = np.array([4.2, 1.9, 1.6]) * rng.uniform(0.9, 1.1, (n, 3))
+        boxes[:, 0:3] = gt_database.rect_to_lidar(calib, cam_loc)
+        boxes[:, 2] += boxes[:, 5] / 2
+        boxes[:, 6] = rng.uniform(-3, 3, n)
+        preds.append({'pred_boxes': torch.from_numpy(boxes), 'pred_scores': torch.from_numpy(rng.uniform(0.3, 1, n).astype(np.float32)),
+                      'pred_labels': torch.from_numpy(np.array([1, 1, 1, 2]))})
+    gt_dir, dt_dir = tmp_path / 'gt', tmp_path / 'dt'
+    gt_dir.mkdir(), dt_dir.mkdir()
+    annos = kitti_dataset.generate_prediction_dicts(batch, preds, names, output_path=gt_dir)
+    assert len(annos) == frames and annos[0]['name'].tolist() == ['Car', 'Car', 'Car', 'Pedestrian']
+    gts = kitti_common.get_label_annos(str(gt_dir))
+    for g, a in zip(gts, annos):                                  # the file round trip keeps four decimals
+        g['occluded'][:] = 0
+        g['truncated'][:] = 0.0
+        assert np.abs(g['location'] - a['location']).max() < 1e-4 and np.abs(g['dimensions'] - a['dimensions']).max() < 1e-4
+        assert (g['bbox'][:, 3] - g['bbox'][:, 1]).min() > 40       # visible at every level
+    text, ap = kitti_dataset.evaluation(annos, names, gts)
+    assert all(abs(v - 100.0) < 1e-6 for k, v in ap.items() if k.startswith('Car')), ap
+    assert 'Car AP_R40@0.50, 0.50, 0.50:' in text
+    for p in preds:
+        p['pred_boxes'] = p['pred_boxes'] + torch.tensor([3.0, 0, 0, 0, 0, 0, 0])
+    shifted = kitti_dataset.generate_prediction_dicts(batch, preds, names, output_path=dt_dir)
+    _, ap2 = kitti_dataset.evaluation(shifted, names, gts)
+    assert ap2['Car_3d/moderate_R40'] < 50.0
+
+
+def test_model_nms_utils_against_the_checker():
+    from oracle import iou3d_oracle as I
+    from dfu3d_amd.pcdet_kitti import model_nms_utils as M
+    rng = np.random.default_rng(21)
+    n = 400
+    boxes = np.zeros((n, 7), np.float32)
+    boxes[:, 0:2] = rng.uniform(-25, 25, (n, 2))
+    boxes[:, 3:6] = np.array([4.0, 1.8, 1.6]) * rng.uniform(0.8, 1.2, (n, 3))
+    boxes[:, 6] = rng.uniform(-3, 3, n)
+    scores = (rng.permutation(n).astype(np.float32) + 1) / (n + 1)
+    cfg = {'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.2, 'NMS_PRE_MAXSIZE': 300, 'NMS_POST_MAXSIZE': 50}
+    tb, ts = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    sel, sc = M.class_agnostic_nms(ts, tb, cfg, score_thresh=0.1)
+    above = np.nonzero(scores >= 0.1)[0]
+    keep, iou = I.nms(boxes[above], scores[above], 0.2, pre_maxsize=300)
+    want = above[keep[:50]]
+    if (np.abs(iou - 0.2) < 1e-5).any() and not np.array_equal(sel.cpu().numpy(), want):
+        pytest.skip("a pair at the threshold")
+    assert np.array_equal(sel.cpu().numpy(), want) and np.array_equal(sc.cpu().numpy(), scores[want])
+    # per-class columns
+    cls_scores = torch.stack([ts, ts.flip(0)], dim=1)
+    s2, l2, b2 = M.multi_classes_nms(cls_scores, tb, cfg, score_thresh=0.1)
+    assert s2.shape[0] == l2.shape[0] == b2.shape[0] and set(l2.cpu().tolist()) == {0, 1}
+    first = (l2 == 0).sum().item()
+    assert np.array_equal(b2[:first].cpu().numpy(), boxes[want])
+    # class-specific thresholds
+    labels = torch.from_numpy((np.arange(n) % 2).astype(np.int64)).cuda()
+    cfg3 = {'NMS_THRESH': [0.2, 0.5], 'NMS_PRE_MAXSIZE': [300, 300], 'NMS_POST_MAXSIZE': [50, 50]}
+    sel3, _ = M.class_specific_nms(ts, tb, labels, cfg3, score_thresh=0.1)
+    lab = labels.cpu().numpy()[sel3.cpu().numpy()]
+    assert (np.diff(lab) >= 0).all() and len(sel3) > 0
