@@ -51,10 +51,10 @@ def main():
         ev1.record()
         combos = [(c, l, float(mo[k, metric, m])) for m, c in enumerate(cls) for l in range(3) for k in range(3)]
         matched, n_valid = st.eval_match_scores(ev.fr, ov, metric, combos)
-        ev2.record()
         th = torch.rand((len(combos), 41), dtype=torch.float64, device='cuda').sort(dim=1, descending=True)[0]
-        st.eval_match_stats(ev.fr, ov, metric, combos, th, torch.full((len(combos),), 41, dtype=torch.int32, device='cuda'),
-                            metric == 0)
+        nth = torch.full((len(combos),), 41, dtype=torch.int32, device='cuda')
+        ev2.record()
+        st.eval_match_stats(ev.fr, ov, metric, combos, th, nth, metric == 0)
         ev3.record()
         torch.cuda.synchronize()
         print("  metric %d: overlaps %.3f ms (%d pairs), matched scores %.3f ms, statistics %.3f ms (%d cells x 41 thresholds)"
