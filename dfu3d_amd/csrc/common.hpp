@@ -163,7 +163,10 @@ __device__ __forceinline__ Recip make_recip(const ViewCalib &c) {
 }
 __device__ __forceinline__ double div_reused(double a, double b, double r) {
   const double q0 = a * r;
-  if (__builtin_expect(!(fabs(q0) < 1e300) || q0 == 0.0 || !(fabs(q0) > 1e-290), 0)) return a / b;
+  // the shortcut holds for 2^-900 <= |q0| < 2^900; zero, tiny, huge and non-finite quotients take the division.
+  // One unsigned range test on the exponent field (32-bit integer work: fp64 compares issue at half rate)
+  const uint32_t hi = (uint32_t)__double2hiint(q0) & 0x7FFFFFFFu;
+  if (__builtin_expect(hi - 0x07B00000u >= 0x78400000u - 0x07B00000u, 0)) return a / b;
   const double rem = fma(-q0, b, a);
   return fma(rem, r, q0);
 }

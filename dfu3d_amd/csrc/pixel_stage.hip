@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t pixel_bin(const ViewCalib &c, const Recip &r
   const int it = (int)ct - g.t_lo, ip = (int)cp - g.p_lo;
   if (it < 0 || it >= g.t_n || ip < 0 || ip >= g.p_n) { range_err = true; return NOBIN; }
   key = (key_axis == 2) ? z : y;
-  if (key == 0.0) key = 0.0;
+  key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   return (uint32_t)(it * g.p_n + ip);
 }
 
@@ -130,7 +130,7 @@ __device__ __forceinline__ double pixel_key(const ViewCalib &c, const Recip &rc,
   double x, y, z;
   pixel_to_lidar(c, rc, col, row, d, x, y, z);
   double key = (key_axis == 2) ? z : y;
-  if (key == 0.0) key = 0.0;
+  key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   return key;
 }
 
@@ -249,9 +249,8 @@ __global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float4 *__restrict__ 
 // as TB_AMBIG through the comparisons)
 __device__ __forceinline__ int tab_bin(const float4 *__restrict__ tab, float q0, float inv_w, int J, float q,
                                        float delta) {
-  int j = (int)((q - q0) * inv_w);
-  j = min(max(j, 0), J - 1);
-  const float4 e = tab[j];
+  const int j = (int)((q - q0) * inv_w);
+  const float4 e = tab[min((unsigned)max(j, 0), (unsigned)(J - 1))];
   const int kn = __float_as_int(e.w);
   const bool above = q > e.x + delta;
   const bool low = q < e.y - delta;
@@ -364,7 +363,7 @@ __device__ __forceinline__ void classify_fast(const FastCal &fc, const dfu3d_bin
     amb = amb || !(fabsf(xf[k]) > 8.0f * err[k] + 1e-20f);               // the sign of x decides the branch of atan(y/x)
     const float qa = yf[k] * __builtin_amdgcn_rcpf(fabsf(xf[k]) + fabsf(yf[k]));
     const float qp = xf[k] < 0.0f ? -qa : qa;
-    const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * rsqrtf(s2));
+    const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * __builtin_amdgcn_rsqf(s2));   // (s2 > 1e-4 or amb)
     amb = amb || kt == TB_AMBIG || kp == TB_AMBIG;
     const int itk = (amb ? g.t_lo : kt) - g.t_lo, ipk = (amb ? g.p_lo : kp) - g.p_lo;   // |kt|, |kp| <= 1e9: no wrap
     amb = amb || itk < 0 || itk >= g.t_n || ipk < 0 || ipk >= g.p_n;
@@ -388,7 +387,7 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
   ip_out = ip[0];
   if (want_key && res[0] < AMBIG) {
     key = pixel_to_lidar_axis(c, rc, kc, col, row, d);
-    if (key == 0.0) key = 0.0;
+    key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   }
   return res[0];
 }
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
         bins[r][k] = b;
         tmin = min(tmin, its[r][k]); pmin = min(pmin, ips[r][k]);
         keys[r][k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
-        if (keys[r][k] == 0.0) keys[r][k] = 0.0;
+        keys[r][k] += 0.0;                                    // -0.0 -> +0.0, every other value unchanged
       }
     }
   }
@@ -679,7 +678,7 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
   double x, yy, z;
   pixel_to_lidar(X.c, X.rc, col, row, d_pix, x, yy, z);
   double key = (X.key_axis == 2) ? z : yy;
-  if (key == 0.0) key = 0.0;
+  key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
   if (cw > (uint32_t)X.max_points || ordered_key(key) != e_kmin) {
     const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
