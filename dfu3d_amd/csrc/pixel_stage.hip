@@ -399,6 +399,12 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 // atomics per touched bin instead of one per pixel (6x fewer for dense depth).
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
+#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of thread 0 per phase of k_bp_bin, summed over workgroups (tools/p1_timing.py) */
+__device__ unsigned long long g_p1_dbg[16];
+#define P1_T(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_p1_dbg[k], (unsigned long long)(t_ - p1_t)); p1_t = t_; } } while (0)
+#else
+#define P1_T(k) do {} while (0)
+#endif
 constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
                                                    // the window set-up, its flush and the reductions are paid once per 2048 pixels
 __global__ __launch_bounds__(PB) void k_bp_bin(
@@ -412,6 +418,10 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
   __shared__ int s_namb, s_base, s_t0, s_p0;
+#ifdef DFU3D_DBG_GRID_TIMING
+  long long p1_t = clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_p1_dbg[8], 1ull);
+#endif
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
@@ -435,6 +445,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   };
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
+  P1_T(0);                                        // set-up: records, window reset, barrier
   uint32_t bins[RPT][PPT];
   double keys[RPT][PPT];
   int its[RPT][PPT], ips[RPT][PPT];
@@ -469,6 +480,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       }
     }
   }
+  P1_T(1);                                        // depth loads, classification, exact keys (thread 0's wave)
   // window origin: wave minimum first (all lanes), then one LDS atomic per wave -- 256 lanes on two
   // addresses serialise
 #pragma unroll
@@ -479,6 +491,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
+  P1_T(2);                                        // origin reduction + barrier (= waiting for the slowest wave's classification)
   // runs of equal bins among a thread's four consecutive pixels are merged first
   auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
                     unsigned long long cm) {
@@ -527,23 +540,37 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     }
     if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
   }
+  P1_T(3);                                        // run merging + LDS window atomics
   __syncthreads();
-  // flush the window: one set of global atomics per touched bin
-  for (int w = threadIdx.x; w < WIN_T * WIN_P; w += PB) {
-    const uint32_t cw = s_cnt[w];
+  P1_T(4);                                        // barrier
+  // flush the window: one set of global atomics per touched bin.  The atomic on `first` returns the value it replaced
+  // (the bit-map update below needs it): all of a thread's atomics are issued before the first returned value is looked
+  // at -- one memory round trip per workgroup instead of one per slot of the thread.
+  constexpr int FL = (WIN_T * WIN_P + PB - 1) / PB;
+  uint32_t f_new[FL], f_old[FL];
+#pragma unroll
+  for (int i = 0; i < FL; i++) {
+    const int w = threadIdx.x + i * PB;
+    f_new[i] = NOBIN; f_old[i] = 0u;
+    const uint32_t cw = (w < WIN_T * WIN_P) ? s_cnt[w] : 0u;
     if (cw == 0u) continue;
 #ifdef DFU3D_DBG_P1_NO_FLUSH          /* timing experiment only: results are wrong */
     continue;
 #endif
     const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
     const int64_t e = tb0 + b;
+    f_new[i] = s_first[w];
     atomicAdd(&T.cnt[e], cw);
-    const uint32_t oldf = atomicMin(&T.first[e], s_first[w]);
+    f_old[i] = atomicMin(&T.first[e], f_new[i]);
     atomicMin(&T.kmin[e], s_kmin[w]);
     atomicMin(&T.combo[e], s_combo[w]);
-    if (oldf > s_first[w]) new_first(s_first[w], oldf);
   }
+#pragma unroll
+  for (int i = 0; i < FL; i++)
+    if (f_old[i] > f_new[i]) new_first(f_new[i], f_old[i]);      // (f_new = NOBIN, the largest value, for an idle slot)
+  P1_T(5);                                        // flush loop (issue of the global atomics)
   __syncthreads();
+  P1_T(6);                                        // barrier
   // the workgroup's own bits: contiguous 128-byte wave atomics, one per bit-map tile (XOR: other tiles may already
   // have toggled here)
   if (threadIdx.x < 32 * RPT && s_bits[threadIdx.x]) {
@@ -552,11 +579,23 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
       atomicXor(&bitmap_v[((size_t)(ty * RPT + sub) * tiles_x + tx) * 32 + (threadIdx.x & 31)], s_bits[threadIdx.x]);
   }
   const int na = s_namb;
+  P1_T(7);                                        // bit-map flush
   if (na == 0) return;
   if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
   __syncthreads();
   for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + s_base + i] = s_amb[i];
 }
+
+#ifdef DFU3D_DBG_GRID_TIMING
+extern "C" int dfu3d_debug_p1_timing(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_p1_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_p1_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+#endif
 
 // Tier 2: the undecided pixels, full fp64 classification (pixel_bin).
 __global__ __launch_bounds__(256) void k_bp_bin_amb(
