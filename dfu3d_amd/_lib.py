@@ -133,6 +133,11 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(dfu3d_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_version():
+    """DFU3D_VERSION of include/dfu3d.h."""
+    return int(re.search(r"#define\s+DFU3D_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+
+
 def lib():
     """Load (building in-tree if needed) libdfu3d_hip.so; raises if impossible."""
     global _LIB
