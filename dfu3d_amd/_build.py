@@ -56,6 +56,8 @@ VARIANTS = {
     "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],
     "grid_timing": ["-DDFU3D_DBG_GRID_TIMING"],
     "grid_split": ["-DDFU3D_GRID_SPLIT_LAUNCH"],
+    # radius filter, phase B: the points of two candidate ranges requested together (measurement for DESIGN §10 item 1)
+    "rf2": ["-DDFU3D_RF_RANGES_PER_STEP=2"],
 }
 
 

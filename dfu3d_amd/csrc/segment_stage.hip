@@ -520,6 +520,10 @@ __device__ __forceinline__ float box_dist2(float qx, float qy, float qz, float l
 }
 
 // Phase B: one wave per queued query.
+#ifndef DFU3D_RF_RANGES_PER_STEP
+#define DFU3D_RF_RANGES_PER_STEP 1
+#endif
+constexpr int RF_RQ = DFU3D_RF_RANGES_PER_STEP;   // candidate ranges whose points are requested together (tuning constant; 2 is the `rf2` dev build)
 __global__ __launch_bounds__(256) void k_radius_resolve(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     const float4 *__restrict__ pq, const float *__restrict__ boxes, const long long *__restrict__ seg_base,
@@ -579,30 +583,37 @@ __global__ __launch_bounds__(256) void k_radius_resolve(
                box_dist2(qf.x, qf.y, qf.z, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w) <= hi2;
       }
       unsigned long long m = __ballot(cand);
-      while (m && cnt <= nb) {                       // uniform: the candidate ranges of this step, one by one
-        const int k = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const long long c0 = (r0 + k) << (BOX_SHIFT - 6);
-        // the eight chunks of the range are requested together (one memory round trip, not eight in a row: a query's
+      while (m && cnt <= nb) {                       // uniform: the candidate ranges of this step, RF_RQ at a time
+        // the eight chunks of a range are requested together (one memory round trip, not eight in a row: a query's
         // candidate ranges were a chain of dependent loads, and the kernel's 0.24 ms was that chain)
         constexpr int RC = 1 << (BOX_SHIFT - 6);
-        float4 o[RC];
-        bool in[RC];
+        long long c0[RF_RQ];
+        bool have[RF_RQ];
 #pragma unroll
-        for (int u = 0; u < RC; u++) {
-          const long long g = ((c0 + u) << 6) + lane;
-          in[u] = (g >= base) && (g < end) && (c0 + u != c_own);
+        for (int q = 0; q < RF_RQ; q++) {
+          have[q] = m != 0ull;
+          const int k = have[q] ? __ffsll((long long)m) - 1 : 0;
+          m &= m - 1ull;                             // (0 stays 0)
+          c0[q] = (r0 + k) << (BOX_SHIFT - 6);
+        }
+        float4 o[RF_RQ * RC];
+        bool in[RF_RQ * RC];
+#pragma unroll
+        for (int u = 0; u < RF_RQ * RC; u++) {
+          const long long c = c0[u / RC] + (u % RC);
+          const long long g = (c << 6) + lane;
+          in[u] = have[u / RC] && (g >= base) && (g < end) && (c != c_own);
           o[u] = in[u] ? pq[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
-        for (int u = 0; u < RC; u++) {
+        for (int u = 0; u < RF_RQ * RC; u++) {
           bool hit = false;
           if (in[u]) {
             const float dx = qf.x - o[u].x, dy = qf.y - o[u].y, dz = qf.z - o[u].z;
             const float d2 = dx * dx + dy * dy + dz * dz;
             hit = d2 < lo2;
             if (!hit && !(d2 > hi2)) {                 // too close to call in float32
-              const long long g = ((c0 + u) << 6) + lane;
+              const long long g = ((c0[u / RC] + (u % RC)) << 6) + lane;
               const double ex = x - px[g], ey = y - py[g], ez = z - pz[g];
               double d = ex * ex;
               d += ey * ey;
