@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void k_eval_match(
   const long long g0 = gt_off[f], d0 = dt_off[f];
   const int G = (int)(gt_off[f + 1] - g0), D = (int)(dt_off[f + 1] - d0);
   const double *ovf = ov + ov_off[f];
+  if (D > EV_MAX_DET || D < 0 || G < 0) return;                // (uniform) offsets that contradict max_dt: touch nothing
   const int W = (D + 31) >> 5;
   for (int w = 0; w < W; w++) s_assigned[w * 64 + lane] = 0u;
   for (int j = lane; j < D; j += 64) s_idt[j] = (signed char)ignored_dt(dt_code[d0 + j], dt_bbox + 4 * (d0 + j), cb);
