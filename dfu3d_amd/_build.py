@@ -26,24 +26,51 @@ def sources():
 
 
 def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = (sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
+    return _stale(OUT)
+
+
+def _deps():
+    return (sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
             + [os.path.join(INCLUDE, "dfu3d.h")])
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _stale(out):
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in _deps())
+
+
+def _compile(out, extra, verbose):
+    """hipcc into a temporary file next to `out`, then an atomic rename, all under an exclusive lock: every rank of
+    a multi-rank launch may find the library stale at the same moment (fresh checkout, copy without time stamps);
+    one of them compiles, the others wait on the lock and find the finished file -- nobody ever dlopens a
+    half-written code object."""
+    import fcntl
+    import tempfile
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not _stale(out) and not extra.get("force"):
+                return out
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            fd, tmp = tempfile.mkstemp(prefix=os.path.basename(out) + ".", suffix=".tmp", dir=os.path.dirname(out))
+            os.close(fd)
+            cmd = [hipcc] + FLAGS + extra.get("flags", []) + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, out)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("DFU3D_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+    return _compile(OUT, {"force": force, "flags": os.environ.get("DFU3D_EXTRA_HIPCC_FLAGS", "").split()}, verbose)
 
 
 # Variant builds for tests: the same sources with a debug switch, next to the product library.
@@ -56,6 +83,16 @@ VARIANTS = {
     "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],
     "grid_timing": ["-DDFU3D_DBG_GRID_TIMING"],
     "grid_split": ["-DDFU3D_GRID_SPLIT_LAUNCH"],
+    # radius filter: cycles per phase of k_rf_stream / k_rf_resolve (tools/rf_timing.py)
+    "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
+    # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
+    "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
+    "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
+    # radius filter: cycles per phase of k_rf_stream / k_rf_resolve (tools/rf_timing.py)
+    "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
+    # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
+    "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
+    "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
     # radius filter, phase B: the points of two candidate ranges requested together (measurement for DESIGN §10 item 1)
     "rf2": ["-DDFU3D_RF_RANGES_PER_STEP=2"],
 }
@@ -67,16 +104,9 @@ def variant_path(name):
 
 def build_variant(name, force=False, verbose=False):
     out = variant_path(name)
-    deps = (sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
-            + [os.path.join(INCLUDE, "dfu3d.h")])
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+    if not force and not _stale(out):
         return out
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + VARIANTS[name] + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out
+    return _compile(out, {"force": force, "flags": VARIANTS[name]}, verbose)
 
 
 if __name__ == "__main__":

@@ -86,6 +86,8 @@ SIGNATURES = {
                                      c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfu3d_segments_scratch_words": (c_i64, [c_i32, c_i32, c_i32]),
+    "dfu3d_rf_shadow_bytes": (c_i64, [c_i64]),
+    "dfu3d_rf_queue_ints": (c_i64, [c_i64]),
     "dfu3d_radius_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i64, _P, _P, _P, _P, _P,
                                     c_i32, _P]),
     "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,

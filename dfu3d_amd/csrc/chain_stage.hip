@@ -68,7 +68,7 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
   t.base_a = (int64_t *)take(8 * S); t.base_b = (int64_t *)take(8 * S); t.base_ab = (int64_t *)take(8 * 2 * S);
   t.cnt_a = (int32_t *)take(4 * S); t.cnt_b = (int32_t *)take(4 * S); t.cnt_all = (int32_t *)take(4 * S);
   t.cnt_ab = (int32_t *)take(4 * 2 * S); t.tile_off = (int32_t *)take(4 * (2 * S + 2));
-  t.queue = (int32_t *)take(4 * (2 + P)); t.stat_enable = (int32_t *)take(4 * S);
+  t.queue = (int32_t *)take(4 * DFU3D_RF_QUEUE_INTS(P)); t.stat_enable = (int32_t *)take(4 * S);
   t.shadow = take(DFU3D_SHADOW_BYTES(P));
   t.chunk_cnt = (int32_t *)take(4 * dfu3d_segments_scratch_words(c->V, c->cap_n, c->cap_vox));
   t.rad_ab = (double *)take(8 * 2 * S);
@@ -135,7 +135,7 @@ extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
       return up(V * z->table_entries * DFU3D_TABLE_ENTRY_BYTES) + up(4 * pw) + up(4 * bw);
     }
     case DFU3D_STAGE_RADIUS_FILTER:                      /* shadow, tile_off, flags, queue (2S joint segments) */
-      return P > 0 ? up(DFU3D_SHADOW_BYTES(P)) + up(4 * (2 * S + 1)) + up(P) + up(4 * (2 + P)) : DFU3D_EINVAL;
+      return P > 0 ? up(DFU3D_SHADOW_BYTES(P)) + up(4 * (2 * S + 1)) + up(P) + up(4 * DFU3D_RF_QUEUE_INTS(P)) : DFU3D_EINVAL;
     case DFU3D_STAGE_STAT_FILTER:                        /* tile_off, flags, mean_d */
       return P > 0 ? up(4 * (S + 1)) + up(P) + up(8 * P) : DFU3D_EINVAL;
     case DFU3D_STAGE_BALLQUERY_FUSE:                     /* tile_off, flags */

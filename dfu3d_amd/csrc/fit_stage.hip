@@ -20,7 +20,6 @@ constexpr int CT = 512;            // threads per clustering workgroup
 constexpr int GRP = 32;            // points per summary / bounding-box group
 constexpr int BLK = 32;            // groups per block (1024 points): second pruning level
 constexpr int PAIR_SMALL = 32;     // grid clustering: cell runs up to this length are paired by a single lane
-constexpr int GRID_LONG_N = 8192;  // grid clustering: instances above this size get 1024 threads
 constexpr int GU = 4;              // grid clustering: points per thread and step of a sweep over the instance
 constexpr int SMALL_N = 4096;      // segments up to this size: 32-bit parents, 20 KB of LDS
 constexpr int LARGE_N = 61440;     // up to this size: 16-bit parents in LDS (120 KB)

@@ -316,28 +316,44 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 // the arithmetic) can do; whatever is not certain is decided from the fp64 pool with the
 // reference's predicate d2 < r2 (Open3D / nanoflann, self included).
 //
-// Phase A (k_radius_flags) streams the shadow linearly over the used part of the pool, 2048
-// positions per workgroup, all of a wave's loads issued up front.  A query is tested against
-// itself and its two list neighbours (lane^1, lane^2 -- the lists are in pixel / sweep order,
-// so list neighbours are spatial neighbours; this settles ~98 % for nb_points = 1), then, if a
-// lane of the wave is still undecided, against eight of the wave's points broadcast as scalar
-// operands (v_readlane).  What is still undecided is kept in an LDS list of the workgroup and
-// tried pairwise against the other undecided points of the workgroup (an outlier's neighbours
-// are usually other outliers a few dozen list positions away).  The rest -- isolated points and
-// the rare uncertain comparisons -- goes to phase B through one global atomic per workgroup.
-// Phase A also leaves, per wave range (512 consecutive pool positions), two bounding boxes: one of the
-// points it decided and one of the points it could not decide (outliers: kept apart so that they do not
-// blow up the first).  Phase B (k_radius_resolve): one wave per queued query tests its own 64-chunk, then
-// sweeps the BOXES of its segment (64 ranges = 32 k positions per step, a lane each) and tests the points
-// of the few ranges whose boxes come within the radius: float32 shadow with certain-hit / certain-miss
-// bounds, fp64 for the pairs in between.  Every point of the segment lies in one of the two boxes of its
-// range, so nothing is missed.
+// Phase A (k_rf_stream) streams the shadow linearly over the used part of the pool: 2048 positions
+// per workgroup, 512 per wave, all eight loads of a wave issued up front, 64 VGPRs (eight workgroups
+// per compute unit).  A point is tested against its two LIST neighbours (lane ^ 1, lane ^ 2 of its
+// 64-chunk, exchanged with DPP quad permutes -- the lists are in pixel / sweep order, so list
+// neighbours are spatial neighbours).  A point with such a neighbour is COHERENT; for nb_points = 1
+// it is decided at once (~98 % of a dense cloud).  The coherent points of a wave's 512 positions are
+// summarised by one bounding box; they are surface points, so the box is tight.  Everything else --
+// the INCOHERENT points (outliers, sparse sweeps) and, for nb_points > 1, the coherent points that
+// could not collect enough neighbours inside their wave -- goes to a list of the workgroup in LDS and is tried
+// pairwise there.  The workgroup then appends its incoherent points to the U LIST of their segment
+// (ulist[seg_base + k]: a dense array per segment, filled through one atomic per workgroup and
+// segment; at most as long as the segment, so it lives at the segment's own pool positions of a
+// second scratch array) and queues the points that are still undecided.
+// Phase B (k_rf_resolve): one wave per queued point counts from scratch: the incoherent points of its
+// segment (a coalesced sweep over the segment's U list) plus the coherent points of the ranges whose
+// box comes within the radius (a lane per box; a candidate range is re-read and the coherence of its
+// points re-derived with phase A's own function, so every point of the segment is counted exactly
+// once: through the U list or through its range).  A query is a chain of four to five round trips
+// whatever the size of its segment; round 2's version walked the candidate ranges of boxes that
+// outliers had blown up one after the other (0.23 ms for 0.14 % of the points).
 constexpr int RFB = 256;           // threads per phase-A workgroup
 constexpr int RF_IT = 8;           // 64-point chunks per wave
 constexpr int RF_WG = RFB * RF_IT; // pool positions per workgroup
-constexpr int RF_STRIDE = 8;       // phase A tries lanes 0, 8, 16, ... of the wave
-constexpr int RF_LIST = 512;       // undecided points a workgroup tries pairwise in LDS
+constexpr int RF_STRIDE = 8;       // nb_points > 1: lanes 0, 8, 16, ... of the chunk are broadcast
+#ifndef DFU3D_RF_OCC
+#define DFU3D_RF_OCC 8
+#endif
+constexpr int RF_OCC = DFU3D_RF_OCC;   // phase-A workgroups per compute unit the register allocation aims at
+#ifndef DFU3D_RF_PW
+#define DFU3D_RF_PW 4
+#endif
+constexpr int RF_PW = DFU3D_RF_PW;     // partners per step of the pairwise loop
+constexpr int RF_WLIST = 128;      // list of a wave in LDS
+constexpr int RF_LIST = RF_WLIST * (RFB / 64);
 constexpr uint32_t RF_NOSEG = 0xFFFFu;
+constexpr int BOX_FLOATS = 8;      // per range: min x y z, pad | max x y z, pad  (coherent points only)
+constexpr int BOX_SHIFT = 9;       // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
+constexpr float BOX_EMPTY = 3.0e38f;
 
 // bound on |float32 distance - true distance| for a query at (x,y,z) and neighbours within ~r of it:
 // each coordinate of either point carries <= 2^-24 relative rounding, the differences, squares and
@@ -374,141 +390,302 @@ __device__ __forceinline__ float wave_max63(float v) {
   v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
   return v;
 }
-constexpr int BOX_FLOATS = 12;               // per range: decided min xyz, max xyz | undecided min xyz, max xyz
-constexpr int BOX_SHIFT = 9;                 // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
-constexpr float BOX_EMPTY = 3.0e38f;
 
-__global__ __launch_bounds__(RFB) void k_radius_flags(
-    const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S,
-    uint8_t *__restrict__ flags, int *__restrict__ queue, float *__restrict__ boxes) {
-  __shared__ float4 s_pt[RF_LIST];
-  __shared__ int s_pos[RF_LIST], s_cnt[RF_LIST], s_q[RF_LIST];
-  __shared__ int s_n, s_nq, s_base;
+// v_min_f32 / v_max_f32 without the canonicalisation of both operands that fminf / fmaxf add (no NaN can occur here)
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// value of lane ^ 1 (CTRL 0xB1) / lane ^ 2 (CTRL 0x4E): quad permutes, every source lane is inside the quad.
+// All 64 lanes must be active where this is called.
+template <int CTRL>
+__device__ __forceinline__ float quad_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// The list-neighbour test, shared by phase A and by phase B's re-derivation (the two must agree bit for bit:
+// same expression, no contraction).  wb: the shadow word (segment | radius) -- equal words <=> same segment.
+__device__ __forceinline__ void rf_list_neighbours(float x, float y, float z, uint32_t wb, float thr2, bool &h1, bool &h2) {
+  const float x1 = quad_f<0xB1>(x), y1 = quad_f<0xB1>(y), z1 = quad_f<0xB1>(z);
+  const float x2 = quad_f<0x4E>(x), y2 = quad_f<0x4E>(y), z2 = quad_f<0x4E>(z);
+  const uint32_t w1 = quad_u<0xB1>(wb), w2 = quad_u<0x4E>(wb);
+  float dx = x - x1, dy = y - y1, dz = z - z1;
+  h1 = (w1 == wb) & (dx * dx + dy * dy + dz * dz < thr2);
+  dx = x - x2; dy = y - y2; dz = z - z2;
+  h2 = (w2 == wb) & (dx * dx + dy * dy + dz * dz < thr2);
+}
+__device__ __forceinline__ float4 rf_noseg_point() { return make_float4(0.f, 0.f, 0.f, __uint_as_float(RF_NOSEG << 16)); }
+
+// entry of a workgroup's LDS list: s_meta = position in the workgroup (11 bits) | incoherent << 11 | pending << 12 | count << 16
+constexpr uint32_t RFM_INCOH = 1u << 11, RFM_PEND = 1u << 12;
+constexpr int RF_QSHARDS = 64;             // the queue of undecided points has 64 parts, each with its counter on a line of its own
+constexpr int RF_QHDR = RF_QSHARDS * 16;   // (one counter took every workgroup's atomic: ~90 per microsecond is all one word does)
+constexpr int RF_LQ_CAP = 1 << 16;         // "long" queries: more candidate ranges than their wave scans itself
+constexpr int RF_ITEM_CAP = 1 << 20;       // their (query, range) work items
+constexpr int RF_INLINE_CAND = 2;
+constexpr int RF_WORK_HDR = 32;            // ints: [0] long queries, [16] work items
+
+struct RfScratch {
+  uint8_t *flags;
+  int *queue;               // [16 q]: length of part q; part q = queue + RF_QHDR + q * qcap
+  long long qcap;
+  float *dbox;              // BOX_FLOATS per range
+  float4 *ulist;            // (x, y, z, pool position) of the incoherent points of segment s at seg_base[s] + k, k < ucount[s]
+  int *work;                // RF_WORK_HDR counters | ucount (65536) | long-query records (4 ints) | work items (2 ints)
+  int *ucount;
+  const long long *seg_base;
+};
+__host__ __device__ inline long long rf_queue_part_cap(long long pool_cap) {
+  const long long nwg = (pool_cap + RF_WG - 1) / RF_WG;
+  return ((nwg + RF_QSHARDS - 1) / RF_QSHARDS) * RF_WG;
+}
+
+#ifdef DFU3D_DBG_RF_TIMING         /* dev build (tools/rf_timing.py): clock64 of thread 0 / lane 0 at the phase marks, one record per workgroup / wave (plain stores) */
+constexpr int RF_DBG_WG = 32768, RF_DBG_F = 12;
+__device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recB[16384 * RF_DBG_F];
+#define RF_T(k) do { const long long t_ = clock64(); rf_rec[k] += (unsigned int)(t_ - rf_t); rf_t = t_; } while (0)
+#else
+#define RF_T(k) do {} while (0)
+#endif
+
+template <bool NB1>
+__global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
+    const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S, RfScratch W) {
+  // the list of the workgroup: one part per wave (no atomics, a chunk's registers are free as soon as it is done)
+  __shared__ float4 s_pt[RF_LIST + 4];
+  __shared__ uint32_t s_meta[RF_LIST + 4];
+  __shared__ int s_hit[RF_LIST];
+  __shared__ int s_wn[RFB / 64], s_nq, s_base;
   long long n_used = n_max;
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
   const long long wg0 = (long long)blockIdx.x * RF_WG;
   if (wg0 >= n_used) return;
-  if (threadIdx.x == 0) { s_n = 0; s_nq = 0; }
-  __syncthreads();
+  if (threadIdx.x == 0) s_nq = 0;
+#pragma unroll
+  for (int k = 0; k < RF_LIST / RFB; k++) s_hit[k * RFB + threadIdx.x] = 0;
   const int lane = lane_id();
-  const long long w0 = wg0 + (long long)(threadIdx.x >> 6) * (64 * RF_IT);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the wave's addresses are SGPR base + lane)
+  const long long w0 = wg0 + (long long)wave * (64 * RF_IT);
+#ifdef DFU3D_DBG_RF_TIMING
+  unsigned int rf_rec[5] = {0};
+  long long rf_t = clock64();
+  const unsigned long long rf_r0 = wall_clock64();
+  auto rf_flush = [&](int np_) {
+    if (threadIdx.x == 0 && blockIdx.x < RF_DBG_WG) {
+      unsigned long long *o_ = g_rf_recA + (size_t)blockIdx.x * RF_DBG_F;
+      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
+      o_[5] = 1; o_[6] = (unsigned long long)np_; o_[8] = rf_r0; o_[9] = wall_clock64();
+    }
+  };
+#endif
+  // (positions at or beyond n_used are read all the same -- the scratch allocation extends megabytes beyond the
+  // shadow proper -- and marked "no segment" afterwards: eight loads, no branch between them)
   float4 p[RF_IT];
 #pragma unroll
-  for (int it = 0; it < RF_IT; it++) {
-    const long long i = w0 + it * 64 + lane;
-    p[it] = (i < n_used) ? pq[i] : make_float4(0.f, 0.f, 0.f, __uint_as_float(RF_NOSEG << 16));
-  }
-  float bx[BOX_FLOATS];                        // per lane, reduced over the wave once at the end
-#pragma unroll
-  for (int k = 0; k < BOX_FLOATS; k++) bx[k] = ((k % 6) < 3) ? BOX_EMPTY : -BOX_EMPTY;
+  for (int it = 0; it < RF_IT; it++) p[it] = pq[w0 + it * 64 + lane];
+  const int lim = (int)min(max(n_used - w0, 0ll), (long long)(64 * RF_IT));     // (scalar)
+  RF_T(0);
+  float lx = BOX_EMPTY, ly = BOX_EMPTY, lz = BOX_EMPTY, hx = -BOX_EMPTY, hy = -BOX_EMPTY, hz = -BOX_EMPTY;
+  int run = 0;                                    // listed points of this wave so far (wave-uniform)
 #pragma unroll
   for (int it = 0; it < RF_IT; it++) {
     const long long i = w0 + it * 64 + lane;
     const float x = p[it].x, y = p[it].y, z = p[it].z;
-    const uint32_t wb = __float_as_uint(p[it].w);
-    const uint32_t seg = wb >> 16;
+    const uint32_t wb = (it * 64 + lane < lim) ? __float_as_uint(p[it].w) : (RF_NOSEG << 16);
     const float r = __uint_as_float(wb << 16);
-    const bool valid = seg < (uint32_t)S;           // "no segment" mark, or a slot nobody wrote: never a point
-    if (__ballot(valid) == 0ull) continue;
+    const bool valid = (wb >> 16) < (uint32_t)S;    // "no segment" mark, or a slot nobody wrote: never a point
     const bool active = valid && (r > 0.0f);
-    if (valid && !active) flags[i] = (r == 0.0f) ? 1 : 0;     // r == 0: no filter; r < 0 / NaN: drop all
     const float thr2 = rf_certain_hit2(x, y, z, r);
+    bool h1, h2;
+    rf_list_neighbours(x, y, z, wb, thr2, h1, h2);
+    const bool coh = active && (h1 || h2);
+    bool listed, pend;
     int cnt = 1;                                    // the query itself (d = 0 < r^2)
-    {
-      const float x1 = __shfl_xor(x, 1, 64), y1 = __shfl_xor(y, 1, 64), z1 = __shfl_xor(z, 1, 64);
-      const float x2 = __shfl_xor(x, 2, 64), y2 = __shfl_xor(y, 2, 64), z2 = __shfl_xor(z, 2, 64);
-      const uint32_t s1 = (uint32_t)__shfl_xor((int)seg, 1, 64), s2 = (uint32_t)__shfl_xor((int)seg, 2, 64);
-      float dx = x - x1, dy = y - y1, dz = z - z1;
-      cnt += (s1 == seg && dx * dx + dy * dy + dz * dz < thr2) ? 1 : 0;
-      dx = x - x2; dy = y - y2; dz = z - z2;
-      cnt += (s2 == seg && dx * dx + dy * dy + dz * dz < thr2) ? 1 : 0;
-    }
-    if (__ballot(active && cnt <= nb)) {
-      const int l1 = lane ^ 1, l2 = lane ^ 2;
-      for (int j = 0; j < 64; j += RF_STRIDE) {
-        const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
-        const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), j));
-        const float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), j));
-        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)seg, j);
-        const float dx = x - xj, dy = y - yj, dz = z - zj;
-        if (sj == seg && dx * dx + dy * dy + dz * dz < thr2 && j != lane && j != l1 && j != l2) cnt++;
-        if (__ballot(active && cnt <= nb) == 0ull) break;
-      }
-    }
-    const bool pending = active && cnt <= nb;
-    if (active && !pending) flags[i] = 1;
-    if (valid) {   // the range's two boxes: points decided here | points left undecided
-      const int o = pending ? 6 : 0;
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int q = k * 6;
-        if (q == o) {
-          bx[q + 0] = fminf(bx[q + 0], x); bx[q + 1] = fminf(bx[q + 1], y); bx[q + 2] = fminf(bx[q + 2], z);
-          bx[q + 3] = fmaxf(bx[q + 3], x); bx[q + 4] = fmaxf(bx[q + 4], y); bx[q + 5] = fmaxf(bx[q + 5], z);
+    if (NB1) {
+      listed = active && !coh;
+      pend = listed;
+    } else {
+      cnt += (h1 ? 1 : 0) + (h2 ? 1 : 0);
+      if (__ballot(active && cnt <= nb)) {
+        const int l1 = lane ^ 1, l2 = lane ^ 2;
+        for (int j = 0; j < 64; j += RF_STRIDE) {
+          const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+          const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), j));
+          const float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), j));
+          const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)wb, j);
+          const float dx = x - xj, dy = y - yj, dz = z - zj;
+          if (wj == wb && dx * dx + dy * dy + dz * dz < thr2 && j != lane && j != l1 && j != l2) cnt++;
+          if (__ballot(active && cnt <= nb) == 0ull) break;
         }
       }
+      pend = active && cnt <= nb;
+      listed = active && (pend || !coh);
     }
-    const unsigned long long pm = __ballot(pending);
-    if (pm) {                       // workgroup-local list (LDS), one LDS atomic per wave
-      int slot0 = 0;
-      if (lane == 0) slot0 = atomicAdd(&s_n, __popcll(pm));
-      slot0 = __builtin_amdgcn_readfirstlane(slot0);
-      if (pending) {
-        const int slot = slot0 + __popcll(pm & ((1ull << lane) - 1ull));
-        if (slot < RF_LIST) {
-          s_pt[slot] = p[it];
-          s_pos[slot] = (int)(i - wg0);
-          s_cnt[slot] = cnt;
-        } else {                     // list full (a pathological tile): straight to phase B
-          const int g = atomicAdd(&queue[0], 1);
-          queue[2 + g] = (int)i;
+    // decided here: inactive segments (r == 0: no filter; r < 0 / NaN: drop all) and the coherent points that
+    // are not listed; the listed points get their flag at the end of the workgroup
+#ifndef DFU3D_DBG_RF_NOFLAGS
+    if (valid && !listed) W.flags[i] = active ? 1 : ((r == 0.0f) ? 1 : 0);
+#endif
+    lx = min_raw(lx, coh ? x : BOX_EMPTY); ly = min_raw(ly, coh ? y : BOX_EMPTY); lz = min_raw(lz, coh ? z : BOX_EMPTY);
+    hx = max_raw(hx, coh ? x : -BOX_EMPTY); hy = max_raw(hy, coh ? y : -BOX_EMPTY); hz = max_raw(hz, coh ? z : -BOX_EMPTY);
+    const unsigned long long m = __ballot(listed);
+    if (m) {
+      if (listed) {
+        const int slot = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < RF_WLIST) {
+          s_pt[wave * RF_WLIST + slot] = make_float4(x, y, z, __uint_as_float(wb));
+          s_meta[wave * RF_WLIST + slot] = (uint32_t)(i - wg0) | (coh ? 0u : RFM_INCOH) | (pend ? RFM_PEND : 0u) | ((uint32_t)min(cnt, 15) << 16);
+        } else {                     // list full (a pathological tile): straight to the segment's U list / the queue
+          const uint32_t seg = wb >> 16;
+          if (!coh) {
+            const int k = atomicAdd(&W.ucount[seg], 1);
+            W.ulist[W.seg_base[seg] + k] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
+          }
+          if (pend) {
+            const int qs = (int)(blockIdx.x % RF_QSHARDS);
+            const int g = atomicAdd(&W.queue[16 * qs], 1);
+            W.queue[RF_QHDR + qs * W.qcap + g] = (int)i;
+          }
+          W.flags[i] = pend ? 0 : 1;
         }
       }
+      run += __popcll(m);
     }
   }
+  RF_T(1);
   {
-#pragma unroll
-    for (int k = 0; k < BOX_FLOATS; k++) bx[k] = ((k % 6) < 3) ? wave_min63(bx[k]) : wave_max63(bx[k]);
+    lx = wave_min63(lx); ly = wave_min63(ly); lz = wave_min63(lz);
+    hx = wave_max63(hx); hy = wave_max63(hy); hz = wave_max63(hz);
     if (lane == 63 && w0 < n_used) {
-      float4 *o = (float4 *)(boxes + (size_t)(w0 >> BOX_SHIFT) * BOX_FLOATS);
-      o[0] = make_float4(bx[0], bx[1], bx[2], bx[3]);
-      o[1] = make_float4(bx[4], bx[5], bx[6], bx[7]);
-      o[2] = make_float4(bx[8], bx[9], bx[10], bx[11]);
+      float4 *o = (float4 *)(W.dbox + (size_t)(w0 >> BOX_SHIFT) * BOX_FLOATS);
+      o[0] = make_float4(lx, ly, lz, 0.0f);
+      o[1] = make_float4(hx, hy, hz, 0.0f);
     }
   }
-  __syncthreads();
-  const int np = min(s_n, RF_LIST);
-  if (np == 0) return;
-  // pairwise among the workgroup's undecided points.  A partner that phase A already looked at
-  // (same chunk: lane^1, lane^2 and the broadcast lanes 0, 8, ...) is skipped: counted or not, it
-  // must not be counted twice.
-  for (int a = threadIdx.x; a < np; a += RFB) {
-    const float4 q = s_pt[a];
-    const uint32_t wa = __float_as_uint(q.w);
-    const uint32_t seg = wa >> 16;
-    const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
-    int cnt = s_cnt[a];
-    const int pa = s_pos[a];
-    for (int b = 0; b < np && cnt <= nb; b++) {
-      const float4 o = s_pt[b];
-      if ((__float_as_uint(o.w) >> 16) != seg || b == a) continue;
-      const int pb = s_pos[b];
-      if ((pb >> 6) == (pa >> 6)) {
-        const int lb = pb & 63, la = pa & 63;
-        if (lb == (la ^ 1) || lb == (la ^ 2) || (lb & (RF_STRIDE - 1)) == 0) continue;
+#ifdef DFU3D_DBG_RF_NOTAIL          /* dev build (wrong results): the streaming part alone */
+  return;
+#endif
+  // The wave's incoherent points join the U lists of their segments: one returning atomic per segment (the lists
+  // are in position order, so a segment's points are neighbours), issued while the other waves still stream.
+  const int nw = min(run, RF_WLIST);
+  __builtin_amdgcn_wave_barrier();
+  for (int k0 = 0; k0 < nw; k0 += 64) {           // uniform
+    const int k = k0 + lane;
+    const bool v = k < nw;
+    const float4 q = s_pt[wave * RF_WLIST + (v ? k : 0)];
+    const uint32_t mq = v ? s_meta[wave * RF_WLIST + k] : 0u;
+    const uint32_t wq = __float_as_uint(q.w);
+    unsigned long long rem = __ballot(v && (mq & RFM_INCOH));
+    while (rem) {                                  // uniform: one round per segment
+      const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+      const uint32_t wseg = (uint32_t)__builtin_amdgcn_readlane((int)wq, first);
+      const bool mine = ((rem >> lane) & 1ull) && wq == wseg;
+      const unsigned long long mm = __ballot(mine);
+      long long base = 0;
+      if (lane == first) {
+        const uint32_t seg = wseg >> 16;
+        base = W.seg_base[seg] + atomicAdd(&W.ucount[seg], __popcll(mm));
       }
-      const float dx = q.x - o.x, dy = q.y - o.y, dz = q.z - o.z;
-      if (dx * dx + dy * dy + dz * dz < thr2) cnt++;
+      const int blo = __builtin_amdgcn_readlane((int)(base & 0xFFFFFFFFll), first);
+      const int bhi = __builtin_amdgcn_readlane((int)(base >> 32), first);
+      if (mine) {
+        const long long d = (((long long)bhi << 32) | (unsigned int)blo) + __popcll(mm & ((1ull << lane) - 1ull));
+        W.ulist[d] = make_float4(q.x, q.y, q.z, __uint_as_float((uint32_t)(wg0 + (mq & 0x7FFu))));
+      }
+      rem &= ~mm;
     }
-    if (cnt > nb) flags[wg0 + pa] = 1;
-    else s_q[atomicAdd(&s_nq, 1)] = pa;
+  }
+  if (lane == 0) s_wn[wave] = nw;
+  __syncthreads();
+  RF_T(2);
+  int wn[RFB / 64], pre[RFB / 64];
+  int np = 0;
+#pragma unroll
+  for (int w = 0; w < RFB / 64; w++) { wn[w] = s_wn[w]; pre[w] = np; np += wn[w]; }
+#ifdef DFU3D_DBG_RF_TIMING
+  if (np == 0) rf_flush(0);
+#endif
+  if (np == 0) return;
+  // Pairwise among the workgroup's listed points.  Entry c (in position order over the four parts) is looked after by
+  // lane c % 64 of EVERY wave, wave w testing it against the partners of part w only; the hits meet in s_hit.  A partner
+  // that the entry's wave already looked at (same chunk: lane^1, lane^2 and, for nb_points > 1, the broadcast lanes
+  // 0, 8, ...) must not be counted twice (for nb_points = 1 a pending point has no hit among them, only the point
+  // itself has to be left out).  Four partners per step, their LDS reads requested together, no branches: the first
+  // version (one thread per entry, one partner per step, two dependent LDS reads and three branches) spent 24 of a
+  // workgroup's 36 microseconds here, one wave of four-partner steps still 6.6.
+  auto entry_slot = [&](int c) -> int {
+    const int w = (c >= pre[1] ? 1 : 0) + (c >= pre[2] ? 1 : 0) + (c >= pre[3] ? 1 : 0);
+    return w * RF_WLIST + (c - (w == 0 ? 0 : w == 1 ? pre[1] : w == 2 ? pre[2] : pre[3]));
+  };
+  const int n_mine = wn[0] * (wave == 0) + wn[1] * (wave == 1) + wn[2] * (wave == 2) + wn[3] * (wave == 3);
+#pragma unroll 1
+  for (int c0 = 0; c0 < np; c0 += 64) {                  // uniform
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int a = entry_slot(live ? c : 0);
+    const float4 q = s_pt[a];
+    const uint32_t wa = __float_as_uint(q.w), ma = s_meta[a];
+    const bool pend_a = live && (ma & RFM_PEND);
+    if (__ballot(pend_a) == 0ull) continue;
+    const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
+    const int pa = (int)(ma & 0x7FFu), la = pa & 63;
+    int hits = 0;
+#pragma unroll 1
+    for (int k2 = 0; k2 < n_mine; k2 += RF_PW) {
+      float4 o[RF_PW];
+      uint32_t mb[RF_PW];
+#pragma unroll
+      for (int u = 0; u < RF_PW; u++) { o[u] = s_pt[wave * RF_WLIST + k2 + u]; mb[u] = s_meta[wave * RF_WLIST + k2 + u]; }
+#pragma unroll
+      for (int u = 0; u < RF_PW; u++) {
+        const int pb = (int)(mb[u] & 0x7FFu), lb = pb & 63;
+        const bool seen = NB1 ? (pb == pa)
+                              : (((pb >> 6) == (pa >> 6)) &
+                                 ((lb == la) | (lb == (la ^ 1)) | (lb == (la ^ 2)) | ((lb & (RF_STRIDE - 1)) == 0)));
+        const float dx = q.x - o[u].x, dy = q.y - o[u].y, dz = q.z - o[u].z;
+        const bool hit = (k2 + u < n_mine) & (__float_as_uint(o[u].w) == wa) & !seen & (dx * dx + dy * dy + dz * dz < thr2);
+        hits += hit ? 1 : 0;
+      }
+    }
+    if (pend_a && hits) atomicAdd(&s_hit[c], hits);
+  }
+  RF_T(3);
+  __syncthreads();
+  constexpr int ROUNDS = RF_LIST / RFB;
+  int e_qk[ROUNDS], e_pos[ROUNDS];
+  bool e_pend[ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; rd++) {
+    const int c = rd * RFB + (int)threadIdx.x;
+    e_qk[rd] = 0; e_pos[rd] = 0; e_pend[rd] = false;
+    if (c >= np) continue;
+    const uint32_t ma = s_meta[entry_slot(c)];
+    const int pa = (int)(ma & 0x7FFu);
+    const bool pend = (ma & RFM_PEND) && ((int)((ma >> 16) & 15u) + s_hit[c] <= nb);
+    e_pos[rd] = pa;
+    e_pend[rd] = pend;
+    W.flags[wg0 + pa] = pend ? 0 : 1;
+    if (pend) e_qk[rd] = atomicAdd(&s_nq, 1);
   }
   __syncthreads();
   const int nq = s_nq;
+#ifdef DFU3D_DBG_RF_TIMING
+  if (nq == 0) rf_flush(np);
+#endif
   if (nq == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&queue[0], nq);        // one global atomic per workgroup
+  const int qs = (int)(blockIdx.x % RF_QSHARDS);
+  if (threadIdx.x == 0) s_base = atomicAdd(&W.queue[16 * qs], nq);        // one global atomic per workgroup
   __syncthreads();
-  for (int k = threadIdx.x; k < nq; k += RFB) queue[2 + s_base + k] = (int)(wg0 + s_q[k]);
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; rd++)
+    if (e_pend[rd]) W.queue[RF_QHDR + qs * W.qcap + s_base + e_qk[rd]] = (int)(wg0 + e_pos[rd]);
+#ifdef DFU3D_DBG_RF_TIMING
+  RF_T(4);
+  rf_flush(np);
+#endif
 }
 
 // squared distance from q to an axis-aligned box (0 inside)
@@ -519,115 +696,241 @@ __device__ __forceinline__ float box_dist2(float qx, float qy, float qz, float l
   return dx * dx + dy * dy + dz * dz;
 }
 
-// Phase B: one wave per queued query.
-#ifndef DFU3D_RF_RANGES_PER_STEP
-#define DFU3D_RF_RANGES_PER_STEP 1
-#endif
-constexpr int RF_RQ = DFU3D_RF_RANGES_PER_STEP;   // candidate ranges whose points are requested together (tuning constant; 2 is the `rf2` dev build)
-__global__ __launch_bounds__(256) void k_radius_resolve(
+// one queued point with everything its tests need
+struct RfQuery {
+  long long i;
+  float4 qf;
+  uint32_t wq;
+  long long base, end;
+  double x, y, z, r2;
+  float lo2, hi2;       // float32 screening: certainly inside below lo2, certainly outside above hi2, fp64 in between
+};
+__device__ __forceinline__ bool rf_load_query(RfQuery &Q, long long i, const float4 *pq, const double *px, const double *py,
+                                              const double *pz, const long long *seg_base, const int *seg_cnt,
+                                              const double *radius, int S) {
+  Q.i = i;
+  Q.qf = pq[i];
+  Q.wq = __float_as_uint(Q.qf.w);
+  const int s = (int)(Q.wq >> 16);                       // < S: phase A queues nothing else
+  if (s >= S) return false;
+  const int n = max(seg_cnt[s], 0);
+  Q.base = seg_base[s];
+  Q.end = Q.base + n;
+  if (i < Q.base || i >= Q.end) return false;            // cannot happen for a shadow built from this table
+  const double r = radius[s];
+  Q.r2 = r * r;
+  Q.x = px[i]; Q.y = py[i]; Q.z = pz[i];
+  const float rf = (float)r;
+  const float eb = rf_bound(Q.qf.x, Q.qf.y, Q.qf.z, rf) + rf * 2.4e-7f;
+  const float tl = rf - eb, th = rf + eb;
+  Q.lo2 = (tl > 0.0f) ? tl * tl * 0.999999f : -1.0f;
+  Q.hi2 = th * th * 1.000001f;
+  return true;
+}
+// is the point with shadow o at pool position g within the radius of the query?
+__device__ __forceinline__ bool rf_within(const RfQuery &Q, const float4 &o, long long g, const double *px, const double *py,
+                                          const double *pz) {
+  const float dx = Q.qf.x - o.x, dy = Q.qf.y - o.y, dz = Q.qf.z - o.z;
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  bool hit = d2 < Q.lo2;
+  if (!hit && !(d2 > Q.hi2)) {                     // too close to call in float32
+    const double ex = Q.x - px[g], ey = Q.y - py[g], ez = Q.z - pz[g];
+    double d = ex * ex;
+    d += ey * ey;
+    d += ez * ez;
+    hit = d < Q.r2;
+  }
+  return hit;
+}
+// the COHERENT points of range rg (512 positions) within the radius of the query: the range is read as phase A's wave
+// read it and the coherence of its points re-derived with phase A's own function.  Whole wave, uniform.
+__device__ __forceinline__ int rf_scan_range(const RfQuery &Q, long long rg, const float4 *pq, long long n_used,
+                                             const double *px, const double *py, const double *pz) {
+  const int lane = lane_id();
+  const long long c0 = rg << (BOX_SHIFT - 6);
+  float4 o[RF_IT];
+#pragma unroll
+  for (int u = 0; u < RF_IT; u++) {
+    const long long g = ((c0 + u) << 6) + lane;
+    o[u] = pq[g];                                   // (as in phase A: read, then marked if beyond n_used)
+    if (g >= n_used) o[u].w = __uint_as_float(RF_NOSEG << 16);
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < RF_IT; u++) {
+    const long long g = ((c0 + u) << 6) + lane;
+    const uint32_t wb = __float_as_uint(o[u].w);
+    const float thr2 = rf_certain_hit2(o[u].x, o[u].y, o[u].z, __uint_as_float(wb << 16));
+    bool h1, h2;
+    rf_list_neighbours(o[u].x, o[u].y, o[u].z, wb, thr2, h1, h2);
+    const bool hit = (wb == Q.wq) && (h1 || h2) && rf_within(Q, o[u], g, px, py, pz);
+    cnt += __popcll(__ballot(hit));
+  }
+  return cnt;
+}
+
+// Phase B: one wave per queued point, counting from scratch.
+constexpr int RF_UL = 4;           // U-list loads in flight per lane
+__global__ __launch_bounds__(256) void k_rf_resolve(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
-    const float4 *__restrict__ pq, const float *__restrict__ boxes, const long long *__restrict__ seg_base,
-    const int *__restrict__ seg_cnt, const double *__restrict__ radius, int nb, int S, long long pool_cap,
-    uint8_t *__restrict__ flags, const int *__restrict__ queue) {
-  const int nq = (int)min((long long)queue[0], pool_cap);
+    const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max,
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, const double *__restrict__ radius,
+    int nb, int S, RfScratch W) {
+  long long n_used = n_max;
+  if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
   const int lane = lane_id();
+  // the parts of the queue: lane q holds the number of entries in the parts up to and including q
+  const int q_incl = wave_incl_scan((int)min((long long)max(W.queue[16 * lane], 0), W.qcap));
+  const int nq = __builtin_amdgcn_readlane(q_incl, 63);
+  int *lq_tab = W.work + RF_WORK_HDR + 65536, *items = lq_tab + 4 * RF_LQ_CAP;
   for (int e = wave; e < nq; e += nwaves) {
-    const long long i = queue[2 + e];
-    const float4 qf = pq[i];
-    const int s = (int)(__float_as_uint(qf.w) >> 16);     // < S: phase A queues nothing else
-    if (s >= S) continue;
-    const int n = max(seg_cnt[s], 0);
-    const long long base = seg_base[s], end = base + n;
-    if (i < base || i >= end) continue;                   // cannot happen for a shadow built from this table
-    const double r = radius[s], r2 = r * r;
-    const double x = px[i], y = py[i], z = pz[i];
-    // float32 screening: certainly inside below lo2, certainly outside above hi2, fp64 in between
-    const float rf = (float)r;
-    const float eb = rf_bound(qf.x, qf.y, qf.z, rf) + rf * 2.4e-7f;
-    const float tl = rf - eb, th = rf + eb;
-    const float lo2 = (tl > 0.0f) ? tl * tl * 0.999999f : -1.0f;
-    const float hi2 = th * th * 1.000001f;
+#ifdef DFU3D_DBG_RF_TIMING
+    unsigned long long rf_rec[RF_DBG_F] = {0};
+    long long rf_t = clock64();
+    int dbg_cand = 0;
+#endif
+    const int part = __popcll(__ballot(q_incl <= e));
+    const int before = part ? __builtin_amdgcn_readlane(q_incl, part - 1) : 0;
+    RfQuery Q;
+    if (!rf_load_query(Q, W.queue[RF_QHDR + part * W.qcap + (e - before)], pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
+    const int nu = (int)min((long long)max(W.ucount[Q.wq >> 16], 0), Q.end - Q.base);
     int cnt = 0;
-    // the points of chunk c (pool positions 64c .. 64c+63) that belong to the segment
-    auto test_chunk = [&](long long c) {
-      const long long g = (c << 6) + lane;
-      const bool in = (g >= base) && (g < end);
-      bool hit = false;
-      if (in) {
-        const float4 o = pq[g];
-        const float dx = qf.x - o.x, dy = qf.y - o.y, dz = qf.z - o.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        hit = d2 < lo2;
-        if (!hit && !(d2 > hi2)) {                   // too close to call in float32
-          const double ex = x - px[g], ey = y - py[g], ez = z - pz[g];
-          double d = ex * ex;
-          d += ey * ey;
-          d += ez * ez;
-          hit = d < r2;
-        }
+    RF_T(0);
+    // (1) the incoherent points of the segment (the query itself is one of them unless it is coherent)
+    for (int k0 = 0; k0 < nu && cnt <= nb; k0 += 64 * RF_UL) {
+      float4 o[RF_UL];
+      bool in[RF_UL];
+#pragma unroll
+      for (int u = 0; u < RF_UL; u++) {
+        const int k = k0 + u * 64 + lane;
+        in[u] = k < nu;
+        o[u] = in[u] ? W.ulist[Q.base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      cnt += __popcll(__ballot(hit));
-    };
-    const long long c_own = i >> 6;
-    test_chunk(c_own);                               // the query itself is counted here (d = 0 < r2)
-    const long long r_lo = base >> BOX_SHIFT, r_hi = (end - 1) >> BOX_SHIFT;
+#pragma unroll
+      for (int u = 0; u < RF_UL; u++) {
+        const bool hit = in[u] && rf_within(Q, o[u], (long long)__float_as_uint(o[u].w), px, py, pz);
+        cnt += __popcll(__ballot(hit));
+      }
+    }
+    RF_T(1);
+    // (2) the coherent points of the ranges whose box comes within the radius: the first RF_INLINE_CAND of them are
+    // read here, the others become work items of k_rf_ranges (a query near many boxes -- boxes that a pair of
+    // neighbouring outliers has blown up -- was a chain of range reads, one query took 0.26 ms)
+    const long long r_lo = Q.base >> BOX_SHIFT, r_hi = (Q.end - 1) >> BOX_SHIFT;
+    int n_inline = 0, n_items = 0, lq = -1;
     for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
       const long long rg = r0 + lane;
       bool cand = false;
       if (rg <= r_hi) {
-        const float4 *bp = (const float4 *)(boxes + (size_t)rg * BOX_FLOATS);
-        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-        cand = box_dist2(qf.x, qf.y, qf.z, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y) <= hi2 ||
-               box_dist2(qf.x, qf.y, qf.z, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w) <= hi2;
+        const float4 *bp = (const float4 *)(W.dbox + (size_t)rg * BOX_FLOATS);
+        const float4 b0 = bp[0], b1 = bp[1];
+        cand = box_dist2(Q.qf.x, Q.qf.y, Q.qf.z, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z) <= Q.hi2;
       }
       unsigned long long m = __ballot(cand);
-      while (m && cnt <= nb) {                       // uniform: the candidate ranges of this step, RF_RQ at a time
-        // the eight chunks of a range are requested together (one memory round trip, not eight in a row: a query's
-        // candidate ranges were a chain of dependent loads, and the kernel's 0.24 ms was that chain)
-        constexpr int RC = 1 << (BOX_SHIFT - 6);
-        long long c0[RF_RQ];
-        bool have[RF_RQ];
-#pragma unroll
-        for (int q = 0; q < RF_RQ; q++) {
-          have[q] = m != 0ull;
-          const int k = have[q] ? __ffsll((long long)m) - 1 : 0;
-          m &= m - 1ull;                             // (0 stays 0)
-          c0[q] = (r0 + k) << (BOX_SHIFT - 6);
+      while (m && cnt <= nb && n_inline < RF_INLINE_CAND) {            // uniform
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        n_inline++;
+#ifdef DFU3D_DBG_RF_TIMING
+        dbg_cand++;
+#endif
+        cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
+      }
+      if (m && cnt <= nb) {                          // the rest of this batch: work items
+        const int c = __popcll(m);
+        int ib = 0;
+        if (lane == 0) {
+          if (lq < 0) lq = atomicAdd(&W.work[0], 1);
+          ib = (lq < RF_LQ_CAP) ? atomicAdd(&W.work[16], c) : RF_ITEM_CAP;
         }
-        float4 o[RF_RQ * RC];
-        bool in[RF_RQ * RC];
-#pragma unroll
-        for (int u = 0; u < RF_RQ * RC; u++) {
-          const long long c = c0[u / RC] + (u % RC);
-          const long long g = (c << 6) + lane;
-          in[u] = have[u / RC] && (g >= base) && (g < end) && (c != c_own);
-          o[u] = in[u] ? pq[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int u = 0; u < RF_RQ * RC; u++) {
-          bool hit = false;
-          if (in[u]) {
-            const float dx = qf.x - o[u].x, dy = qf.y - o[u].y, dz = qf.z - o[u].z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            hit = d2 < lo2;
-            if (!hit && !(d2 > hi2)) {                 // too close to call in float32
-              const long long g = ((c0[u / RC] + (u % RC)) << 6) + lane;
-              const double ex = x - px[g], ey = y - py[g], ez = z - pz[g];
-              double d = ex * ex;
-              d += ey * ey;
-              d += ez * ez;
-              hit = d < r2;
-            }
+        lq = __builtin_amdgcn_readfirstlane(lq);
+        ib = __builtin_amdgcn_readfirstlane(ib);
+        if (lq < RF_LQ_CAP && ib + c <= RF_ITEM_CAP) {
+          if ((m >> lane) & 1ull) {
+            const int t = ib + __popcll(m & ((1ull << lane) - 1ull));
+            items[2 * t] = lq;
+            items[2 * t + 1] = (int)rg;
           }
-          cnt += __popcll(__ballot(hit));
+          n_items += c;
+#ifdef DFU3D_DBG_RF_TIMING
+          dbg_cand += c;
+#endif
+        } else {                                     // tables full (never seen): read the ranges here after all
+          while (m && cnt <= nb) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
+          }
         }
       }
     }
-    if (lane == 0) flags[i] = (cnt > nb) ? 1 : 0;
+    if (lane == 0) {
+      if (n_items && cnt <= nb) {                    // k_rf_ranges finishes the count
+        lq_tab[4 * lq] = (int)Q.i;
+        lq_tab[4 * lq + 1] = n_items;
+        lq_tab[4 * lq + 2] = cnt;
+        lq_tab[4 * lq + 3] = 0;
+      } else {
+        if (lq >= 0 && lq < RF_LQ_CAP) lq_tab[4 * lq + 1] = 0;   // (items of a query that got its answer meanwhile are skipped)
+        W.flags[Q.i] = (cnt > nb) ? 1 : 0;
+      }
+    }
+#ifdef DFU3D_DBG_RF_TIMING
+    RF_T(2);
+    if (lane == 0 && wave < 16384) {
+      rf_rec[3] = 1; rf_rec[4] = (unsigned long long)nu; rf_rec[5] = (unsigned long long)dbg_cand;
+      rf_rec[6] = (unsigned long long)(r_hi - r_lo + 1); rf_rec[7] = (cnt > nb) ? 1 : 0; rf_rec[8] = (unsigned long long)(Q.end - Q.base);
+      for (int k = 0; k < RF_DBG_F; k++) g_rf_recB[(size_t)wave * RF_DBG_F + k] += rf_rec[k];
+    }
+#endif
   }
 }
+
+// Phase B, the long queries: one wave per (query, candidate range); the hits meet in the query's record (count in the
+// low word, finished items in the high word of ONE 64-bit atomic), whoever finishes the last item writes the flag.
+__global__ __launch_bounds__(256) void k_rf_ranges(
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max,
+    const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, const double *__restrict__ radius,
+    int nb, int S, RfScratch W) {
+  const int n_items = min(W.work[16], RF_ITEM_CAP);
+  if (n_items <= 0) return;
+  long long n_used = n_max;
+  if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  int *lq_tab = W.work + RF_WORK_HDR + 65536, *items = lq_tab + 4 * RF_LQ_CAP;
+  for (int t = wave; t < n_items; t += nwaves) {
+    const int lq = items[2 * t];
+    const long long rg = items[2 * t + 1];
+    if (lq < 0 || lq >= RF_LQ_CAP) continue;
+    const int total = lq_tab[4 * lq + 1];
+    if (total <= 0) continue;
+    RfQuery Q;
+    if (!rf_load_query(Q, lq_tab[4 * lq], pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
+    const int hits = rf_scan_range(Q, rg, pq, n_used, px, py, pz);
+    if (lane_id() == 0) {
+      const unsigned long long old = atomicAdd((unsigned long long *)(lq_tab + 4 * lq + 2), (unsigned long long)hits | (1ull << 32));
+      if ((int)(old >> 32) + 1 == total) W.flags[Q.i] = ((int)(old & 0xFFFFFFFFull) + hits > nb) ? 1 : 0;
+    }
+  }
+}
+
+#ifdef DFU3D_DBG_RF_TIMING
+extern "C" int dfu3d_debug_rf_timing(unsigned long long *out_a, unsigned long long *out_b, int reset) {
+  if (out_a && hipMemcpyFromSymbol(out_a, HIP_SYMBOL(g_rf_recA), sizeof(g_rf_recA)) != hipSuccess) return DFU3D_ELAUNCH;
+  if (out_b && hipMemcpyFromSymbol(out_b, HIP_SYMBOL(g_rf_recB), sizeof(g_rf_recB)) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    void *pa = nullptr, *pb = nullptr;
+    if (hipGetSymbolAddress(&pa, HIP_SYMBOL(g_rf_recA)) != hipSuccess || hipGetSymbolAddress(&pb, HIP_SYMBOL(g_rf_recB)) != hipSuccess)
+      return DFU3D_ELAUNCH;
+    if (hipMemset(pa, 0, sizeof(g_rf_recA)) != hipSuccess || hipMemset(pb, 0, sizeof(g_rf_recB)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+#endif
 
 // standalone use of the filter (no k_seg_write in front): float32 shadow of the given segments
 __global__ __launch_bounds__(QT) void k_shadow_build(
@@ -644,30 +947,51 @@ __global__ __launch_bounds__(QT) void k_shadow_build(
   }
 }
 
-// in-place ordered compaction of SHORT lists (the per-instance LiDAR lists): one wave per segment
-__global__ __launch_bounds__(256) void k_seg_compact_short(
+// in-place ordered compaction of SHORT lists (the per-instance LiDAR lists): one workgroup per segment, 2048
+// positions per step, a thread looks after 8 consecutive ones; flags and coordinates are requested together (no
+// load waits for another), one block scan gives the destinations.  History: one wave per segment walking 64 (later
+// 512) positions at a time was a chain of dependent round trips for the longest list (0.03 / 0.02 ms for 0.36 M points).
+// A destination never lies ahead of a source of the same or a later step, and every source of a step is in registers
+// before the scan's barriers, i.e. before the first store of the step.
+constexpr int CS_T = 256, CS_E = 8;
+__global__ __launch_bounds__(CS_T) void k_seg_compact_short(
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     const long long *__restrict__ seg_base, int *__restrict__ seg_cnt, const uint8_t *__restrict__ flags, int S) {
-  const int s = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (s >= S) return;
+  __shared__ int s_w[CS_T / 64];
+  const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0) return;
   const long long base = seg_base[s];
-  const int lane = lane_id();
   int running = 0;
-  for (int t0 = 0; t0 < n; t0 += 64) {
-    const int i = t0 + lane;
-    const bool f = (i < n) && flags[base + i];
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (f) { x = px[base + i]; y = py[base + i]; z = pz[base + i]; }
-    const unsigned long long m = __ballot(f);
-    if (f) {                                        // dst <= src of every lane: loads above come first
-      const long long d = base + running + __popcll(m & ((1ull << lane) - 1ull));
-      px[d] = x; py[d] = y; pz[d] = z;
+  for (int t0 = 0; t0 < n; t0 += CS_T * CS_E) {
+    const int i0 = t0 + (int)threadIdx.x * CS_E;
+    bool f[CS_E];
+    double x[CS_E], y[CS_E], z[CS_E];
+#pragma unroll
+    for (int u = 0; u < CS_E; u++) {
+      const int i = i0 + u;
+      const bool in = i < n;
+      f[u] = in && flags[base + i];
+      x[u] = in ? px[base + i] : 0.0;
+      y[u] = in ? py[base + i] : 0.0;
+      z[u] = in ? pz[base + i] : 0.0;
     }
-    running += __popcll(m);
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < CS_E; u++) mine += f[u] ? 1 : 0;
+    int tot;
+    int r = block_excl_scan<CS_T / 64>(mine, s_w, tot);
+#pragma unroll
+    for (int u = 0; u < CS_E; u++) {
+      if (f[u]) {
+        const long long d = base + running + r;
+        px[d] = x[u]; py[d] = y[u]; pz[d] = z[u];
+        r++;
+      }
+    }
+    running += tot;
   }
-  if (lane == 0) seg_cnt[s] = running;
+  if (threadIdx.x == 0) seg_cnt[s] = running;
 }
 
 // ---------------------------------------------------------------- a12 ball query
@@ -1079,6 +1403,9 @@ extern "C" int dfu3d_segments_build(
   return DFU3D_OK;
 }
 
+extern "C" int64_t dfu3d_rf_shadow_bytes(int64_t pool_cap) { return pool_cap > 0 ? DFU3D_SHADOW_BYTES(pool_cap) : DFU3D_EINVAL; }
+extern "C" int64_t dfu3d_rf_queue_ints(int64_t pool_cap) { return pool_cap > 0 ? DFU3D_RF_QUEUE_INTS(pool_cap) : DFU3D_EINVAL; }
+
 extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int64_t *seg_base,
                                    int32_t *seg_cnt, const double *radius, int32_t nb_points,
                                    int32_t S, int64_t pool_cap, const int64_t *n_used, void *shadow,
@@ -1093,7 +1420,18 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   if ((uintptr_t)shadow & 15u) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float4 *pq = (float4 *)shadow;
-  float *boxes = (float *)(pq + pool_cap);           // 12 floats per 64 pool slots, behind the shadow proper
+  // scratch behind the shadow proper: one box per 512 slots, the per-segment U lists (at the segments' own pool
+  // positions), counters, the tables of the long queries
+  const size_t n_ranges = (size_t)((pool_cap + 511) / 512 + 1);
+  RfScratch W;
+  W.flags = flags;
+  W.queue = queue;
+  W.qcap = rf_queue_part_cap(pool_cap);
+  W.dbox = (float *)(pq + pool_cap);
+  W.ulist = (float4 *)((char *)W.dbox + 48 * n_ranges);
+  W.work = (int *)(W.ulist + pool_cap);
+  W.ucount = W.work + RF_WORK_HDR;
+  W.seg_base = (const long long *)seg_base;
   if (phases & DFU3D_RF_SHADOW) {
     // positions outside the given segments carry the "no segment" mark (all bits set)
     if (hipMemsetAsync(pq, 0xFF, sizeof(float4) * (size_t)pool_cap, st) != hipSuccess) return DFU3D_ELAUNCH;
@@ -1105,19 +1443,28 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_FLAGS) {
-    if (hipMemsetAsync(queue, 0, 2 * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
-    hipLaunchKernelGGL(k_radius_flags, dim3((unsigned)((pool_cap + RF_WG - 1) / RF_WG)), dim3(RFB), 0, st, pq,
-                       (const long long *)n_used, (long long)pool_cap, nb_points, S, flags, queue, boxes);
+    if (hipMemsetAsync(queue, 0, RF_QHDR * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (hipMemsetAsync(W.work, 0, sizeof(int) * (size_t)(RF_WORK_HDR + S), st) != hipSuccess) return DFU3D_ELAUNCH;
+    const dim3 grid((unsigned)((pool_cap + RF_WG - 1) / RF_WG));
+    if (nb_points == 1)
+      hipLaunchKernelGGL(k_rf_stream<true>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
+                         nb_points, S, W);
+    else
+      hipLaunchKernelGGL(k_rf_stream<false>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
+                         nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
-    hipLaunchKernelGGL(k_radius_resolve, dim3(4096), dim3(256), 0, st, px, py, pz, pq, boxes,
-                       (const long long *)seg_base, seg_cnt, radius, nb_points, S, (long long)pool_cap, flags, queue);
+    hipLaunchKernelGGL(k_rf_resolve, dim3(4096), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
+                       (long long)pool_cap, (const long long *)seg_base, seg_cnt, radius, nb_points, S, W);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rf_ranges, dim3(1024), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
+                       (long long)pool_cap, (const long long *)seg_base, seg_cnt, radius, nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {
     if (phases & DFU3D_RF_SHORT_LISTS) {
-      hipLaunchKernelGGL(k_seg_compact_short, dim3((S + 3) / 4), dim3(256), 0, st, px, py, pz,
+      hipLaunchKernelGGL(k_seg_compact_short, dim3(S), dim3(CS_T), 0, st, px, py, pz,
                          (const long long *)seg_base, seg_cnt, flags, S);
     } else {
       hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,

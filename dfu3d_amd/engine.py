@@ -153,7 +153,7 @@ class PseudoBoxEngine:
             L.base_ab = torch.empty(2 * S, dtype=torch.int64, device=d)
             L.cnt_ab = i32(2 * S)
             L.rad_ab = f64(2 * S)
-            L.queue = i32(2 + pc)
+            L.queue = i32(st.rf_queue_ints(pc))
             L.shadow = torch.empty(st.shadow_floats(pc), dtype=torch.float32, device=d)
             L.chunk_cnt = i32(int(st._lib.lib().dfu3d_segments_scratch_words(V, cap_n, cv)))
             L.pool_cursor = torch.zeros(1, dtype=torch.int64, device=d)
@@ -362,7 +362,7 @@ class PseudoBoxEngine:
             R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
                            self.tile_off, self.flags, self.mean_d)
-        self._count("rf_undecided", self.queue[0:1])
+        self._count("rf_undecided", self.queue[0:1024:16])
         self._count("ball_points", self.cnt_a)
         self._count("ball_points", self.cnt_b)
         R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,

@@ -225,7 +225,12 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
 
 def shadow_floats(pool_cap):
     """float32 elements of the radius filter's shadow scratch (DFU3D_SHADOW_BYTES / 4)."""
-    return 4 * pool_cap + 12 * ((pool_cap + 511) // 512 + 1)
+    return 8 * pool_cap + 12 * ((pool_cap + 511) // 512 + 1) + 9699456 // 4
+
+
+def rf_queue_ints(pool_cap):
+    """int32 elements of the radius filter's queue scratch (DFU3D_RF_QUEUE_INTS)."""
+    return 1024 + 64 * (((pool_cap + 2047) // 2048 + 63) // 64) * 2048
 
 
 def segments_build(a_bits, a_x, a_y, a_z, a_n, a_cap, b_bits, b_x, b_y, b_z, b_n, b_cap, V,
@@ -278,7 +283,7 @@ def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap,
         _chk(shadow, "shadow", torch.float32, numel=shadow_floats(pool_cap)),
         _chk(tile_off, "tile_off", torch.int32, min_numel=S + 1),
         _chk(flags, "flags", torch.uint8, numel=pool_cap),
-        _chk(queue, "queue", torch.int32, min_numel=2 + pool_cap), int(phases), _stream())
+        _chk(queue, "queue", torch.int32, min_numel=rf_queue_ints(pool_cap)), int(phases), _stream())
     _lib.check(rc, "dfu3d_radius_filter")
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 130          /* 0.1.3 */
+#define DFU3D_VERSION 140          /* 0.1.4: radius-filter scratch sizes (DFU3D_SHADOW_BYTES, DFU3D_RF_QUEUE_INTS) */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -228,19 +228,26 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
  * takes only decisions that float32 rounding cannot change; everything else is decided in fp64
  * from the pool.  Segments must not overlap; S < 65535.
  * n_used: device int64 = number of pool slots in use (NULL: pool_cap).
- * Scratch: shadow (DFU3D_SHADOW_BYTES(pool_cap) bytes, 16-byte aligned: 16 B per slot + two bounding boxes
- * per 512 slots for the second phase), tile_off int32 (S+1), flags uint8
- * (pool_cap), queue int32 (2 + pool_cap: undecided pool positions between the two kernels). */
+ * Scratch: shadow (DFU3D_SHADOW_BYTES(pool_cap) bytes, 16-byte aligned: the 16 B per slot the filter streams,
+ * then what the second phase reads -- one bounding box per 512 slots, the per-segment lists of the points
+ * without a list neighbour (16 B per slot at most), their lengths and the work items of queries near many
+ * boxes), tile_off int32 (S+1), flags uint8 (pool_cap), queue int32 (DFU3D_RF_QUEUE_INTS(pool_cap), 16-byte
+ * aligned: undecided pool positions between the kernels). */
 int dfu3d_radius_filter(double *px, double *py, double *pz,
                         const int64_t *seg_base, int32_t *seg_cnt,
                         const double *radius, int32_t nb_points, int32_t S,
                         int64_t pool_cap, const int64_t *n_used, void *shadow,
                         int32_t *tile_off, uint8_t *flags,
                         int32_t *queue, int32_t phases, void *stream);
-#define DFU3D_SHADOW_BYTES(pool_cap) (16 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 511) / 512 + 1))
+#define DFU3D_SHADOW_BYTES(pool_cap) (32 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 511) / 512 + 1) + 9699456)
+/* int32 elements of `queue`: 64 parts (one per 64th of the 2048-slot workgroups) behind their 64 counters */
+#define DFU3D_RF_QUEUE_INTS(pool_cap) (1024 + 64 * ((((int64_t)(pool_cap) + 2047) / 2048 + 63) / 64) * 2048)
+/* the two macros as functions, for hosts that cannot evaluate C macros (ctypes, cgo, JNI) */
+int64_t dfu3d_rf_shadow_bytes(int64_t pool_cap);
+int64_t dfu3d_rf_queue_ints(int64_t pool_cap);
 #define DFU3D_RF_SHADOW 1   /* shadow of the given segments (not needed behind dfu3d_segments_build(..., shadow)) */
-#define DFU3D_RF_FLAGS 2    /* k_radius_flags: list neighbours / own wave / own workgroup, float32          */
-#define DFU3D_RF_RESOLVE 4  /* k_radius_resolve: the undecided against their whole segment                   */
+#define DFU3D_RF_FLAGS 2    /* k_rf_stream: list neighbours / own wave / own workgroup, float32             */
+#define DFU3D_RF_RESOLVE 4  /* k_rf_resolve: the undecided against their whole segment                       */
 #define DFU3D_RF_COMPACT 8  /* ordered in-place compaction of the given segments                            */
 #define DFU3D_RF_ALL 15
 #define DFU3D_RF_SHORT_LISTS 16 /* hint for COMPACT: one wave per segment (the per-instance LiDAR lists)    */

@@ -186,7 +186,7 @@ def test_radius_filter_matches_oracle(st):
         st.radius_filter(px, py, pz, _t(base), seg_cnt, _t(radius), nb, S, cap,
                          torch.zeros(S + 1, dtype=torch.int32, device=DEV),
                          torch.zeros(cap, dtype=torch.uint8, device=DEV),
-                         torch.zeros(2 + 2 * cap, dtype=torch.int32, device=DEV))
+                         torch.zeros(st.rf_queue_ints(cap), dtype=torch.int32, device=DEV))
         torch.cuda.synchronize()
         out_cnt = seg_cnt.cpu().numpy()
         X = torch.stack([px, py, pz], 1).cpu().numpy()
@@ -230,7 +230,7 @@ def test_radius_filter_pairs_at_the_threshold(st):
         st.radius_filter(px, py, pz, _t(base), seg_cnt, _t(radius), nb, S, cap,
                          torch.zeros(S + 1, dtype=torch.int32, device=DEV),
                          torch.zeros(cap, dtype=torch.uint8, device=DEV),
-                         torch.zeros(2 + cap, dtype=torch.int32, device=DEV))
+                         torch.zeros(st.rf_queue_ints(cap), dtype=torch.int32, device=DEV))
         torch.cuda.synchronize()
         out_cnt = seg_cnt.cpu().numpy()
         X = torch.stack([px, py, pz], 1).cpu().numpy()
@@ -318,7 +318,7 @@ def test_masked_ballquery_equals_filter_then_fuse(st):
     radius = _t(np.array([0.6, 3.0, 0.6, 3.0, 0.6, 3.0]))
     tile_off = torch.zeros(2 * S + 2, dtype=torch.int32, device=DEV)
     flags = torch.zeros(cap, dtype=torch.uint8, device=DEV)
-    queue = torch.zeros(2 + 2 * cap, dtype=torch.int32, device=DEV)
+    queue = torch.zeros(st.rf_queue_ints(cap), dtype=torch.int32, device=DEV)
     st.radius_filter(px, py, pz, tb, cnt_b, radius, 1, S, cap, tile_off, flags, queue,
                      phases=st.RF_ALL & ~st.RF_COMPACT)
     st.ballquery_fuse(px, py, pz, ta, cnt_a, tb, cnt_b, 0.1, S, cap, tile_off, flags, masked=True)

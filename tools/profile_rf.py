@@ -1,43 +1,126 @@
-"""Dev tool (GPU): phases of dfu3d_radius_filter on the state snapshotted before each of the engine's two calls
-(LiDAR lists, pseudo lists): time per phase, queue length after phase A, achieved GB/s of 21 B/point."""
-import sys, os, time
+"""Dev tool (GPU): the radius-filter stage on the state the engine hands it (joint LiDAR + pseudo lists of `frames` bench
+frames): time per kernel (HIP events on the launch stream, best / median of `reps`), queue length after phase A, length of
+the U lists, achieved GB/s of the stage at 21 B/point, and a check of the keep mask against a brute-force float64 count on
+a sample of segments.
+
+    python tools/profile_rf.py [frames=64] [reps=20]
+"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from dfu3d_amd import synth, stages as st
+import numpy as np
+import torch
+
+from dfu3d_amd import stages as st, synth
 from dfu3d_amd.engine import PseudoBoxEngine
 from dfu3d_amd.params import Params
-frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-dev = "cuda:0"; p = Params()
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = "cuda:0"
+p = Params()
 scenes = [synth.make_scene(f, dense=True, device=dev, k_min=30, k_max=40) for f in range(frames)]
 b = synth.to_view_batch(scenes, p, dev)
-eng = PseudoBoxEngine(p, 900, 1600, 8, 34720, views_per_chunk=frames * 6, pool_per_view=1 << 17)
+eng = PseudoBoxEngine(p, 900, 1600, 8, 34720, views_per_chunk=frames * 6)
 snaps = []
 orig = st.radius_filter
-def hook(px, py, pz, base, cnt, radius, nb, S, pool_cap, tile_off, flags, queue, phases=st.RF_ALL):
-    snaps.append(dict(px=px.clone(), py=py.clone(), pz=pz.clone(), base=base.clone(), cnt=cnt.clone(), radius=radius.clone()))
-    return orig(px, py, pz, base, cnt, radius, nb, S, pool_cap, tile_off, flags, queue, phases=phases)
+
+
+def hook(px, py, pz, base, cnt, radius, nb, S, pool_cap, tile_off, flags, queue, phases=st.RF_ALL, shadow=None, n_used=None):
+    snaps.append(dict(px=px.clone(), py=py.clone(), pz=pz.clone(), base=base.clone(), cnt=cnt.clone(), radius=radius.clone(),
+                      S=S, phases=phases, shadow=shadow.clone(), n_used=n_used.clone()))
+    return orig(px, py, pz, base, cnt, radius, nb, S, pool_cap, tile_off, flags, queue, phases=phases, shadow=shadow, n_used=n_used)
+
+
 st.radius_filter = hook
-eng.run(b); torch.cuda.synchronize()
+eng.run(b)
+torch.cuda.synchronize()
 st.radius_filter = orig
-S = eng.Vc * eng.M
-for name, sn in zip(("lidar", "pseudo"), snaps):
-    n = int(sn["cnt"].sum())
-    best = {}
-    for rep in range(4):
-        px, py, pz = sn["px"].clone(), sn["py"].clone(), sn["pz"].clone()
-        base, cnt = sn["base"].clone(), sn["cnt"].clone()
-        for tag, ph in (("tiles", st.RF_TILES), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE), ("compact", st.RF_COMPACT)):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            orig(px, py, pz, base, cnt, sn["radius"], p.nb_points, S, eng.pool_cap, eng.tile_off, eng.flags, eng.queue, phases=ph)
-            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-            best[tag] = min(best.get(tag, 1e9), dt)
-            if tag == "flags" and rep == 0:
-                nq = int(eng.queue[0])
-            if tag == "resolve" and rep == 0:
-                nlong = int(eng.queue[1])
-    kept = int(cnt.sum())
-    print("%-6s points %8d kept %8d queued %7d (%.2f%%) long %6d  tiles %.3f flags %.3f resolve %.3f compact %.3f ms (host-timed, +~0.02 launch)  flags: %.0f GB/s"
-          % (name, n, kept, nq, 100.0 * nq / max(n, 1), nlong, best["tiles"], best["flags"], best["resolve"], best["compact"],
-             21.0 * n / (best["flags"] - 0.0) / 1e6))
-    cn = sn["cnt"].cpu().numpy()
-    print("       segments nonempty %d, size pct 50/90/99/max %s" % ((cn > 0).sum(), np.percentile(cn[cn > 0], [50, 90, 99, 100]).astype(int)))
+joint = snaps[0]                    # FLAGS | RESOLVE over the 2S joint lists
+short = snaps[2] if len(snaps) > 2 else snaps[-1]     # COMPACT | SHORT_LISTS over the S LiDAR lists
+n_pts = int(joint["cnt"].sum())
+S2 = joint["S"]
+
+
+def timed(fn):
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return min(ts), float(np.median(ts))
+
+
+def call(sn, phases, cnt=None):
+    orig(sn["px"], sn["py"], sn["pz"], sn["base"], sn["cnt"] if cnt is None else cnt, sn["radius"], p.nb_points, sn["S"],
+         eng.pool_cap, eng.tile_off, eng.flags, eng.queue, phases=phases, shadow=sn["shadow"], n_used=sn["n_used"])
+
+
+t_flags = timed(lambda: call(joint, st.RF_FLAGS))
+nq = int(eng.queue[0:1024:16].sum())
+t_res = timed(lambda: call(joint, st.RF_RESOLVE))
+flags = eng.flags.clone()
+cnt_save = short["cnt"].clone()
+pool_save = [short[k].clone() for k in ("px", "py", "pz")]
+
+
+def compact():
+    call(short, st.RF_COMPACT | st.RF_SHORT_LISTS)
+
+
+ts = []
+for _ in range(reps):
+    short["cnt"].copy_(cnt_save)
+    for k, t in zip(("px", "py", "pz"), pool_save):
+        short[k].copy_(t)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); compact(); e1.record(); e1.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+t_cmp = (min(ts), float(np.median(ts)))
+stage = t_flags[0] + t_res[0] + t_cmp[0]
+print("points %d  segments %d  queued %d (%.3f%%)" % (n_pts, S2, nq, 100.0 * nq / max(n_pts, 1)))
+print("phase A %.1f / %.1f us   phase B %.1f / %.1f us   short compaction %.1f / %.1f us   (best / median, events include ~2 us launch)"
+      % (t_flags + t_res + t_cmp))
+print("stage (best) %.1f us = %.0f GB/s at 21 B/point = %.3f of 8 TB/s; phase A alone %.0f GB/s" %
+      (stage, 21.0 * n_pts / stage / 1e3, 21.0 * n_pts / stage / 1e3 / 8000.0, 21.0 * n_pts / t_flags[0] / 1e3))
+# U lists
+n_ranges = (eng.pool_cap + 511) // 512 + 1
+sh = joint["shadow"]
+uoff = 4 * eng.pool_cap + 12 * n_ranges + 4 * eng.pool_cap + 32
+ucount = sh[uoff:uoff + S2].view(torch.int32).cpu().numpy()
+print("U lists: %d points (%.2f%% of the pool), longest %d" % (ucount.sum(), 100.0 * ucount.sum() / max(n_pts, 1), ucount.max()))
+# keep mask against a brute-force float64 count (sample of segments, all sizes)
+base = joint["base"].cpu().numpy(); cnt = joint["cnt"].cpu().numpy(); rad = joint["radius"].cpu().numpy()
+X = torch.stack([joint["px"], joint["py"], joint["pz"]], 1)
+rng = np.random.default_rng(0)
+order = [s for s in np.argsort(-cnt)[:3]] + list(rng.permutation(np.nonzero(cnt > 0)[0])[:200])
+bad = tot = 0
+for s in order:
+    n = int(cnt[s]);
+    if n == 0:
+        continue
+    P = X[base[s]:base[s] + n]
+    r = float(rad[s])
+    if r == 0.0:
+        exp = torch.ones(n, dtype=torch.bool, device=dev)
+    elif not r > 0.0:
+        exp = torch.zeros(n, dtype=torch.bool, device=dev)
+    else:
+        exp = torch.empty(n, dtype=torch.bool, device=dev)
+        for q0 in range(0, n, 4096):
+            Q = P[q0:q0 + 4096]
+            c = torch.zeros(Q.shape[0], dtype=torch.int64, device=dev)
+            for j0 in range(0, n, 16384):
+                R = P[j0:j0 + 16384]
+                dx = Q[:, None, 0] - R[None, :, 0]; dy = Q[:, None, 1] - R[None, :, 1]; dz = Q[:, None, 2] - R[None, :, 2]
+                d = dx * dx; d = d + dy * dy; d = d + dz * dz
+                c += (d < r * r).sum(1)
+            exp[q0:q0 + 4096] = c > p.nb_points
+    got = flags[base[s]:base[s] + n] != 0
+    bad += int((got != exp).sum()); tot += n
+print("keep mask vs brute force: %d differences in %d points of %d segments" % (bad, tot, len(order)))
