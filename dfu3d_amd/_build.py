@@ -88,11 +88,29 @@ VARIANTS = {
     # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
     "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
     "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
+    # radius filter, phase A: tuning builds (correct results): list neighbours lane^1 / lane^2 or across the rows, no prefetch of the next tile, grids
+    "rf_quad": ["-DDFU3D_RF_NBR=0"],
+    "rf_wave": ["-DDFU3D_RF_NBR=2"],
+    "rf_g2048": ["-DDFU3D_RF_GRID=2048"],
+    "rf_g4096": ["-DDFU3D_RF_GRID=4096"],
+    "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
+    "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
+    "rf_ul4": ["-DDFU3D_RF_UL=4"],
     # radius filter: cycles per phase of k_rf_stream / k_rf_resolve (tools/rf_timing.py)
     "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
     # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
     "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
     "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
+    # radius filter, phase A: tuning builds (correct results): list neighbours lane^1 / lane^2 or across the rows, no prefetch of the next tile, grids
+    "rf_quad": ["-DDFU3D_RF_NBR=0"],
+    "rf_wave": ["-DDFU3D_RF_NBR=2"],
+    "rf_nopf": ["-DDFU3D_RF_NO_PREFETCH"],
+    "rf_g4096": ["-DDFU3D_RF_GRID=4096"],
+    "rf_g1536": ["-DDFU3D_RF_GRID=1536"],
+    "rf_g8192_nopf": ["-DDFU3D_RF_GRID=8192", "-DDFU3D_RF_NO_PREFETCH"],
+    "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
+    "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
+    "rf_ul4": ["-DDFU3D_RF_UL=4"],
     # radius filter, phase B: the points of two candidate ranges requested together (measurement for DESIGN §10 item 1)
     "rf2": ["-DDFU3D_RF_RANGES_PER_STEP=2"],
 }

@@ -316,26 +316,37 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 // the arithmetic) can do; whatever is not certain is decided from the fp64 pool with the
 // reference's predicate d2 < r2 (Open3D / nanoflann, self included).
 //
-// Phase A (k_rf_stream) streams the shadow linearly over the used part of the pool: 2048 positions
-// per workgroup, 512 per wave, all eight loads of a wave issued up front, 64 VGPRs (eight workgroups
-// per compute unit).  A point is tested against its two LIST neighbours (lane ^ 1, lane ^ 2 of its
-// 64-chunk, exchanged with DPP quad permutes -- the lists are in pixel / sweep order, so list
-// neighbours are spatial neighbours).  A point with such a neighbour is COHERENT; for nb_points = 1
-// it is decided at once (~98 % of a dense cloud).  The coherent points of a wave's 512 positions are
-// summarised by one bounding box; they are surface points, so the box is tight.  Everything else --
-// the INCOHERENT points (outliers, sparse sweeps) and, for nb_points > 1, the coherent points that
-// could not collect enough neighbours inside their wave -- goes to a list of the workgroup in LDS and is tried
-// pairwise there.  The workgroup then appends its incoherent points to the U LIST of their segment
-// (ulist[seg_base + k]: a dense array per segment, filled through one atomic per workgroup and
-// segment; at most as long as the segment, so it lives at the segment's own pool positions of a
-// second scratch array) and queues the points that are still undecided.
-// Phase B (k_rf_resolve): one wave per queued point counts from scratch: the incoherent points of its
-// segment (a coalesced sweep over the segment's U list) plus the coherent points of the ranges whose
-// box comes within the radius (a lane per box; a candidate range is re-read and the coherence of its
-// points re-derived with phase A's own function, so every point of the segment is counted exactly
-// once: through the U list or through its range).  A query is a chain of four to five round trips
-// whatever the size of its segment; round 2's version walked the candidate ranges of boxes that
-// outliers had blown up one after the other (0.23 ms for 0.14 % of the points).
+// Phase A (k_rf_stream) is a pure stream over the used part of the pool: a wave takes a RANGE of 512 positions (all
+// eight loads issued up front, 64 VGPRs = eight waves per SIMD, no LDS, no barrier, no returning atomic) and tests every
+// point against its two LIST neighbours (the positions before and behind, inside rows of 16 lanes, DPP row shifts --
+// the lists are in pixel / sweep order, so list neighbours are spatial neighbours).  A point with such a neighbour
+// is COHERENT; for nb_points = 1 it is decided at once (~98 % of a dense cloud).  The coherent points of a range
+// are summarised by one bounding box (they are surface points: the box is tight); every other point -- the
+// INCOHERENT ones (depth outliers that became the representative of their voxel, row ends of a mask, sparse
+// sweeps) and, for nb_points > 1, the coherent points that could not collect enough neighbours inside their
+// chunk -- is LISTED: it goes to the range's U slots (uent / upos[range * 128 + k]), straight from the lane.
+// Phase A' (k_rf_pair): a wave per range puts its U slots, the tail of the range before and the head of the range
+// behind into LDS and counts, for every listed point of its range, the listed points within the radius among the 16
+// before and the 16 behind it in the list.  A lower bound of the true count: above nb_points the point
+// is kept, otherwise it is queued (one returning atomic per wave that has any, on one of 64 counters).  The wave also
+// leaves a second box per range, around its incoherent points.
+// Phase B (k_rf_resolve): one wave per queued point counts from scratch.  A short segment (the LiDAR lists) is
+// simply read whole.  Otherwise: the incoherent points of the segment's ranges (the U slots of the ranges whose
+// second box comes within the radius, nearest ranges first) plus the coherent points of the ranges whose first box
+// comes within the radius (such a range is re-read and the coherence of its points re-derived with phase A's own
+// function, so every point of the segment is counted exactly once: through U slots or through its range).  The
+// first two such ranges are read by the wave itself, further ones become work items of k_rf_ranges.
+// History, all measured on the bench pool (11.5 M points; tools/rf_timing.py, tools/rf_variants.py):
+//  * round 2: phase B walked candidate ranges one after the other: 0.23 ms for 0.14 % of the points (a box that a
+//    pair of neighbouring outliers has blown up is a candidate for every query of its segment: one query had 71);
+//  * a workgroup-wide list, per-segment U lists (one returning atomic per workgroup and segment) and a pairwise stage
+//    behind a barrier made a phase-A workgroup live 36 us (24 of them in a one-partner-per-step loop), 17 us once the
+//    loop was spread over the waves: 186 / 86 us per pass with 2048 resident workgroups of 32 KB each;
+//  * waves on their own with the pairwise stage and the queue atomic at their end: 65 us -- the stream alone takes
+//    35 us, so the lists moved to a pass of their own that touches 2 % of the points;
+//  * three quarters of the workgroups of a grid over the pool's CAPACITY started only to find nothing (14 us of
+//    machine time): the grid is capped and a workgroup walks its tiles;
+//  * wave_shr:1 / wave_shl:1 (neighbours across the rows of 16 lanes) made the chunk loop 40 % longer.
 constexpr int RFB = 256;           // threads per phase-A workgroup
 constexpr int RF_IT = 8;           // 64-point chunks per wave
 constexpr int RF_WG = RFB * RF_IT; // pool positions per workgroup
@@ -344,16 +355,28 @@ constexpr int RF_STRIDE = 8;       // nb_points > 1: lanes 0, 8, 16, ... of the 
 #define DFU3D_RF_OCC 8
 #endif
 constexpr int RF_OCC = DFU3D_RF_OCC;   // phase-A workgroups per compute unit the register allocation aims at
-#ifndef DFU3D_RF_PW
-#define DFU3D_RF_PW 4
+#ifndef DFU3D_RF_GRID
+#define DFU3D_RF_GRID 8192
 #endif
-constexpr int RF_PW = DFU3D_RF_PW;     // partners per step of the pairwise loop
-constexpr int RF_WLIST = 128;      // list of a wave in LDS
-constexpr int RF_LIST = RF_WLIST * (RFB / 64);
+constexpr int RF_GRID = DFU3D_RF_GRID; // phase-A workgroups at most (2048 fit the chip at once)
+constexpr int RF_WLIST = 128;      // U slots of a range
 constexpr uint32_t RF_NOSEG = 0xFFFFu;
-constexpr int BOX_FLOATS = 8;      // per range: min x y z, pad | max x y z, pad  (coherent points only)
+constexpr int BOX_FLOATS = 16;     // per range: coherent min xyz, #listed | coherent max xyz, - | incoherent min xyz, - | incoherent max xyz, -
 constexpr int BOX_SHIFT = 9;       // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
 constexpr float BOX_EMPTY = 3.0e38f;
+#ifndef DFU3D_RF_SC
+#define DFU3D_RF_SC 4
+#endif
+constexpr int RF_SC = DFU3D_RF_SC;     // chunks of a range / a short segment phase B has in flight
+constexpr int RF_DIRECT = 1024;    // phase B reads segments up to this size whole
+constexpr int RF_NEAR = 2;         // phase B looks at the U slots of its own range +- RF_NEAR first
+constexpr int RF_QSHARDS = 64;     // the queue of undecided points has 64 parts, each with its counter on a line of its own
+constexpr int RF_QHDR = RF_QSHARDS * 16;   // (one counter took every wave's atomic: ~90 per microsecond is all one word does)
+constexpr int RF_LQ_CAP = 1 << 16;         // "long" queries: more candidate ranges than their wave scans itself
+constexpr int RF_ITEM_CAP = 1 << 20;       // their (query, range) work items
+constexpr int RF_INLINE_CAND = 2;
+constexpr int RF_WORK_HDR = 32;            // ints: [0] long queries, [16] work items
+constexpr uint32_t RF_INCOH = 0x80000000u; // upos: position | RF_INCOH
 
 // bound on |float32 distance - true distance| for a query at (x,y,z) and neighbours within ~r of it:
 // each coordinate of either point carries <= 2^-24 relative rounding, the differences, squares and
@@ -366,6 +389,10 @@ __device__ __forceinline__ float rf_certain_hit2(float x, float y, float z, floa
   return (t > 0.0f) ? t * t * 0.999999f : -1.0f;
 }
 
+// v_min_f32 / v_max_f32 without the canonicalisation of both operands that fminf / fmaxf add (no NaN can occur here)
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // wave-wide min / max with DPP row operations (VALU, no LDS traffic); the result is valid in lane 63
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float old, float v) {
@@ -373,67 +400,75 @@ __device__ __forceinline__ float dpp_f(float old, float v) {
                                                                CTRL, ROW_MASK, 0xF, false));
 }
 __device__ __forceinline__ float wave_min63(float v) {
-  v = fminf(v, dpp_f<0xB1, 0xF>(v, v));      // quad_perm [1,0,3,2]
-  v = fminf(v, dpp_f<0x4E, 0xF>(v, v));      // quad_perm [2,3,0,1]
-  v = fminf(v, dpp_f<0x141, 0xF>(v, v));     // row_half_mirror
-  v = fminf(v, dpp_f<0x140, 0xF>(v, v));     // row_mirror: every lane of a row holds the row's minimum
-  v = fminf(v, dpp_f<0x142, 0xA>(v, v));     // row_bcast15 into rows 1 and 3
-  v = fminf(v, dpp_f<0x143, 0xC>(v, v));     // row_bcast31 into rows 2 and 3
+  v = min_raw(v, dpp_f<0xB1, 0xF>(v, v));      // quad_perm [1,0,3,2]
+  v = min_raw(v, dpp_f<0x4E, 0xF>(v, v));      // quad_perm [2,3,0,1]
+  v = min_raw(v, dpp_f<0x141, 0xF>(v, v));     // row_half_mirror
+  v = min_raw(v, dpp_f<0x140, 0xF>(v, v));     // row_mirror: every lane of a row holds the row's minimum
+  v = min_raw(v, dpp_f<0x142, 0xA>(v, v));     // row_bcast15 into rows 1 and 3
+  v = min_raw(v, dpp_f<0x143, 0xC>(v, v));     // row_bcast31 into rows 2 and 3
   return v;
 }
 __device__ __forceinline__ float wave_max63(float v) {
-  v = fmaxf(v, dpp_f<0xB1, 0xF>(v, v));
-  v = fmaxf(v, dpp_f<0x4E, 0xF>(v, v));
-  v = fmaxf(v, dpp_f<0x141, 0xF>(v, v));
-  v = fmaxf(v, dpp_f<0x140, 0xF>(v, v));
-  v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));
-  v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
+  v = max_raw(v, dpp_f<0xB1, 0xF>(v, v));
+  v = max_raw(v, dpp_f<0x4E, 0xF>(v, v));
+  v = max_raw(v, dpp_f<0x141, 0xF>(v, v));
+  v = max_raw(v, dpp_f<0x140, 0xF>(v, v));
+  v = max_raw(v, dpp_f<0x142, 0xA>(v, v));
+  v = max_raw(v, dpp_f<0x143, 0xC>(v, v));
   return v;
 }
 
-// v_min_f32 / v_max_f32 without the canonicalisation of both operands that fminf / fmaxf add (no NaN can occur here)
-__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
-// value of lane ^ 1 (CTRL 0xB1) / lane ^ 2 (CTRL 0x4E): quad permutes, every source lane is inside the quad.
-// All 64 lanes must be active where this is called.
+// value of the lane before / behind (DPP row_shr:1 / row_shl:1: inside the rows of 16 lanes; the lane without such
+// a neighbour reads 0).  All 64 lanes must be active where this is called.
+#ifndef DFU3D_RF_NBR
+#define DFU3D_RF_NBR 1
+#endif
+#if DFU3D_RF_NBR == 0
+constexpr int RF_NB1 = 0xB1, RF_NB2 = 0x4E, RF_ND1 = 1, RF_ND2 = 2, RF_NXOR = 1;       // lane ^ 1, lane ^ 2 (quad permutes)
+#elif DFU3D_RF_NBR == 1
+constexpr int RF_NB1 = 0x111, RF_NB2 = 0x101, RF_ND1 = -1, RF_ND2 = 1, RF_NXOR = 0;    // row_shr:1, row_shl:1
+#else
+constexpr int RF_NB1 = 0x138, RF_NB2 = 0x130, RF_ND1 = -1, RF_ND2 = 1, RF_NXOR = 0;    // wave_shr:1, wave_shl:1
+#endif
+// the lane whose point lane `lane` tested as its neighbour number d (-1 where the permute reads nothing)
+__device__ __forceinline__ int rf_nbr_lane(int lane, int d) {
+  if (RF_NXOR) return lane ^ d;
+  const int t = lane + d;
+  if (DFU3D_RF_NBR == 1) return ((t >> 4) == (lane >> 4)) ? t : -1;
+  return (t >= 0 && t < 64) ? t : -1;
+}
 template <int CTRL>
-__device__ __forceinline__ float quad_f(float v) {
+__device__ __forceinline__ float nbr_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
-__device__ __forceinline__ uint32_t quad_u(uint32_t v) {
+__device__ __forceinline__ uint32_t nbr_u(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // The list-neighbour test, shared by phase A and by phase B's re-derivation (the two must agree bit for bit:
-// same expression, no contraction).  wb: the shadow word (segment | radius) -- equal words <=> same segment.
+// same expression, no contraction).  wb: the shadow word (segment | radius) -- equal words <=> same segment; a word
+// of 0 (what a lane reads for a missing neighbour) is segment 0 WITHOUT a radius, i.e. never the word of an active
+// point.  (First version: lane ^ 1 and lane ^ 2 -- 2.9 % of the bench pool incoherent against 2.2 %: one point of
+// three at the end of a mask row had both partners in the next row.)
 __device__ __forceinline__ void rf_list_neighbours(float x, float y, float z, uint32_t wb, float thr2, bool &h1, bool &h2) {
-  const float x1 = quad_f<0xB1>(x), y1 = quad_f<0xB1>(y), z1 = quad_f<0xB1>(z);
-  const float x2 = quad_f<0x4E>(x), y2 = quad_f<0x4E>(y), z2 = quad_f<0x4E>(z);
-  const uint32_t w1 = quad_u<0xB1>(wb), w2 = quad_u<0x4E>(wb);
+  const float x1 = nbr_f<RF_NB1>(x), y1 = nbr_f<RF_NB1>(y), z1 = nbr_f<RF_NB1>(z);
+  const float x2 = nbr_f<RF_NB2>(x), y2 = nbr_f<RF_NB2>(y), z2 = nbr_f<RF_NB2>(z);
+  const uint32_t w1 = nbr_u<RF_NB1>(wb), w2 = nbr_u<RF_NB2>(wb);
   float dx = x - x1, dy = y - y1, dz = z - z1;
   h1 = (w1 == wb) & (dx * dx + dy * dy + dz * dz < thr2);
   dx = x - x2; dy = y - y2; dz = z - z2;
   h2 = (w2 == wb) & (dx * dx + dy * dy + dz * dz < thr2);
 }
-__device__ __forceinline__ float4 rf_noseg_point() { return make_float4(0.f, 0.f, 0.f, __uint_as_float(RF_NOSEG << 16)); }
-
-// entry of a workgroup's LDS list: s_meta = position in the workgroup (11 bits) | incoherent << 11 | pending << 12 | count << 16
-constexpr uint32_t RFM_INCOH = 1u << 11, RFM_PEND = 1u << 12;
-constexpr int RF_QSHARDS = 64;             // the queue of undecided points has 64 parts, each with its counter on a line of its own
-constexpr int RF_QHDR = RF_QSHARDS * 16;   // (one counter took every workgroup's atomic: ~90 per microsecond is all one word does)
-constexpr int RF_LQ_CAP = 1 << 16;         // "long" queries: more candidate ranges than their wave scans itself
-constexpr int RF_ITEM_CAP = 1 << 20;       // their (query, range) work items
-constexpr int RF_INLINE_CAND = 2;
-constexpr int RF_WORK_HDR = 32;            // ints: [0] long queries, [16] work items
 
 struct RfScratch {
   uint8_t *flags;
   int *queue;               // [16 q]: length of part q; part q = queue + RF_QHDR + q * qcap
   long long qcap;
-  float *dbox;              // BOX_FLOATS per range
-  float4 *ulist;            // (x, y, z, pool position) of the incoherent points of segment s at seg_base[s] + k, k < ucount[s]
+  float *rrec;              // BOX_FLOATS per range
+  float4 *uent;             // (x, y, z, shadow word) of listed point k of range rg at rg * RF_WLIST + k, k < #listed (rrec[.][3])
+  uint32_t *upos;           // its pool position | RF_INCOH
+  float4 *ulist;            // (x, y, z, position) of incoherent points that found their range's slots full: per segment, at seg_base[s] + k, k < ucount[s]
   int *work;                // RF_WORK_HDR counters | ucount (65536) | long-query records (4 ints) | work items (2 ints)
   int *ucount;
   const long long *seg_base;
@@ -442,10 +477,19 @@ __host__ __device__ inline long long rf_queue_part_cap(long long pool_cap) {
   const long long nwg = (pool_cap + RF_WG - 1) / RF_WG;
   return ((nwg + RF_QSHARDS - 1) / RF_QSHARDS) * RF_WG;
 }
+// append to the part of the queue that belongs to `key` (any number; consecutive keys use different counters)
+__device__ __forceinline__ void rf_queue_push(const RfScratch &W, long long key, unsigned long long mask, bool mine, uint32_t gpos) {
+  const int lane = lane_id();
+  const int qs = (int)(key % RF_QSHARDS);
+  int g = 0;
+  if (lane == 0) g = atomicAdd(&W.queue[16 * qs], __popcll(mask));
+  g = __builtin_amdgcn_readfirstlane(g);
+  if (mine) W.queue[RF_QHDR + qs * W.qcap + g + __popcll(mask & ((1ull << lane) - 1ull))] = (int)gpos;
+}
 
-#ifdef DFU3D_DBG_RF_TIMING         /* dev build (tools/rf_timing.py): clock64 of thread 0 / lane 0 at the phase marks, one record per workgroup / wave (plain stores) */
+#ifdef DFU3D_DBG_RF_TIMING         /* dev build (tools/rf_timing.py): clock64 of lane 0 at the phase marks, one record per wave (plain stores) */
 constexpr int RF_DBG_WG = 32768, RF_DBG_F = 12;
-__device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recB[16384 * RF_DBG_F];
+__device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recP[RF_DBG_WG * RF_DBG_F], g_rf_recB[16384 * RF_DBG_F];
 #define RF_T(k) do { const long long t_ = clock64(); rf_rec[k] += (unsigned int)(t_ - rf_t); rf_t = t_; } while (0)
 #else
 #define RF_T(k) do {} while (0)
@@ -454,238 +498,220 @@ __device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recB[16384 *
 template <bool NB1>
 __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S, RfScratch W) {
-  // the list of the workgroup: one part per wave (no atomics, a chunk's registers are free as soon as it is done)
-  __shared__ float4 s_pt[RF_LIST + 4];
-  __shared__ uint32_t s_meta[RF_LIST + 4];
-  __shared__ int s_hit[RF_LIST];
-  __shared__ int s_wn[RFB / 64], s_nq, s_base;
   long long n_used = n_max;
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
-  const long long wg0 = (long long)blockIdx.x * RF_WG;
-  if (wg0 >= n_used) return;
-  if (threadIdx.x == 0) s_nq = 0;
-#pragma unroll
-  for (int k = 0; k < RF_LIST / RFB; k++) s_hit[k * RFB + threadIdx.x] = 0;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the wave's addresses are SGPR base + lane)
-  const long long w0 = wg0 + (long long)wave * (64 * RF_IT);
+  // the grid is capped (a pool is sized for the worst case); a workgroup walks its tiles
+  for (long long wg0 = (long long)blockIdx.x * RF_WG; wg0 < n_used; wg0 += (long long)gridDim.x * RF_WG) {
+    const long long w0 = wg0 + (long long)wave * (64 * RF_IT);
+    if (w0 >= n_used) break;
 #ifdef DFU3D_DBG_RF_TIMING
-  unsigned int rf_rec[5] = {0};
-  long long rf_t = clock64();
-  const unsigned long long rf_r0 = wall_clock64();
-  auto rf_flush = [&](int np_) {
-    if (threadIdx.x == 0 && blockIdx.x < RF_DBG_WG) {
-      unsigned long long *o_ = g_rf_recA + (size_t)blockIdx.x * RF_DBG_F;
-      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
-      o_[5] = 1; o_[6] = (unsigned long long)np_; o_[8] = rf_r0; o_[9] = wall_clock64();
-    }
-  };
+    unsigned int rf_rec[5] = {0};
+    long long rf_t = clock64();
+    const unsigned long long rf_r0 = wall_clock64();
 #endif
-  // (positions at or beyond n_used are read all the same -- the scratch allocation extends megabytes beyond the
-  // shadow proper -- and marked "no segment" afterwards: eight loads, no branch between them)
-  float4 p[RF_IT];
+    // (positions at or beyond n_used are read all the same -- the scratch allocation extends megabytes beyond the
+    // shadow proper -- and marked "no segment" afterwards: eight loads, no branch between them)
+    float4 p[RF_IT];
 #pragma unroll
-  for (int it = 0; it < RF_IT; it++) p[it] = pq[w0 + it * 64 + lane];
-  const int lim = (int)min(max(n_used - w0, 0ll), (long long)(64 * RF_IT));     // (scalar)
-  RF_T(0);
-  float lx = BOX_EMPTY, ly = BOX_EMPTY, lz = BOX_EMPTY, hx = -BOX_EMPTY, hy = -BOX_EMPTY, hz = -BOX_EMPTY;
-  int run = 0;                                    // listed points of this wave so far (wave-uniform)
+    for (int it = 0; it < RF_IT; it++) p[it] = pq[w0 + it * 64 + lane];
+    const int lim = (int)min(n_used - w0, (long long)(64 * RF_IT));     // (scalar)
+    RF_T(0);
+    const long long rg = w0 >> BOX_SHIFT;
+    float4 *my_ent = W.uent + rg * RF_WLIST;
+    uint32_t *my_pos = W.upos + rg * RF_WLIST;
+    float lx = BOX_EMPTY, ly = BOX_EMPTY, lz = BOX_EMPTY, hx = -BOX_EMPTY, hy = -BOX_EMPTY, hz = -BOX_EMPTY;
+    int run = 0;                                    // listed points of this wave so far (wave-uniform)
 #pragma unroll
-  for (int it = 0; it < RF_IT; it++) {
-    const long long i = w0 + it * 64 + lane;
-    const float x = p[it].x, y = p[it].y, z = p[it].z;
-    const uint32_t wb = (it * 64 + lane < lim) ? __float_as_uint(p[it].w) : (RF_NOSEG << 16);
-    const float r = __uint_as_float(wb << 16);
-    const bool valid = (wb >> 16) < (uint32_t)S;    // "no segment" mark, or a slot nobody wrote: never a point
-    const bool active = valid && (r > 0.0f);
-    const float thr2 = rf_certain_hit2(x, y, z, r);
-    bool h1, h2;
-    rf_list_neighbours(x, y, z, wb, thr2, h1, h2);
-    const bool coh = active && (h1 || h2);
-    bool listed, pend;
-    int cnt = 1;                                    // the query itself (d = 0 < r^2)
-    if (NB1) {
-      listed = active && !coh;
-      pend = listed;
-    } else {
-      cnt += (h1 ? 1 : 0) + (h2 ? 1 : 0);
-      if (__ballot(active && cnt <= nb)) {
-        const int l1 = lane ^ 1, l2 = lane ^ 2;
-        for (int j = 0; j < 64; j += RF_STRIDE) {
-          const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
-          const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), j));
-          const float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), j));
-          const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)wb, j);
-          const float dx = x - xj, dy = y - yj, dz = z - zj;
-          if (wj == wb && dx * dx + dy * dy + dz * dz < thr2 && j != lane && j != l1 && j != l2) cnt++;
-          if (__ballot(active && cnt <= nb) == 0ull) break;
-        }
-      }
-      pend = active && cnt <= nb;
-      listed = active && (pend || !coh);
-    }
-    // decided here: inactive segments (r == 0: no filter; r < 0 / NaN: drop all) and the coherent points that
-    // are not listed; the listed points get their flag at the end of the workgroup
-#ifndef DFU3D_DBG_RF_NOFLAGS
-    if (valid && !listed) W.flags[i] = active ? 1 : ((r == 0.0f) ? 1 : 0);
-#endif
-    lx = min_raw(lx, coh ? x : BOX_EMPTY); ly = min_raw(ly, coh ? y : BOX_EMPTY); lz = min_raw(lz, coh ? z : BOX_EMPTY);
-    hx = max_raw(hx, coh ? x : -BOX_EMPTY); hy = max_raw(hy, coh ? y : -BOX_EMPTY); hz = max_raw(hz, coh ? z : -BOX_EMPTY);
-    const unsigned long long m = __ballot(listed);
-    if (m) {
-      if (listed) {
-        const int slot = run + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot < RF_WLIST) {
-          s_pt[wave * RF_WLIST + slot] = make_float4(x, y, z, __uint_as_float(wb));
-          s_meta[wave * RF_WLIST + slot] = (uint32_t)(i - wg0) | (coh ? 0u : RFM_INCOH) | (pend ? RFM_PEND : 0u) | ((uint32_t)min(cnt, 15) << 16);
-        } else {                     // list full (a pathological tile): straight to the segment's U list / the queue
-          const uint32_t seg = wb >> 16;
-          if (!coh) {
-            const int k = atomicAdd(&W.ucount[seg], 1);
-            W.ulist[W.seg_base[seg] + k] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
+    for (int it = 0; it < RF_IT; it++) {
+      const long long i = w0 + it * 64 + lane;
+      const float x = p[it].x, y = p[it].y, z = p[it].z;
+      const uint32_t wb = (it * 64 + lane < lim) ? __float_as_uint(p[it].w) : (RF_NOSEG << 16);
+      const float r = __uint_as_float(wb << 16);
+      const bool valid = (wb >> 16) < (uint32_t)S;    // "no segment" mark, or a slot nobody wrote: never a point
+      const bool active = valid && (r > 0.0f);
+      const float thr2 = rf_certain_hit2(x, y, z, r);
+      bool h1, h2;
+      rf_list_neighbours(x, y, z, wb, thr2, h1, h2);
+      const bool coh = active && (h1 || h2);
+      bool listed;
+      if (NB1) {
+        listed = active && !coh;
+      } else {
+        int cnt = 1 + (h1 ? 1 : 0) + (h2 ? 1 : 0);   // the point itself (d = 0 < r^2) and its list neighbours
+        if (__ballot(active && cnt <= nb)) {
+          const int l1 = rf_nbr_lane(lane, RF_ND1), l2 = rf_nbr_lane(lane, RF_ND2);
+          for (int j = 0; j < 64; j += RF_STRIDE) {
+            const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+            const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), j));
+            const float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), j));
+            const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)wb, j);
+            const float dx = x - xj, dy = y - yj, dz = z - zj;
+            if (wj == wb && dx * dx + dy * dy + dz * dz < thr2 && j != lane && j != l1 && j != l2) cnt++;
+            if (__ballot(active && cnt <= nb) == 0ull) break;
           }
-          if (pend) {
-            const int qs = (int)(blockIdx.x % RF_QSHARDS);
+        }
+        listed = active && (cnt <= nb || !coh);
+      }
+      // decided here: inactive segments (r == 0: no filter; r < 0 / NaN: drop all) and the coherent points that
+      // are not listed; a listed point gets its flag in phase A' (or B)
+#ifndef DFU3D_DBG_RF_NOFLAGS
+      if (valid && !listed) W.flags[i] = active ? 1 : ((r == 0.0f) ? 1 : 0);
+#endif
+      lx = min_raw(lx, coh ? x : BOX_EMPTY); ly = min_raw(ly, coh ? y : BOX_EMPTY); lz = min_raw(lz, coh ? z : BOX_EMPTY);
+      hx = max_raw(hx, coh ? x : -BOX_EMPTY); hy = max_raw(hy, coh ? y : -BOX_EMPTY); hz = max_raw(hz, coh ? z : -BOX_EMPTY);
+      const unsigned long long m = __ballot(listed);
+      if (m) {
+        if (listed) {
+          const int slot = run + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot < RF_WLIST) {
+            my_ent[slot] = make_float4(x, y, z, __uint_as_float(wb));
+            my_pos[slot] = (uint32_t)i | (coh ? 0u : RF_INCOH);
+          } else {                     // slots full (a pathological range): the segment's overflow list and the queue
+            const uint32_t seg = wb >> 16;
+            if (!coh) {
+              const int k = atomicAdd(&W.ucount[seg], 1);
+              W.ulist[W.seg_base[seg] + k] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
+            }
+            const int qs = (int)(rg % RF_QSHARDS);
             const int g = atomicAdd(&W.queue[16 * qs], 1);
             W.queue[RF_QHDR + qs * W.qcap + g] = (int)i;
+            W.flags[i] = 0;
           }
-          W.flags[i] = pend ? 0 : 1;
         }
+        run += __popcll(m);
       }
-      run += __popcll(m);
     }
-  }
-  RF_T(1);
-  {
+    RF_T(1);
     lx = wave_min63(lx); ly = wave_min63(ly); lz = wave_min63(lz);
     hx = wave_max63(hx); hy = wave_max63(hy); hz = wave_max63(hz);
-    if (lane == 63 && w0 < n_used) {
-      float4 *o = (float4 *)(W.dbox + (size_t)(w0 >> BOX_SHIFT) * BOX_FLOATS);
-      o[0] = make_float4(lx, ly, lz, 0.0f);
+    if (lane == 63) {
+      float4 *o = (float4 *)(W.rrec + (size_t)rg * BOX_FLOATS);
+      o[0] = make_float4(lx, ly, lz, __int_as_float(min(run, RF_WLIST)));
       o[1] = make_float4(hx, hy, hz, 0.0f);
     }
-  }
-#ifdef DFU3D_DBG_RF_NOTAIL          /* dev build (wrong results): the streaming part alone */
-  return;
-#endif
-  // The wave's incoherent points join the U lists of their segments: one returning atomic per segment (the lists
-  // are in position order, so a segment's points are neighbours), issued while the other waves still stream.
-  const int nw = min(run, RF_WLIST);
-  __builtin_amdgcn_wave_barrier();
-  for (int k0 = 0; k0 < nw; k0 += 64) {           // uniform
-    const int k = k0 + lane;
-    const bool v = k < nw;
-    const float4 q = s_pt[wave * RF_WLIST + (v ? k : 0)];
-    const uint32_t mq = v ? s_meta[wave * RF_WLIST + k] : 0u;
-    const uint32_t wq = __float_as_uint(q.w);
-    unsigned long long rem = __ballot(v && (mq & RFM_INCOH));
-    while (rem) {                                  // uniform: one round per segment
-      const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
-      const uint32_t wseg = (uint32_t)__builtin_amdgcn_readlane((int)wq, first);
-      const bool mine = ((rem >> lane) & 1ull) && wq == wseg;
-      const unsigned long long mm = __ballot(mine);
-      long long base = 0;
-      if (lane == first) {
-        const uint32_t seg = wseg >> 16;
-        base = W.seg_base[seg] + atomicAdd(&W.ucount[seg], __popcll(mm));
-      }
-      const int blo = __builtin_amdgcn_readlane((int)(base & 0xFFFFFFFFll), first);
-      const int bhi = __builtin_amdgcn_readlane((int)(base >> 32), first);
-      if (mine) {
-        const long long d = (((long long)bhi << 32) | (unsigned int)blo) + __popcll(mm & ((1ull << lane) - 1ull));
-        W.ulist[d] = make_float4(q.x, q.y, q.z, __uint_as_float((uint32_t)(wg0 + (mq & 0x7FFu))));
-      }
-      rem &= ~mm;
-    }
-  }
-  if (lane == 0) s_wn[wave] = nw;
-  __syncthreads();
-  RF_T(2);
-  int wn[RFB / 64], pre[RFB / 64];
-  int np = 0;
-#pragma unroll
-  for (int w = 0; w < RFB / 64; w++) { wn[w] = s_wn[w]; pre[w] = np; np += wn[w]; }
 #ifdef DFU3D_DBG_RF_TIMING
-  if (np == 0) rf_flush(0);
+    RF_T(2);
+    if (lane == 0 && rg < RF_DBG_WG) {
+      unsigned long long *o_ = g_rf_recA + (size_t)rg * RF_DBG_F;
+      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
+      o_[5] = 1; o_[6] = (unsigned long long)run; o_[8] = rf_r0; o_[9] = wall_clock64();
+    }
 #endif
-  if (np == 0) return;
-  // Pairwise among the workgroup's listed points.  Entry c (in position order over the four parts) is looked after by
-  // lane c % 64 of EVERY wave, wave w testing it against the partners of part w only; the hits meet in s_hit.  A partner
-  // that the entry's wave already looked at (same chunk: lane^1, lane^2 and, for nb_points > 1, the broadcast lanes
-  // 0, 8, ...) must not be counted twice (for nb_points = 1 a pending point has no hit among them, only the point
-  // itself has to be left out).  Four partners per step, their LDS reads requested together, no branches: the first
-  // version (one thread per entry, one partner per step, two dependent LDS reads and three branches) spent 24 of a
-  // workgroup's 36 microseconds here, one wave of four-partner steps still 6.6.
-  auto entry_slot = [&](int c) -> int {
-    const int w = (c >= pre[1] ? 1 : 0) + (c >= pre[2] ? 1 : 0) + (c >= pre[3] ? 1 : 0);
-    return w * RF_WLIST + (c - (w == 0 ? 0 : w == 1 ? pre[1] : w == 2 ? pre[2] : pre[3]));
-  };
-  const int n_mine = wn[0] * (wave == 0) + wn[1] * (wave == 1) + wn[2] * (wave == 2) + wn[3] * (wave == 3);
-#pragma unroll 1
-  for (int c0 = 0; c0 < np; c0 += 64) {                  // uniform
-    const int c = c0 + lane;
-    const bool live = c < np;
-    const int a = entry_slot(live ? c : 0);
-    const float4 q = s_pt[a];
-    const uint32_t wa = __float_as_uint(q.w), ma = s_meta[a];
-    const bool pend_a = live && (ma & RFM_PEND);
-    if (__ballot(pend_a) == 0ull) continue;
-    const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
-    const int pa = (int)(ma & 0x7FFu), la = pa & 63;
-    int hits = 0;
-#pragma unroll 1
-    for (int k2 = 0; k2 < n_mine; k2 += RF_PW) {
-      float4 o[RF_PW];
-      uint32_t mb[RF_PW];
-#pragma unroll
-      for (int u = 0; u < RF_PW; u++) { o[u] = s_pt[wave * RF_WLIST + k2 + u]; mb[u] = s_meta[wave * RF_WLIST + k2 + u]; }
-#pragma unroll
-      for (int u = 0; u < RF_PW; u++) {
-        const int pb = (int)(mb[u] & 0x7FFu), lb = pb & 63;
-        const bool seen = NB1 ? (pb == pa)
-                              : (((pb >> 6) == (pa >> 6)) &
-                                 ((lb == la) | (lb == (la ^ 1)) | (lb == (la ^ 2)) | ((lb & (RF_STRIDE - 1)) == 0)));
-        const float dx = q.x - o[u].x, dy = q.y - o[u].y, dz = q.z - o[u].z;
-        const bool hit = (k2 + u < n_mine) & (__float_as_uint(o[u].w) == wa) & !seen & (dx * dx + dy * dy + dz * dz < thr2);
-        hits += hit ? 1 : 0;
+  }
+}
+
+// Phase A': one wave per range.  The listed points of the range, the last RF_WIN of the range before and the first
+// RF_WIN of the range behind stand in LDS in list order; listed point c is tested against the RF_WIN listed points
+// before and the RF_WIN behind it (itself included: d = 0), a lane per point, every lane its own partner -- 2 RF_WIN + 1
+// steps whatever the number of listed points.  Measured before this: a wave per FOUR ranges with all pairs in LDS
+// (ranges of sparse or noisy lists have a hundred listed points: single waves ran for 60 us, the pass took 72 us);
+// a wave per range, all pairs, partners broadcast with v_readlane (64 us, 43 us with the partners capped).
+constexpr int RF_WIN = 16;
+constexpr int RF_PLDS = RF_WLIST + 2 * RF_WIN;
+__global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n_used_ptr, long long n_max, int nb, RfScratch W) {
+  __shared__ float4 s_e[4][RF_PLDS];
+  long long n_used = n_max;
+  if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
+  const long long n_rg = (n_used + (1 << BOX_SHIFT) - 1) >> BOX_SHIFT;
+  const int lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4 *my_e = s_e[wv];
+  for (long long rg = (long long)blockIdx.x * 4 + wv; rg < n_rg; rg += (long long)gridDim.x * 4) {
+#ifdef DFU3D_DBG_RF_TIMING
+    unsigned int rf_rec[5] = {0};
+    long long rf_t = clock64();
+#endif
+    // lane l < 3: the number of listed points of range rg - 1 + l (0 outside the used ranges)
+    int nl = 0;
+    {
+      const long long rgl = rg - 1 + lane;
+      if (lane < 3 && rgl >= 0 && rgl < n_rg) nl = min(max(__float_as_int(W.rrec[(size_t)rgl * BOX_FLOATS + 3]), 0), RF_WLIST);
+    }
+    const int n_own = __builtin_amdgcn_readlane(nl, 1);
+    float4 *rec = (float4 *)(W.rrec + (size_t)rg * BOX_FLOATS);
+    if (n_own == 0) {                                // nothing listed here: only the (empty) second box
+      if (lane == 0) {
+        rec[2] = make_float4(BOX_EMPTY, BOX_EMPTY, BOX_EMPTY, 0.0f);
+        rec[3] = make_float4(-BOX_EMPTY, -BOX_EMPTY, -BOX_EMPTY, 0.0f);
+      }
+      continue;
+    }
+    const int n_prev = __builtin_amdgcn_readlane(nl, 0), n_next = __builtin_amdgcn_readlane(nl, 2);
+    const int t_prev = min(n_prev, RF_WIN), t_next = min(n_next, RF_WIN);     // what of the neighbours is taken
+    // all loads first: the range (two halves), its positions, the tail before, the head behind
+    const bool v0 = lane < n_own, v1 = lane + 64 < n_own;
+    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q0 = v0 ? W.uent[rg * RF_WLIST + lane] : none;
+    const uint32_t p0 = v0 ? W.upos[rg * RF_WLIST + lane] : 0u;
+    float4 q1 = none, eh = none;
+    uint32_t p1 = 0u;
+    if (n_own > 64) {                                // uniform
+      if (v1) { q1 = W.uent[rg * RF_WLIST + 64 + lane]; p1 = W.upos[rg * RF_WLIST + 64 + lane]; }
+    }
+    // lanes 0 .. t_prev-1: the tail of the range before; lanes 32 .. 32+t_next-1: the head of the range behind
+    if (lane < t_prev) eh = W.uent[(rg - 1) * RF_WLIST + n_prev - t_prev + lane];
+    else if (lane >= 32 && lane - 32 < t_next) eh = W.uent[(rg + 1) * RF_WLIST + lane - 32];
+    RF_T(0);
+    // LDS, list order: [RF_WIN - t_prev, RF_WIN) tail | [RF_WIN, RF_WIN + n_own) own | [.., + t_next) head
+    __builtin_amdgcn_wave_barrier();
+    if (v0) my_e[RF_WIN + lane] = q0;
+    if (v1) my_e[RF_WIN + 64 + lane] = q1;
+    if (lane < t_prev) my_e[RF_WIN - t_prev + lane] = eh;
+    else if (lane >= 32 && lane - 32 < t_next) my_e[RF_WIN + n_own + lane - 32] = eh;
+    {                                                // the box around the range's incoherent points
+      const bool i0 = (p0 & RF_INCOH) != 0u, i1 = (p1 & RF_INCOH) != 0u;
+      float ux = min_raw(i0 ? q0.x : BOX_EMPTY, i1 ? q1.x : BOX_EMPTY), uy = min_raw(i0 ? q0.y : BOX_EMPTY, i1 ? q1.y : BOX_EMPTY),
+            uz = min_raw(i0 ? q0.z : BOX_EMPTY, i1 ? q1.z : BOX_EMPTY);
+      float vx = max_raw(i0 ? q0.x : -BOX_EMPTY, i1 ? q1.x : -BOX_EMPTY), vy = max_raw(i0 ? q0.y : -BOX_EMPTY, i1 ? q1.y : -BOX_EMPTY),
+            vz = max_raw(i0 ? q0.z : -BOX_EMPTY, i1 ? q1.z : -BOX_EMPTY);
+      ux = wave_min63(ux); uy = wave_min63(uy); uz = wave_min63(uz);
+      vx = wave_max63(vx); vy = wave_max63(vy); vz = wave_max63(vz);
+      if (lane == 63) {
+        rec[2] = make_float4(ux, uy, uz, 0.0f);
+        rec[3] = make_float4(vx, vy, vz, 0.0f);
       }
     }
-    if (pend_a && hits) atomicAdd(&s_hit[c], hits);
-  }
-  RF_T(3);
-  __syncthreads();
-  constexpr int ROUNDS = RF_LIST / RFB;
-  int e_qk[ROUNDS], e_pos[ROUNDS];
-  bool e_pend[ROUNDS];
+    __builtin_amdgcn_wave_barrier();
+    const int lo = RF_WIN - t_prev, hi = RF_WIN + n_own + t_next;      // the filled part of the LDS list
 #pragma unroll
-  for (int rd = 0; rd < ROUNDS; rd++) {
-    const int c = rd * RFB + (int)threadIdx.x;
-    e_qk[rd] = 0; e_pos[rd] = 0; e_pend[rd] = false;
-    if (c >= np) continue;
-    const uint32_t ma = s_meta[entry_slot(c)];
-    const int pa = (int)(ma & 0x7FFu);
-    const bool pend = (ma & RFM_PEND) && ((int)((ma >> 16) & 15u) + s_hit[c] <= nb);
-    e_pos[rd] = pa;
-    e_pend[rd] = pend;
-    W.flags[wg0 + pa] = pend ? 0 : 1;
-    if (pend) e_qk[rd] = atomicAdd(&s_nq, 1);
-  }
-  __syncthreads();
-  const int nq = s_nq;
-#ifdef DFU3D_DBG_RF_TIMING
-  if (nq == 0) rf_flush(np);
-#endif
-  if (nq == 0) return;
-  const int qs = (int)(blockIdx.x % RF_QSHARDS);
-  if (threadIdx.x == 0) s_base = atomicAdd(&W.queue[16 * qs], nq);        // one global atomic per workgroup
-  __syncthreads();
+    for (int h = 0; h < 2; h++) {
+      if (n_own <= h * 64) break;                    // uniform
+      const bool v = h ? v1 : v0;
+      const float4 q = h ? q1 : q0;
+      const uint32_t wa = __float_as_uint(q.w);
+      const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
+      const int ci = RF_WIN + h * 64 + lane;         // the point's own place in the LDS list
+      int cnt = 0;
+#pragma unroll 1
+      for (int d0 = -RF_WIN; d0 <= RF_WIN; d0 += 4) {
+        float4 o[4];
 #pragma unroll
-  for (int rd = 0; rd < ROUNDS; rd++)
-    if (e_pend[rd]) W.queue[RF_QHDR + qs * W.qcap + s_base + e_qk[rd]] = (int)(wg0 + e_pos[rd]);
+        for (int u = 0; u < 4; u++) o[u] = my_e[min(max(ci + d0 + u, 0), RF_PLDS - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = ci + d0 + u;
+          const float dx = q.x - o[u].x, dy = q.y - o[u].y, dz = q.z - o[u].z;
+          cnt += ((d0 + u <= RF_WIN) & (k >= lo) & (k < hi) & (__float_as_uint(o[u].w) == wa) & (dx * dx + dy * dy + dz * dz < thr2)) ? 1 : 0;
+        }
+        if (__ballot(v && cnt <= nb) == 0ull) break;
+      }
+      const bool pend = v && cnt <= nb;
+      const uint32_t gpos = (h ? p1 : p0) & ~RF_INCOH;
+      if (v) W.flags[gpos] = pend ? 0 : 1;
+      const unsigned long long mp = __ballot(pend);
+      if (mp) rf_queue_push(W, rg, mp, pend, gpos);
+    }
 #ifdef DFU3D_DBG_RF_TIMING
-  RF_T(4);
-  rf_flush(np);
+    RF_T(1);
+    if (lane == 0 && rg < RF_DBG_WG) {
+      unsigned long long *o_ = g_rf_recP + (size_t)rg * RF_DBG_F;
+      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
+      o_[5] = 1; o_[6] = (unsigned long long)n_own; o_[7] = (unsigned long long)(hi - lo);
+    }
 #endif
+  }
 }
 
 // squared distance from q to an axis-aligned box (0 inside)
@@ -705,13 +731,14 @@ struct RfQuery {
   double x, y, z, r2;
   float lo2, hi2;       // float32 screening: certainly inside below lo2, certainly outside above hi2, fp64 in between
 };
-__device__ __forceinline__ bool rf_load_query(RfQuery &Q, long long i, const float4 *pq, const double *px, const double *py,
-                                              const double *pz, const long long *seg_base, const int *seg_cnt,
-                                              const double *radius, int S) {
+__device__ __forceinline__ bool rf_load_query(RfQuery &Q, long long i, long long n_max, const float4 *pq, const double *px,
+                                              const double *py, const double *pz, const long long *seg_base,
+                                              const int *seg_cnt, const double *radius, int S) {
+  if (i < 0 || i >= n_max) return false;
   Q.i = i;
   Q.qf = pq[i];
   Q.wq = __float_as_uint(Q.qf.w);
-  const int s = (int)(Q.wq >> 16);                       // < S: phase A queues nothing else
+  const int s = (int)(Q.wq >> 16);                       // < S: nothing else is ever queued
   if (s >= S) return false;
   const int n = max(seg_cnt[s], 0);
   Q.base = seg_base[s];
@@ -725,9 +752,23 @@ __device__ __forceinline__ bool rf_load_query(RfQuery &Q, long long i, const flo
   const float tl = rf - eb, th = rf + eb;
   Q.lo2 = (tl > 0.0f) ? tl * tl * 0.999999f : -1.0f;
   Q.hi2 = th * th * 1.000001f;
+  // every lane holds the same query: keep it in scalar registers (twenty vector registers otherwise)
+  auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto sd = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  auto sl = [](long long v) {
+    return (long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFll)));
+  };
+  Q.i = sl(Q.i); Q.base = sl(Q.base); Q.end = sl(Q.end);
+  Q.qf = make_float4(sf(Q.qf.x), sf(Q.qf.y), sf(Q.qf.z), sf(Q.qf.w));
+  Q.wq = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.wq);
+  Q.x = sd(Q.x); Q.y = sd(Q.y); Q.z = sd(Q.z); Q.r2 = sd(Q.r2);
+  Q.lo2 = sf(Q.lo2); Q.hi2 = sf(Q.hi2);
   return true;
 }
-// is the point with shadow o at pool position g within the radius of the query?
+// is the point with float32 coordinates o at pool position g within the radius of the query?
 __device__ __forceinline__ bool rf_within(const RfQuery &Q, const float4 &o, long long g, const double *px, const double *py,
                                           const double *pz) {
   const float dx = Q.qf.x - o.x, dy = Q.qf.y - o.y, dz = Q.qf.z - o.z;
@@ -747,31 +788,86 @@ __device__ __forceinline__ bool rf_within(const RfQuery &Q, const float4 &o, lon
 __device__ __forceinline__ int rf_scan_range(const RfQuery &Q, long long rg, const float4 *pq, long long n_used,
                                              const double *px, const double *py, const double *pz) {
   const int lane = lane_id();
-  const long long c0 = rg << (BOX_SHIFT - 6);
-  float4 o[RF_IT];
+  int cnt = 0;
+#pragma unroll 1
+  for (int half = 0; half < RF_IT / RF_SC; half++) {
+    const long long c0 = (rg << (BOX_SHIFT - 6)) + half * RF_SC;
+    float4 o[RF_SC];
 #pragma unroll
-  for (int u = 0; u < RF_IT; u++) {
-    const long long g = ((c0 + u) << 6) + lane;
-    o[u] = pq[g];                                   // (as in phase A: read, then marked if beyond n_used)
-    if (g >= n_used) o[u].w = __uint_as_float(RF_NOSEG << 16);
+    for (int u = 0; u < RF_SC; u++) {
+      const long long g = ((c0 + u) << 6) + lane;
+      o[u] = pq[g];                                   // (as in phase A: read, then marked if beyond n_used)
+      if (g >= n_used) o[u].w = __uint_as_float(RF_NOSEG << 16);
+    }
+#pragma unroll
+    for (int u = 0; u < RF_SC; u++) {
+      const long long g = ((c0 + u) << 6) + lane;
+      const uint32_t wb = __float_as_uint(o[u].w);
+      const float thr2 = rf_certain_hit2(o[u].x, o[u].y, o[u].z, __uint_as_float(wb << 16));
+      bool h1, h2;
+      rf_list_neighbours(o[u].x, o[u].y, o[u].z, wb, thr2, h1, h2);
+      const bool hit = (wb == Q.wq) && (h1 || h2) && rf_within(Q, o[u], g, px, py, pz);
+      cnt += __popcll(__ballot(hit));
+    }
+  }
+  return cnt;
+}
+// the INCOHERENT listed points of up to RF_UL ranges (taken from the ballot mask mu; lane k holds range r0 + k and its
+// number of listed points nl) within the radius of the query.  Whole wave, uniform.
+#ifndef DFU3D_RF_UL
+#define DFU3D_RF_UL 4
+#endif
+constexpr int RF_UL = DFU3D_RF_UL;     // ranges / overflow-list loads in flight per lane
+__device__ __forceinline__ int rf_count_slots(const RfQuery &Q, const RfScratch &W, unsigned long long &mu, long long r0, int nl,
+                                              const double *px, const double *py, const double *pz) {
+  const int lane = lane_id();
+  float4 o[RF_UL];
+  uint32_t op[RF_UL];
+  int un[RF_UL];
+  long long ur[RF_UL];
+  bool big = false;                                  // (uniform) one of the ranges has more than 64 listed points
+#pragma unroll
+  for (int u = 0; u < RF_UL; u++) {
+    un[u] = 0;
+    ur[u] = 0;
+    if (mu) {
+      const int k = __ffsll((long long)mu) - 1;
+      mu &= mu - 1ull;
+      un[u] = __builtin_amdgcn_readlane(nl, k);
+      ur[u] = r0 + k;
+    }
+    big |= un[u] > 64;
+    const bool a = lane < un[u];
+    o[u] = a ? W.uent[ur[u] * RF_WLIST + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    op[u] = a ? W.upos[ur[u] * RF_WLIST + lane] : 0u;
   }
   int cnt = 0;
 #pragma unroll
-  for (int u = 0; u < RF_IT; u++) {
-    const long long g = ((c0 + u) << 6) + lane;
-    const uint32_t wb = __float_as_uint(o[u].w);
-    const float thr2 = rf_certain_hit2(o[u].x, o[u].y, o[u].z, __uint_as_float(wb << 16));
-    bool h1, h2;
-    rf_list_neighbours(o[u].x, o[u].y, o[u].z, wb, thr2, h1, h2);
-    const bool hit = (wb == Q.wq) && (h1 || h2) && rf_within(Q, o[u], g, px, py, pz);
+  for (int u = 0; u < RF_UL; u++) {
+    const bool hit = (op[u] & RF_INCOH) && __float_as_uint(o[u].w) == Q.wq && rf_within(Q, o[u], (long long)(op[u] & ~RF_INCOH), px, py, pz);
     cnt += __popcll(__ballot(hit));
+  }
+  if (big) {                                         // the second halves (rare: sparse lists)
+#pragma unroll
+    for (int u = 0; u < RF_UL; u++) {
+      const bool b = lane + 64 < un[u];
+      o[u] = b ? W.uent[ur[u] * RF_WLIST + 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      op[u] = b ? W.upos[ur[u] * RF_WLIST + 64 + lane] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < RF_UL; u++) {
+      const bool hit = (op[u] & RF_INCOH) && __float_as_uint(o[u].w) == Q.wq && rf_within(Q, o[u], (long long)(op[u] & ~RF_INCOH), px, py, pz);
+      cnt += __popcll(__ballot(hit));
+    }
   }
   return cnt;
 }
 
 // Phase B: one wave per queued point, counting from scratch.
-constexpr int RF_UL = 4;           // U-list loads in flight per lane
-__global__ __launch_bounds__(256) void k_rf_resolve(
+#ifndef DFU3D_RFB_OCC
+#define DFU3D_RFB_OCC 5
+#endif
+__global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, const double *__restrict__ radius,
@@ -787,82 +883,115 @@ __global__ __launch_bounds__(256) void k_rf_resolve(
   int *lq_tab = W.work + RF_WORK_HDR + 65536, *items = lq_tab + 4 * RF_LQ_CAP;
   for (int e = wave; e < nq; e += nwaves) {
 #ifdef DFU3D_DBG_RF_TIMING
-    unsigned long long rf_rec[RF_DBG_F] = {0};
+    unsigned int rf_rec[5] = {0};
     long long rf_t = clock64();
     int dbg_cand = 0;
 #endif
     const int part = __popcll(__ballot(q_incl <= e));
     const int before = part ? __builtin_amdgcn_readlane(q_incl, part - 1) : 0;
     RfQuery Q;
-    if (!rf_load_query(Q, W.queue[RF_QHDR + part * W.qcap + (e - before)], pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
-    const int nu = (int)min((long long)max(W.ucount[Q.wq >> 16], 0), Q.end - Q.base);
-    int cnt = 0;
+    if (!rf_load_query(Q, W.queue[RF_QHDR + part * W.qcap + (e - before)], n_max, pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
+    const int n = (int)(Q.end - Q.base);
+    int cnt = 0, n_items = 0, lq = -1;
     RF_T(0);
-    // (1) the incoherent points of the segment (the query itself is one of them unless it is coherent)
-    for (int k0 = 0; k0 < nu && cnt <= nb; k0 += 64 * RF_UL) {
-      float4 o[RF_UL];
-      bool in[RF_UL];
+    if (n <= RF_DIRECT) {
+      // a short segment (the LiDAR lists): every point of it, straight from the shadow
+      const long long c_lo = Q.base >> 6, c_hi = (Q.end - 1) >> 6;
+      for (long long c0 = c_lo; c0 <= c_hi && cnt <= nb; c0 += RF_SC) {
+        float4 o[RF_SC];
 #pragma unroll
-      for (int u = 0; u < RF_UL; u++) {
-        const int k = k0 + u * 64 + lane;
-        in[u] = k < nu;
-        o[u] = in[u] ? W.ulist[Q.base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+        for (int u = 0; u < RF_SC; u++) o[u] = pq[((c0 + u) << 6) + lane];      // (reads beyond the segment stay inside the scratch)
 #pragma unroll
-      for (int u = 0; u < RF_UL; u++) {
-        const bool hit = in[u] && rf_within(Q, o[u], (long long)__float_as_uint(o[u].w), px, py, pz);
-        cnt += __popcll(__ballot(hit));
-      }
-    }
-    RF_T(1);
-    // (2) the coherent points of the ranges whose box comes within the radius: the first RF_INLINE_CAND of them are
-    // read here, the others become work items of k_rf_ranges (a query near many boxes -- boxes that a pair of
-    // neighbouring outliers has blown up -- was a chain of range reads, one query took 0.26 ms)
-    const long long r_lo = Q.base >> BOX_SHIFT, r_hi = (Q.end - 1) >> BOX_SHIFT;
-    int n_inline = 0, n_items = 0, lq = -1;
-    for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
-      const long long rg = r0 + lane;
-      bool cand = false;
-      if (rg <= r_hi) {
-        const float4 *bp = (const float4 *)(W.dbox + (size_t)rg * BOX_FLOATS);
-        const float4 b0 = bp[0], b1 = bp[1];
-        cand = box_dist2(Q.qf.x, Q.qf.y, Q.qf.z, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z) <= Q.hi2;
-      }
-      unsigned long long m = __ballot(cand);
-      while (m && cnt <= nb && n_inline < RF_INLINE_CAND) {            // uniform
-        const int k = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        n_inline++;
-#ifdef DFU3D_DBG_RF_TIMING
-        dbg_cand++;
-#endif
-        cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
-      }
-      if (m && cnt <= nb) {                          // the rest of this batch: work items
-        const int c = __popcll(m);
-        int ib = 0;
-        if (lane == 0) {
-          if (lq < 0) lq = atomicAdd(&W.work[0], 1);
-          ib = (lq < RF_LQ_CAP) ? atomicAdd(&W.work[16], c) : RF_ITEM_CAP;
+        for (int u = 0; u < RF_SC; u++) {
+          const long long g = ((c0 + u) << 6) + lane;
+          const bool hit = (g >= Q.base) && (g < Q.end) && rf_within(Q, o[u], g, px, py, pz);
+          cnt += __popcll(__ballot(hit));
         }
-        lq = __builtin_amdgcn_readfirstlane(lq);
-        ib = __builtin_amdgcn_readfirstlane(ib);
-        if (lq < RF_LQ_CAP && ib + c <= RF_ITEM_CAP) {
-          if ((m >> lane) & 1ull) {
-            const int t = ib + __popcll(m & ((1ull << lane) - 1ull));
-            items[2 * t] = lq;
-            items[2 * t + 1] = (int)rg;
-          }
-          n_items += c;
+      }
+      RF_T(1);
+    } else {
+      const long long r_lo = Q.base >> BOX_SHIFT, r_hi = (Q.end - 1) >> BOX_SHIFT, r_q = Q.i >> BOX_SHIFT;
+      // (1) the listed points next door first: most queued points have their neighbours a few hundred positions away
+      const long long n_lo = max(r_lo, r_q - RF_NEAR), n_hi = min(r_hi, r_q + RF_NEAR);
+      {
+        const long long rg = n_lo + lane;
+        int nl = 0;
+        if (rg <= n_hi) nl = min(max(__float_as_int(W.rrec[(size_t)rg * BOX_FLOATS + 3]), 0), RF_WLIST);
+        unsigned long long mu = __ballot(nl > 0);
+        while (mu && cnt <= nb) cnt += rf_count_slots(Q, W, mu, n_lo, nl, px, py, pz);
+      }
+      RF_T(1);
+      int n_inline = 0;
+      for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
+        const long long rg = r0 + lane;
+        bool cand = false, ucand = false;
+        int nl = 0;
+        if (rg <= r_hi) {
+          const float4 *bp = (const float4 *)(W.rrec + (size_t)rg * BOX_FLOATS);
+          const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+          cand = box_dist2(Q.qf.x, Q.qf.y, Q.qf.z, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z) <= Q.hi2;
+          nl = min(max(__float_as_int(b0.w), 0), RF_WLIST);
+          ucand = nl > 0 && (rg < n_lo || rg > n_hi) &&
+                  box_dist2(Q.qf.x, Q.qf.y, Q.qf.z, b2.x, b2.y, b2.z, b3.x, b3.y, b3.z) <= Q.hi2;
+        }
+        // (2) the incoherent points of the other ranges whose second box comes within the radius
+        unsigned long long mu = __ballot(ucand);
+        while (mu && cnt <= nb) cnt += rf_count_slots(Q, W, mu, r0, nl, px, py, pz);
+        // (3) the coherent points of the ranges whose first box comes within the radius: the first RF_INLINE_CAND of
+        // them are read here, the others become work items of k_rf_ranges
+        unsigned long long m = __ballot(cand);
+        while (m && cnt <= nb && n_inline < RF_INLINE_CAND) {            // uniform
+          const int k = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          n_inline++;
 #ifdef DFU3D_DBG_RF_TIMING
-          dbg_cand += c;
+          dbg_cand++;
 #endif
-        } else {                                     // tables full (never seen): read the ranges here after all
-          while (m && cnt <= nb) {
-            const int k = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
+          cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
+        }
+        if (m && cnt <= nb) {                          // the rest of this batch: work items
+          const int c = __popcll(m);
+          int ib = 0;
+          if (lane == 0) {
+            if (lq < 0) lq = atomicAdd(&W.work[0], 1);
+            ib = (lq < RF_LQ_CAP) ? atomicAdd(&W.work[16], c) : RF_ITEM_CAP;
           }
+          lq = __builtin_amdgcn_readfirstlane(lq);
+          ib = __builtin_amdgcn_readfirstlane(ib);
+          if (lq < RF_LQ_CAP && ib + c <= RF_ITEM_CAP) {
+            if ((m >> lane) & 1ull) {
+              const int t = ib + __popcll(m & ((1ull << lane) - 1ull));
+              items[2 * t] = lq;
+              items[2 * t + 1] = (int)rg;
+            }
+            n_items += c;
+#ifdef DFU3D_DBG_RF_TIMING
+            dbg_cand += c;
+#endif
+          } else {                                     // tables full (never seen): read the ranges here after all
+            while (m && cnt <= nb) {
+              const int k = __ffsll((long long)m) - 1;
+              m &= m - 1ull;
+              cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
+            }
+          }
+        }
+      }
+      // (4) incoherent points that found their range's slots full (pathological ranges): the segment's overflow list
+      const int nov = (int)min((long long)max(W.ucount[Q.wq >> 16], 0), Q.end - Q.base);
+      for (int k0 = 0; k0 < nov && cnt <= nb; k0 += 64 * RF_UL) {
+        float4 o[RF_UL];
+        bool in[RF_UL];
+#pragma unroll
+        for (int u = 0; u < RF_UL; u++) {
+          const int k = k0 + u * 64 + lane;
+          in[u] = k < nov;
+          o[u] = in[u] ? W.ulist[Q.base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < RF_UL; u++) {
+          const bool hit = in[u] && rf_within(Q, o[u], (long long)__float_as_uint(o[u].w), px, py, pz);
+          cnt += __popcll(__ballot(hit));
         }
       }
     }
@@ -880,9 +1009,10 @@ __global__ __launch_bounds__(256) void k_rf_resolve(
 #ifdef DFU3D_DBG_RF_TIMING
     RF_T(2);
     if (lane == 0 && wave < 16384) {
-      rf_rec[3] = 1; rf_rec[4] = (unsigned long long)nu; rf_rec[5] = (unsigned long long)dbg_cand;
-      rf_rec[6] = (unsigned long long)(r_hi - r_lo + 1); rf_rec[7] = (cnt > nb) ? 1 : 0; rf_rec[8] = (unsigned long long)(Q.end - Q.base);
-      for (int k = 0; k < RF_DBG_F; k++) g_rf_recB[(size_t)wave * RF_DBG_F + k] += rf_rec[k];
+      unsigned long long *o_ = g_rf_recB + (size_t)wave * RF_DBG_F;
+      for (int k = 0; k < 3; k++) o_[k] += rf_rec[k];
+      o_[3] += 1; o_[4] += (n <= RF_DIRECT) ? 1 : 0; o_[5] += (unsigned long long)dbg_cand;
+      o_[6] += (unsigned long long)((n + 511) / 512); o_[7] += (cnt > nb) ? 1 : 0; o_[8] += (unsigned long long)n;
     }
 #endif
   }
@@ -909,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_rf_ranges(
     const int total = lq_tab[4 * lq + 1];
     if (total <= 0) continue;
     RfQuery Q;
-    if (!rf_load_query(Q, lq_tab[4 * lq], pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
+    if (!rf_load_query(Q, lq_tab[4 * lq], n_max, pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
     const int hits = rf_scan_range(Q, rg, pq, n_used, px, py, pz);
     if (lane_id() == 0) {
       const unsigned long long old = atomicAdd((unsigned long long *)(lq_tab + 4 * lq + 2), (unsigned long long)hits | (1ull << 32));
@@ -919,14 +1049,18 @@ __global__ __launch_bounds__(256) void k_rf_ranges(
 }
 
 #ifdef DFU3D_DBG_RF_TIMING
-extern "C" int dfu3d_debug_rf_timing(unsigned long long *out_a, unsigned long long *out_b, int reset) {
+extern "C" int dfu3d_debug_rf_timing(unsigned long long *out_a, unsigned long long *out_p, unsigned long long *out_b, int reset) {
   if (out_a && hipMemcpyFromSymbol(out_a, HIP_SYMBOL(g_rf_recA), sizeof(g_rf_recA)) != hipSuccess) return DFU3D_ELAUNCH;
+  if (out_p && hipMemcpyFromSymbol(out_p, HIP_SYMBOL(g_rf_recP), sizeof(g_rf_recP)) != hipSuccess) return DFU3D_ELAUNCH;
   if (out_b && hipMemcpyFromSymbol(out_b, HIP_SYMBOL(g_rf_recB), sizeof(g_rf_recB)) != hipSuccess) return DFU3D_ELAUNCH;
   if (reset) {
-    void *pa = nullptr, *pb = nullptr;
-    if (hipGetSymbolAddress(&pa, HIP_SYMBOL(g_rf_recA)) != hipSuccess || hipGetSymbolAddress(&pb, HIP_SYMBOL(g_rf_recB)) != hipSuccess)
+    void *pa = nullptr, *pp = nullptr, *pb = nullptr;
+    if (hipGetSymbolAddress(&pa, HIP_SYMBOL(g_rf_recA)) != hipSuccess || hipGetSymbolAddress(&pp, HIP_SYMBOL(g_rf_recP)) != hipSuccess ||
+        hipGetSymbolAddress(&pb, HIP_SYMBOL(g_rf_recB)) != hipSuccess)
       return DFU3D_ELAUNCH;
-    if (hipMemset(pa, 0, sizeof(g_rf_recA)) != hipSuccess || hipMemset(pb, 0, sizeof(g_rf_recB)) != hipSuccess) return DFU3D_ELAUNCH;
+    if (hipMemset(pa, 0, sizeof(g_rf_recA)) != hipSuccess || hipMemset(pp, 0, sizeof(g_rf_recP)) != hipSuccess ||
+        hipMemset(pb, 0, sizeof(g_rf_recB)) != hipSuccess)
+      return DFU3D_ELAUNCH;
   }
   return DFU3D_OK;
 }
@@ -1420,15 +1554,17 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   if ((uintptr_t)shadow & 15u) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float4 *pq = (float4 *)shadow;
-  // scratch behind the shadow proper: one box per 512 slots, the per-segment U lists (at the segments' own pool
-  // positions), counters, the tables of the long queries
+  // scratch behind the shadow proper: one record (two boxes, a count) per 512 slots, the ranges' U slots, the
+  // per-segment overflow lists (at the segments' own pool positions), counters, the tables of the long queries
   const size_t n_ranges = (size_t)((pool_cap + 511) / 512 + 1);
   RfScratch W;
   W.flags = flags;
   W.queue = queue;
   W.qcap = rf_queue_part_cap(pool_cap);
-  W.dbox = (float *)(pq + pool_cap);
-  W.ulist = (float4 *)((char *)W.dbox + 48 * n_ranges);
+  W.rrec = (float *)(pq + pool_cap);
+  W.uent = (float4 *)(W.rrec + BOX_FLOATS * n_ranges);
+  W.upos = (uint32_t *)(W.uent + (size_t)RF_WLIST * n_ranges);
+  W.ulist = (float4 *)(W.upos + (size_t)RF_WLIST * n_ranges);
   W.work = (int *)(W.ulist + pool_cap);
   W.ucount = W.work + RF_WORK_HDR;
   W.seg_base = (const long long *)seg_base;
@@ -1445,7 +1581,8 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   if (phases & DFU3D_RF_FLAGS) {
     if (hipMemsetAsync(queue, 0, RF_QHDR * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
     if (hipMemsetAsync(W.work, 0, sizeof(int) * (size_t)(RF_WORK_HDR + S), st) != hipSuccess) return DFU3D_ELAUNCH;
-    const dim3 grid((unsigned)((pool_cap + RF_WG - 1) / RF_WG));
+    const long long n_tiles = (pool_cap + RF_WG - 1) / RF_WG;
+    const dim3 grid((unsigned)(n_tiles < RF_GRID ? n_tiles : RF_GRID));
     if (nb_points == 1)
       hipLaunchKernelGGL(k_rf_stream<true>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
                          nb_points, S, W);
@@ -1453,12 +1590,16 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
       hipLaunchKernelGGL(k_rf_stream<false>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
                          nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
+    const long long g_pair = ((long long)n_ranges + 3) / 4;                     // a wave per range
+    hipLaunchKernelGGL(k_rf_pair, dim3((unsigned)(g_pair < 4096 ? g_pair : 4096)), dim3(256), 0, st, (const long long *)n_used,
+                       (long long)pool_cap, nb_points, W);
+    DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
     hipLaunchKernelGGL(k_rf_resolve, dim3(4096), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
                        (long long)pool_cap, (const long long *)seg_base, seg_cnt, radius, nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_rf_ranges, dim3(1024), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
+    hipLaunchKernelGGL(k_rf_ranges, dim3(512), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
                        (long long)pool_cap, (const long long *)seg_base, seg_cnt, radius, nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
   }

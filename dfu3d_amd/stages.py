@@ -225,7 +225,7 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
 
 def shadow_floats(pool_cap):
     """float32 elements of the radius filter's shadow scratch (DFU3D_SHADOW_BYTES / 4)."""
-    return 8 * pool_cap + 12 * ((pool_cap + 511) // 512 + 1) + 9699456 // 4
+    return 8 * pool_cap + (16 + 512 + 128) * ((pool_cap + 511) // 512 + 1) + 9699456 // 4
 
 
 def rf_queue_ints(pool_cap):

@@ -229,9 +229,9 @@ int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
  * from the pool.  Segments must not overlap; S < 65535.
  * n_used: device int64 = number of pool slots in use (NULL: pool_cap).
  * Scratch: shadow (DFU3D_SHADOW_BYTES(pool_cap) bytes, 16-byte aligned: the 16 B per slot the filter streams,
- * then what the second phase reads -- one bounding box per 512 slots, the per-segment lists of the points
- * without a list neighbour (16 B per slot at most), their lengths and the work items of queries near many
- * boxes), tile_off int32 (S+1), flags uint8 (pool_cap), queue int32 (DFU3D_RF_QUEUE_INTS(pool_cap), 16-byte
+ * then what the later phases read -- two bounding boxes and 128 slots for points without a list neighbour
+ * per 512 slots, per-segment overflow lists (16 B per slot at most), their lengths and the work items of
+ * queries near many boxes), tile_off int32 (S+1), flags uint8 (pool_cap), queue int32 (DFU3D_RF_QUEUE_INTS(pool_cap), 16-byte
  * aligned: undecided pool positions between the kernels). */
 int dfu3d_radius_filter(double *px, double *py, double *pz,
                         const int64_t *seg_base, int32_t *seg_cnt,
@@ -239,7 +239,7 @@ int dfu3d_radius_filter(double *px, double *py, double *pz,
                         int64_t pool_cap, const int64_t *n_used, void *shadow,
                         int32_t *tile_off, uint8_t *flags,
                         int32_t *queue, int32_t phases, void *stream);
-#define DFU3D_SHADOW_BYTES(pool_cap) (32 * (int64_t)(pool_cap) + 48 * (((int64_t)(pool_cap) + 511) / 512 + 1) + 9699456)
+#define DFU3D_SHADOW_BYTES(pool_cap) (32 * (int64_t)(pool_cap) + (64 + 2048 + 512) * (((int64_t)(pool_cap) + 511) / 512 + 1) + 9699456)
 /* int32 elements of `queue`: 64 parts (one per 64th of the 2048-slot workgroups) behind their 64 counters */
 #define DFU3D_RF_QUEUE_INTS(pool_cap) (1024 + 64 * ((((int64_t)(pool_cap) + 2047) / 2048 + 63) / 64) * 2048)
 /* the two macros as functions, for hosts that cannot evaluate C macros (ctypes, cgo, JNI) */

@@ -88,12 +88,16 @@ print("phase A %.1f / %.1f us   phase B %.1f / %.1f us   short compaction %.1f /
       % (t_flags + t_res + t_cmp))
 print("stage (best) %.1f us = %.0f GB/s at 21 B/point = %.3f of 8 TB/s; phase A alone %.0f GB/s" %
       (stage, 21.0 * n_pts / stage / 1e3, 21.0 * n_pts / stage / 1e3 / 8000.0, 21.0 * n_pts / t_flags[0] / 1e3))
-# U lists
+# U slots: the count sits next to each range's first box
 n_ranges = (eng.pool_cap + 511) // 512 + 1
 sh = joint["shadow"]
-uoff = 4 * eng.pool_cap + 12 * n_ranges + 4 * eng.pool_cap + 32
+rec = sh[4 * eng.pool_cap:4 * eng.pool_cap + 16 * n_ranges].view(-1, 16)
+used = (int(joint["n_used"]) + 511) // 512
+nl = rec[:used, 3].contiguous().view(torch.int32).cpu().numpy()
+uoff = 4 * eng.pool_cap + (16 + 512 + 128) * n_ranges + 4 * eng.pool_cap + 32
 ucount = sh[uoff:uoff + S2].view(torch.int32).cpu().numpy()
-print("U lists: %d points (%.2f%% of the pool), longest %d" % (ucount.sum(), 100.0 * ucount.sum() / max(n_pts, 1), ucount.max()))
+print("listed points: %d (%.2f%% of the pool), fullest range %d of 128; overflow lists %d points" %
+      (nl.sum(), 100.0 * nl.sum() / max(n_pts, 1), nl.max(), ucount.sum()))
 # keep mask against a brute-force float64 count (sample of segments, all sizes)
 base = joint["base"].cpu().numpy(); cnt = joint["cnt"].cpu().numpy(); rad = joint["radius"].cpu().numpy()
 X = torch.stack([joint["px"], joint["py"], joint["pz"]], 1)
