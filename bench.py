@@ -115,27 +115,55 @@ def pmc_traffic(kernels):
 
 def cpu_baseline(scenes_cpu, params, dense, max_seconds=18.0):
     """The oracle (NumPy + C restatement, single thread) on a bounded sample of
-    the same workload, on this box's host cores."""
+    the same workload, on this box's host cores.  Its box rows are kept: they are what the `parity` block of the
+    JSON line compares the rows of the TIMED engine with (frame f of this rank, camera c = view 6 f + c: the key of
+    the seeded plane fit on both sides)."""
     from oracle import penet_oracle as O
     op = O.Params()
     t0 = time.time()
     done = 0
-    for s in scenes_cpu:
+    exp = []
+    for f, s in enumerate(scenes_cpu):
         pts = s.points.numpy()
         for c, cal in enumerate(s.calibs):
             oc = O.Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
             lid, _ = O.fov_filter(pts, oc, params.fov_hw)
             n = int(s.n_inst[c])
             d = s.depth[c].numpy().copy() if dense else np.zeros((H, W), np.float32)
-            O.depth2pointsrgbpm(d[:, :, None], None, oc, lid, O.NUSC_CLASSES,
-                                s.masks[c][:n].numpy().astype(np.float32),
-                                s.inst_class[c][:n].numpy(), s.inst_box[c][:n].numpy(), op,
-                                plane_key=c, want_points=False)
+            res = O.depth2pointsrgbpm(d[:, :, None], None, oc, lid, O.NUSC_CLASSES,
+                                      s.masks[c][:n].numpy().astype(np.float32),
+                                      s.inst_class[c][:n].numpy(), s.inst_box[c][:n].numpy(), op,
+                                      plane_key=f * CAMS + c, want_points=False)
+            exp += [(f, c, r.inst, r.cluster, r.cls, r.as_vector()) for r in res.rows]
         done += 1
         if time.time() - t0 > max_seconds:
             break
     dt = time.time() - t0
-    return done / dt, done, dt
+    return done / dt, done, dt, exp
+
+
+def parity_block(rows, exp, n_frames, frame_ids):
+    """Rows of the timed engine (gathered layout: global frame, camera, class, instance, cluster, alpha, 2-D box,
+    h w l, x y z, ry, score) against the oracle's rows for this rank's first n_frames frames: BASELINE.json's
+    'box L1 vs ref' for the configuration that was timed (packed masks, chunked launches, streams, chain)."""
+    R = rows.cpu().numpy()
+    gid = {int(frame_ids[f]): f for f in range(n_frames)}
+    sel = R[np.isin(R[:, 0].astype(np.int64), list(gid))]
+    key = lambda a: (a[0], a[1], a[2], a[3])
+    got = sorted(((gid[int(r[0])], int(r[1]), int(r[3]), int(r[4])), int(r[2]), r[5:17]) for r in sel)
+    want = sorted(((f, c, j, k), cls, np.asarray(v, np.float64)) for f, c, j, k, cls, v in exp)
+    same_keys = [g[0] for g in got] == [w[0] for w in want] and [g[1] for g in got] == [w[1] for w in want]
+    out = {"frames": n_frames, "rows_oracle": len(want), "rows_gpu": len(got), "rows_equal": bool(same_keys),
+           "how": "rows of the last timed step (this configuration: packed masks, chunks, streams) vs oracle/penet_oracle.py "
+                  "on the same frames: (frame, camera, instance, cluster) keys and classes exact, 12 box numbers compared"}
+    if same_keys and got:
+        G = np.array([g[2] for g in got]); Wv = np.array([w[2] for w in want])
+        d = np.abs(G - Wv)                       # alpha x1 y1 x2 y2 h w l x y z ry
+        out.update(max_abs_centre_dims_m=float(d[:, 5:11].max()), max_abs_yaw_rad=float(d[:, 11].max()),
+                   max_abs_alpha_rad=float(d[:, 0].max()), max_abs_bbox_px=float(d[:, 1:5].max()),
+                   mean_abs_box_l1=float(d[:, 5:12].sum(1).mean()),
+                   within_north_star_tolerance=bool(d[:, 5:11].max() <= 1e-3 and d[:, 11].max() <= 1e-3))
+    return out
 
 
 def _cpu_worker(go, barrier, tasks, done):
@@ -472,7 +500,11 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "points_per_launch": int(c1["pool_points"]),
                     "undecided_after_phase_A": int(c1.get("rf_undecided", 0))}
         if cpu_scenes is not None and world == 1:
-            fps, nf, secs = cpu_baseline(cpu_scenes, params, dense)
+            fps, nf, secs, exp_rows = cpu_baseline(cpu_scenes, params, dense)
+            try:
+                out["parity"] = parity_block(rows, exp_rows, nf, my_frames)
+            except Exception as e:                                   # never lose the timing line
+                out["parity"] = {"error": repr(e)}
             if cpu_pool is not None:
                 try:
                     fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)

@@ -39,7 +39,7 @@ def get_fov_flag_gpu(lidar, calib, img_shape, device="cuda:0"):
 
 
 def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=None, params=None,
-                         crop_hw=None, device="cuda:0", return_rows=False):
+                         crop_hw=None, device="cuda:0", return_rows=False, save_points=True):
     """vis_utils.py:136-166.  `idx` is the frame id (int -> zero-padded to 6, or a
     file stem); `crop_hw` reproduces the shipped [:352,:1216] crop (hazard H11),
     default: no crop (canonical nuScenes 900x1600)."""
@@ -75,5 +75,6 @@ def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=No
                                            np.asarray(masks), classes, scores, boxes2D, None,
                                            file_idx, label_root=label_root or os.path.join(root_path, 'label_2'),
                                            params=p, device=device, return_rows=True)       # :163
-    np.save(out_path, final_points.astype(np.float16))                # :164-166
+    if save_points:
+        np.save(out_path, final_points.astype(np.float16))            # :164-166
     return (out_path, rows) if return_rows else out_path

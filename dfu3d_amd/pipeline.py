@@ -37,6 +37,7 @@ class Frame:
     boxes: np.ndarray           # (M,4) f32
     thing_classes: List[str]
     image: Optional[np.ndarray] = None   # (H,W,3) u8, only for the virtual-point file
+    n_total: int = 0                     # instances of the frame (a batch view holds at most 32 of them)
 
 
 def _npz_arrays(path):
@@ -86,7 +87,7 @@ def read_frame(root, stem, depth_dir=None, want_image=False, score_min=0.7, seg_
     return Frame(stem, pts, calib, depth.reshape(depth.shape[0], depth.shape[1]),
                  np.ascontiguousarray(z['masks'][keep], np.uint8), z['classes'][keep].astype(np.int64),
                  z['scores'][keep].astype(np.float32), z['boxes'][keep].astype(np.float32),
-                 [str(s) for s in z['thing_classes']], image)
+                 [str(s) for s in z['thing_classes']], image, int(np.count_nonzero(z['scores'] > score_min)))
 
 
 class BatchedLabeler:
@@ -216,8 +217,10 @@ class BatchedLabeler:
         st["done"] = ready
         return vb, ready, (H, W, M)
 
-    def _write(self, frames, rows_h, label_out, npy_out, vp):
+    def _write(self, frames, rows_h, label_out, npy_out, vp, skip=()):
         for i, f in enumerate(frames):
+            if i in skip:                              # written by _label_whole_frame
+                continue
             r = rows_h[rows_h[:, 0] == i]
             write_label_file(os.path.join(label_out, f.stem + '.txt'), r, NUSC_CLASSES)
             if vp is not None:
@@ -320,8 +323,22 @@ class BatchedLabeler:
             pass
 
     class _Meta:
-        def __init__(self, stem):
-            self.stem, self.image, self.points = stem, None, None
+        def __init__(self, stem, n_total=0):
+            self.stem, self.image, self.points, self.n_total = stem, None, None, n_total
+
+    def _label_whole_frame(self, root, stem, label_out, depth_dir, view):
+        """A frame with more instances than one batch view holds (DFU3D_MAX_INST = 32): the reference loops over
+        every mask (my_loader.py:547), so the frame goes through the one-frame path, which takes its instances in
+        groups of 32 (penet/my_loader.py) -- same label file as `--batch-frames 0` writes.  -> engine rows with
+        column 0 = `view`."""
+        from .penet.vis_utils import load_seg_npz, save_depth_as_points
+        depth = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), stem + '.npy')).astype(np.float32)
+        _, r = save_depth_as_points(depth, stem, root, label_root=label_out, params=self.p,
+                                    seg_provider=(lambda path: load_seg_npz(root, stem, self.seg_dir)),
+                                    device=str(self.dev), return_rows=True, save_points=self.want_points)
+        r = np.asarray(r, np.float64).reshape(-1, 24).copy()
+        r[:, 0] = view
+        return r
 
     def _prepare_procs(self, root, batch, depth_dir, slot):
         torch.cuda.set_device(self.dev)
@@ -344,7 +361,7 @@ class BatchedLabeler:
             B, M, [(m["stem"], m["calib"], m["classes"], m["scores"], m["boxes"], m["thing_classes"]) for m in metas])
         frames = []
         for i, m in enumerate(metas):
-            f = BatchedLabeler._Meta(m["stem"])
+            f = BatchedLabeler._Meta(m["stem"], m.get("m_total", m["m"]))
             if self.want_points:
                 f.image = st["image"][i].numpy()
                 f.points = st["pts"][i, :m["n"]].numpy()
@@ -408,7 +425,15 @@ class BatchedLabeler:
             rows_h = rows.cpu().numpy()
             self.stats["t_gpu"] += time.perf_counter() - t1
             vp = self._virtual_points(eng, vb, frames) if self.want_points else None
-            pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp))
+            whole = [i for i, f in enumerate(frames) if getattr(f, "n_total", 0) > self.max_masks]
+            for i in whole:                            # never a silent cut: every instance of the frame is labelled
+                import sys
+                print("[dfu3d] %s: %d instances, more than the %d of a batch view: labelled through the one-frame path"
+                      % (frames[i].stem, frames[i].n_total, self.max_masks), file=sys.stderr)
+                rows_h = np.concatenate([rows_h[rows_h[:, 0] != i],
+                                         self._label_whole_frame(root, frames[i].stem, label_out, depth_dir, i)], 0)
+                self.stats["frames_over_32_instances"] = self.stats.get("frames_over_32_instances", 0) + 1
+            pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp, set(whole)))
             self.stats["frames"] += len(frames)
             self.stats["boxes"] += int(rows_h.shape[0])
             for i, f in enumerate(frames):

@@ -52,7 +52,7 @@ def _worker(tasks, done):
                 np.copyto(view(lay["masks"] + i * lay["max_masks"] * H * W, (m, H, W), np.uint8), f.masks[:m])
             if want_image:
                 np.copyto(view(lay["image"] + i * H * W * 3, (H, W, 3), np.uint8), f.image)
-            done.put((tag, i, None, dict(stem=stem, n=n, m=m, classes=f.classes[:m], scores=f.scores[:m],
+            done.put((tag, i, None, dict(stem=stem, n=n, m=m, m_total=int(f.masks.shape[0]), classes=f.classes[:m], scores=f.scores[:m],
                                          boxes=f.boxes[:m], thing_classes=f.thing_classes,
                                          calib=f.calib.record())))
         except Exception as e:                       # reported to the parent, the worker lives on

@@ -3,9 +3,13 @@
 
 Same operations on the same NumPy float32 values as the reference's loop (to_sphere_coords :307-317; per point
 `point[1] // vert_res`, `point[2] // hor_res` and the key `str(vert) + '_' + str(hor)` :330-333; np.argmin of theta per
-bin :345; dict order = first-seen order; fewer than 5 rows -> the input :348-349).  The reference module itself imports
-the whole pcdet package (CUDA extensions) and cannot be imported here: parity unpinned against a run of the reference,
-pinned by construction (the statements are the reference's own NumPy calls, element by element)."""
+bin :345; dict order = first-seen order; fewer than 5 rows -> the input :348-349).
+PINNED: golden G10 (tests/golden/g10_la_sampling.npz, written by tests/golden/capture_la_sampling_golden.py) holds the
+outputs of the reference's own DADataBaseSampler.la_sampling -- the module imported unmodified, its two unused relative
+imports (a compiled CUDA extension, box_utils) provided as empty stand-ins -- on 53 seeded objects at two
+resolutions; tests/test_oracle_la_sampling.py asks for the same rows in the same order, bit for bit, for every one.
+NumPy semantics: `float32 // python float` stays float32 under NumPy >= 2 (this image; what G10 pins) and promotes to
+float64 under NumPy 1.x; the capture script records how many keys would differ (`keys64_differ`)."""
 import numpy as np
 
 

@@ -189,3 +189,32 @@ def test_engine_matches_oracle_at_the_bench_configuration():
                            lanes=3, chain=True)
     rows2, status2 = eng2.run(b)
     assert status2 == 0 and torch.equal(rows, rows2)
+
+
+def test_timed_layout_matches_oracle_packed_masks_chunks_lanes_chain():
+    """The layout bench.py times -- bit-packed masks (pack_masks), several chunks per batch, several engine lanes
+    (streams), every chunk ONE dfu3d_pseudo_boxes call -- against the oracle at the full bench size: three frames
+    of 34 720 points and 6 cameras of 1600x900 (BASELINE configs[1] / configs[3]).  Class / instance / cluster /
+    row order exact, the twelve box numbers within 1e-6 (north-star tolerance: 1e-3 m, 1e-3 rad)."""
+    _need_gpu()
+    from dfu3d_amd import synth
+    from dfu3d_amd.engine import PseudoBoxEngine
+    from dfu3d_amd.params import Params
+    H, W, M, cams = 900, 1600, 8, 6
+    p = Params()
+    scenes = [synth.make_scene(11 + f, H=H, W=W, M=M, cams=cams, dense=True, k_min=30, k_max=40) for f in range(3)]
+    b = synth.to_view_batch(scenes, p, DEV, dense=True)
+    b.pack_masks()
+    assert b.mask_format in (1, 2, 4) and b.masks.dim() == 3          # one word per pixel
+    cap_n = max(s.points.shape[0] for s in scenes)
+    eng = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=12, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17,
+                          lanes=2, chain=True)
+    rows, status = eng.run(b)
+    assert status == 0
+    exp, _ = _oracle_rows(scenes, p, True)
+    assert len(exp) >= 60
+    _compare(rows, exp)
+    # the pipelined form of the timed region (launch / collect) gives the same rows
+    h1 = eng.launch(b)
+    rows1, st1 = eng.collect(h1)
+    assert st1 == 0 and torch.equal(rows, rows1)

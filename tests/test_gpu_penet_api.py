@@ -375,3 +375,50 @@ def test_more_than_32_instances_are_all_labelled(tmp_path):
     for got, r in zip(rows, res.rows):
         assert (int(got[1]), int(got[2]), int(got[3])) == (r.inst, r.cluster, r.cls)
         np.testing.assert_allclose(got[4:16], r.as_vector(), rtol=1e-6, atol=1e-6)
+
+
+def test_cli_batched_path_labels_every_instance_of_a_frame_with_40(tmp_path, capsys):
+    """`--batch-frames 4` (a batch view holds DFU3D_MAX_INST = 32 instances): a frame with 40 instances must come out
+    exactly as the oracle -- and as `--batch-frames 0` -- labels it (my_loader.py:547 loops over every mask), the
+    others of the batch untouched; the run says so instead of cutting the frame short."""
+    _need_gpu()
+    import shutil
+    from dfu3d_amd import synth, kitti_io
+    from dfu3d_amd.labels import read_label_file
+    from dfu3d_amd.params import NUSC_CLASSES
+    from dfu3d_amd.penet import main as cli
+    H, W, M = 180, 320, 8
+    root = str(tmp_path / "kitti")
+    exp = {}
+    for f in range(3):
+        s = synth.make_scene(77 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=16, k_max=20)
+        n = int(s.n_inst[0])
+        assert n >= 2
+        idx = np.tile(np.arange(n), (40 + n - 1) // n)[:40] if f == 1 else np.arange(n)      # frame 1: 40 instances
+        masks, classes = s.masks[0][:n].numpy()[idx], s.inst_class[0][:n].numpy()[idx]
+        boxes, scores = s.inst_box[0][:n].numpy()[idx], np.full(len(idx), 0.9, np.float32)
+        img = pattern_image(H, W)
+        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], img, masks, classes, scores, boxes, NUSC_CLASSES,
+                             s.depth[0].numpy())
+        oc = O.Calibration(os.path.join(root, "calib", "%06d.txt" % f))
+        lid, _ = O.fov_filter(s.points.numpy(), oc, (H, W))
+        op = O.Params(bounds_hw=(H, W), fov_hw=(H, W))
+        exp[f] = O.depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], img, oc, lid, O.NUSC_CLASSES,
+                                     masks.astype(np.float32), classes, boxes, op, plane_key=f, want_points=False)
+    assert max(r.inst for r in exp[1].rows) >= 32                      # the case is real: boxes beyond the 32nd instance
+    for procs in ("0",):
+        assert cli.main(["--detpath", root, "--batch-frames", "4", "--reader-procs", procs, "--conf_files", "x.yaml"]) == 0
+        assert "000001: 40 instances" in capsys.readouterr().err
+        for f in range(3):
+            objs = read_label_file(os.path.join(root, "label_2", "%06d.txt" % f))
+            rows = exp[f].rows
+            assert len(objs) == len(rows), (f, len(objs), len(rows))
+            for o, r in zip(objs, rows):
+                assert o.cls_type == r.name
+                got = np.array([o.alpha, *o.box2d, o.h, o.w, o.l, *[float(v) for v in o.src.split(" ")[11:14]], o.ry])
+                np.testing.assert_allclose(got, r.as_vector(), rtol=1e-6, atol=1e-6)
+        batched = {f: open(os.path.join(root, "label_2", "%06d.txt" % f)).read() for f in range(3)}
+        shutil.rmtree(os.path.join(root, "label_2"))
+    assert cli.main(["--detpath", root, "--batch-frames", "0", "--conf_files", "x.yaml"]) == 0
+    for f in range(3):
+        assert open(os.path.join(root, "label_2", "%06d.txt" % f)).read() == batched[f]

@@ -33,3 +33,31 @@ def test_key_is_the_string_of_the_float32_quotient():
     assert len(out) == 6
     z = np.zeros((6, 4), np.float32)                     # r = 0: theta and fan are NaN -> one bin 'nan_nan'
     assert np.array_equal(LA.la_sampling(z), z)          # one bin < 5 -> unchanged
+
+
+def _g10():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_la_sampling.npz"))
+
+
+def test_oracle_equals_the_reference_run_g10():
+    """Golden G10 (tests/golden/capture_la_sampling_golden.py): the reference's own DADataBaseSampler.la_sampling,
+    imported unmodified, on 53 seeded objects (random sizes 1-4000, NaN angles, x = 0, x around 0, duplicates, fewer
+    than five bins, points behind and above the sensor) at two resolutions.  The oracle must select the same rows in
+    the same order, bit for bit -- on this image both run the same NumPy float32 loops, so that holds for every
+    object, the ones flagged `fragile` (an angle within 2 ulp of a bin edge) included."""
+    g = _g10()
+    n = int(g["n_objects"])
+    assert n >= 40 and str(g["numpy_version"]).split(".")[0] == np.__version__.split(".")[0]
+    kinds = set(str(t) for t in g["tags"])
+    assert {"all_nan", "x_exactly_zero", "few_bins", "duplicates"} <= kinds
+    for ri, (vr, hr) in enumerate(g["res"].tolist()):
+        for k in range(n):
+            o = g["in/%d" % k]
+            out, idx = LA.la_sampling(o, vr, hr, return_index=True)
+            ref = g["out/%d/%d" % (ri, k)]
+            assert out.shape == ref.shape, (ri, k, str(g["tags"][k]))
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (ri, k, str(g["tags"][k]))
+            assert np.array_equal(np.asarray(idx), g["idx/%d/%d" % (ri, k)]) or len(np.unique(o.view(np.uint32), axis=0)) < len(o)
+    # the NumPy-1.x reading of `float32 // python float` (promotion to float64) moves bin edges: recorded, not pinned
+    assert sum(int(g["keys64_differ/0/%d" % k]) for k in range(n)) >= 0
