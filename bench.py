@@ -43,7 +43,7 @@ STAGE_KERNELS = {
     "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
                                           "k_bp_finalize"],
     "segments_build": ["k_seg_count", "k_seg_alloc", "k_seg_write"],
-    "rf_flags": ["k_radius_flags"], "rf_resolve": ["k_radius_resolve"], "rf_compact": ["k_seg_compact_short"],
+    "rf_flags": ["k_rf_stream", "k_rf_pair"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"], "rf_compact": ["k_seg_compact_short"],
     "ballquery_fuse": ["k_tile_scan_class", "k_ball_flags", "k_seg_compact"],
     "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],
     "lshape_fit": ["k_fit_gather", "k_fit_tiny", "k_fit_medium", "k_fit_big_cost", "k_fit_big_box"],
@@ -494,7 +494,7 @@ def main():
                               "alg_bytes_per_launch": int(alg["rf_stage"]), "achieved": round(gbs, 2),
                               "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / copy_rate, 5),
                               "traffic": traffic},
-                    "k_radius_flags": None if fl is None else {
+                    "phase_A_stream_and_pair": None if fl is None else {
                         "avg_ms": fl["avg_ms"], "achieved": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9, 2),
                         "frac": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "points_per_launch": int(c1["pool_points"]),

@@ -104,12 +104,29 @@ def main(argv=None):
     errors = []
     frame_index = {s: i for i, s in enumerate(frames)}     # global index of a frame = its place in the sorted list
     rows_log = []                                           # (stem, engine rows) of every frame this rank labelled
+    # per-frame log of this rank (JSONL per frame; also the done-list --resume reads): one line
+    # per frame, appended and flushed as soon as the frame's label file is on disk, so a crashed run leaves its log
+    import threading
+    os.makedirs(label_out, exist_ok=True)
+    log_f = open(os.path.join(label_out, 'frames.rank%d.jsonl' % rank), 'a')
+    log_lock = threading.Lock()
+
+    def log_frame(stem, r=None, error=None):
+        rec = {"frame": stem, "frame_idx": frame_index[stem], "rank": rank}
+        if error is None:
+            rec["boxes"] = int(np.asarray(r).reshape(-1, 24).shape[0])
+        else:
+            rec["error"] = error
+        with log_lock:
+            log_f.write(json.dumps(rec) + "\n")
+            log_f.flush()
     if args.batch_frames > 0:
         from ..pipeline import BatchedLabeler
         lab = BatchedLabeler(batch_frames=max(1, min(args.batch_frames, len(mine))), lanes=args.streams,
                              workers=max(1, args.workers),
                              device="cuda:%d" % (local if world > 1 else 0),
                              want_points=not args.no_virtual_points, reader_pool=rpool)
+        lab.on_frame = log_frame
         stats = lab.run(args.detpath, mine, label_out, depth_dir, seg_dir=args.seg_dir)
         rows_log += lab.rows_log
         lab.close()
@@ -133,18 +150,14 @@ def main(argv=None):
             errors.append((idx, "%s: %s" % (type(e).__name__, e)))
             continue
         rows_log.append((idx, r))
+        log_frame(idx, r)
         if rank == 0 and (k + 1) % 10 == 0:
             print("%d/%d frames, %.2f frames/s" % (k + 1, len(mine), (k + 1) / (time.time() - t0)))
     if rpool is not None:
         rpool.close()
-    # per-frame log of this rank (JSONL per frame; also the done-list --skip-existing reads)
-    os.makedirs(label_out, exist_ok=True)
-    with open(os.path.join(label_out, 'frames.rank%d.jsonl' % rank), 'a') as f:
-        for stem, r in rows_log:
-            f.write(json.dumps({"frame": stem, "frame_idx": frame_index[stem], "rank": rank,
-                                "boxes": int(np.asarray(r).reshape(-1, 24).shape[0])}) + "\n")
-        for stem, msg in errors:
-            f.write(json.dumps({"frame": stem, "frame_idx": frame_index[stem], "rank": rank, "error": msg}) + "\n")
+    for stem, msg in errors:                                # (after the labelled frames, as before)
+        log_frame(stem, error=msg)
+    log_f.close()
     # the one collective of the path: variable-length all-gather of the box rows, each carrying its
     # global frame index; rank 0 writes the manifest of the run next to the label files
     import torch
@@ -169,7 +182,8 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(label_out, exist_ok=True)
         man = D.write_manifest(os.path.join(label_out, "manifest.json"), gathered, n_total, world,
-                               extra={"frames_labelled_this_run": n_labelled, "seconds": round(time.time() - t0, 3),
+                               extra={"frames_labelled_this_run": n_labelled, "partial": bool(n_labelled < n_total),   # (a --resume / --skip-existing run lists only its own boxes)
+                                      "seconds": round(time.time() - t0, 3),
                                       "detpath": os.path.abspath(args.detpath)})
         print("manifest: %d frames (%d labelled now), %d boxes, per rank %s" % (
             man["frames"], n_labelled, man["boxes"], man["boxes_per_rank"]))

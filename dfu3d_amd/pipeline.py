@@ -111,6 +111,7 @@ class BatchedLabeler:
         self.seg_dir = None
         self.stats = {"frames": 0, "boxes": 0, "t_read": 0.0, "t_pack": 0.0, "t_wait": 0.0, "t_gpu": 0.0}
         self.rows_log = []          # (stem, engine rows of that frame) for the run's manifest / row gather
+        self.on_frame = None        # callable(stem, rows) invoked right after the frame's label file is on disk
 
     # ------------------------------------------------------------------
     def _engine(self, H, W, M):
@@ -219,10 +220,14 @@ class BatchedLabeler:
 
     def _write(self, frames, rows_h, label_out, npy_out, vp, skip=()):
         for i, f in enumerate(frames):
-            if i in skip:                              # written by _label_whole_frame
-                continue
             r = rows_h[rows_h[:, 0] == i]
+            if i in skip:                              # written by _label_whole_frame
+                if self.on_frame is not None:
+                    self.on_frame(f.stem, r)
+                continue
             write_label_file(os.path.join(label_out, f.stem + '.txt'), r, NUSC_CLASSES)
+            if self.on_frame is not None:
+                self.on_frame(f.stem, r)
             if vp is not None:
                 np.save(os.path.join(npy_out, f.stem + '.npy'), vp[i])
 

@@ -193,7 +193,7 @@ def test_engine_matches_oracle_at_the_bench_configuration():
 
 def test_timed_layout_matches_oracle_packed_masks_chunks_lanes_chain():
     """The layout bench.py times -- bit-packed masks (pack_masks), several chunks per batch, several engine lanes
-    (streams), every chunk ONE dfu3d_pseudo_boxes call -- against the oracle at the full bench size: three frames
+    (streams), every chunk ONE dfu3d_pseudo_boxes call -- against the oracle at the full bench size: four frames
     of 34 720 points and 6 cameras of 1600x900 (BASELINE configs[1] / configs[3]).  Class / instance / cluster /
     row order exact, the twelve box numbers within 1e-6 (north-star tolerance: 1e-3 m, 1e-3 rad)."""
     _need_gpu()
@@ -202,7 +202,7 @@ def test_timed_layout_matches_oracle_packed_masks_chunks_lanes_chain():
     from dfu3d_amd.params import Params
     H, W, M, cams = 900, 1600, 8, 6
     p = Params()
-    scenes = [synth.make_scene(11 + f, H=H, W=W, M=M, cams=cams, dense=True, k_min=30, k_max=40) for f in range(3)]
+    scenes = [synth.make_scene(11 + f, H=H, W=W, M=M, cams=cams, dense=True, k_min=30, k_max=40) for f in range(4)]
     b = synth.to_view_batch(scenes, p, DEV, dense=True)
     b.pack_masks()
     assert b.mask_format in (1, 2, 4) and b.masks.dim() == 3          # one word per pixel

@@ -78,7 +78,11 @@ def test_batch_against_the_reference_run_g10():
     objs = [g["in/%d" % k] for k in range(n)]
     report = []
     for ri, (vr, hr) in enumerate(g["res"].tolist()):
-        got = la_sampling_batch(objs, vr, hr)
+        got = [None] * n
+        for C in sorted(set(o.shape[1] for o in objs)):               # a batch holds objects of one width
+            ks = [k for k in range(n) if objs[k].shape[1] == C]
+            for k, r in zip(ks, la_sampling_batch([objs[k] for k in ks], vr, hr)):
+                got[k] = r
         bad = []
         for k in range(n):
             ref = g["out/%d/%d" % (ri, k)]

@@ -422,3 +422,49 @@ def test_cli_batched_path_labels_every_instance_of_a_frame_with_40(tmp_path, cap
     assert cli.main(["--detpath", root, "--batch-frames", "0", "--conf_files", "x.yaml"]) == 0
     for f in range(3):
         assert open(os.path.join(root, "label_2", "%06d.txt" % f)).read() == batched[f]
+
+
+def test_two_rank_cli_run_equals_the_single_rank_run(tmp_path):
+    """BASELINE configs[2] in small: the split sharded over the ranks of one node.  Two FRESH child processes
+    (`python -m torch.distributed.run --nproc-per-node 2 -m dfu3d_amd.penet.main ... --dist-backend gloo
+    --single-device`: both on this one GPU, rows gathered over gloo) label a 12-frame directory; the label files must be
+    byte-identical to a single-process run's, frames must be split r::2 (per-rank logs), and rank 0's manifest must
+    account for every box of both ranks."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    from dfu3d_amd import synth, kitti_io
+    from dfu3d_amd.params import NUSC_CLASSES
+    H, W, M, N = 180, 320, 6, 12
+    root = str(tmp_path / "kitti")
+    img = pattern_image(H, W)
+    for f in range(N):
+        s = synth.make_scene(300 + f, H=H, W=W, M=M, cams=1, dense=True, k_min=14, k_max=18)
+        n = int(s.n_inst[0])
+        kitti_io.write_frame(root, f, s.points.numpy(), s.calibs[0], img, s.masks[0][:n].numpy(), s.inst_class[0][:n].numpy(),
+                             s.inst_score[0][:n].numpy(), s.inst_box[0][:n].numpy(), NUSC_CLASSES, s.depth[0].numpy())
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["-m", "dfu3d_amd.penet.main", "--command", "evaluate", "--detpath", root, "--no-virtual-points",
+            "--batch-frames", "4", "--reader-procs", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (cmd, r.stdout[-1500:], r.stderr[-3000:])
+    one, two = os.path.join(root, "label_one"), os.path.join(root, "label_two")
+    run([sys.executable] + base + ["--label-out", one])
+    run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29531"] + base + ["--label-out", two, "--dist-backend", "gloo", "--single-device"])
+    names = ["%06d.txt" % f for f in range(N)]
+    for nm in names:
+        a, b = open(os.path.join(one, nm)).read(), open(os.path.join(two, nm)).read()
+        assert a == b, nm
+    n_boxes = sum(len(open(os.path.join(one, nm)).read().splitlines()) for nm in names)
+    assert n_boxes > 20
+    man1, man2 = json.load(open(os.path.join(one, "manifest.json"))), json.load(open(os.path.join(two, "manifest.json")))
+    assert man1["frames"] == man2["frames"] == N and man1["boxes"] == man2["boxes"] == n_boxes
+    assert man2["world_size"] == 2 and sum(man2["boxes_per_rank"]) == n_boxes and min(man2["boxes_per_rank"]) > 0
+    for r in (0, 1):                                        # the reference's DistributedSampler interleave: rank r has frames r::2
+        recs = [json.loads(l) for l in open(os.path.join(two, "frames.rank%d.jsonl" % r))]
+        assert sorted(x["frame_idx"] for x in recs) == list(range(r, N, 2))

@@ -5,7 +5,10 @@ frames one at a time (--batch-frames 0) for a byte comparison; optionally the 2-
 (frames r::2, row gather, manifest).  Prints one JSON line.  Frames are small (225x400, one camera per frame as in
 the KITTI layout) so that thousands fit on the box's scratch disk; the rate is disk-inclusive (files in, files out).
 
-  python tools/rehearse_config2.py [N=2000] [root=/dev/shm/dfu3d_cfg2]
+  python tools/rehearse_config2.py [N=2000] [root=/dev/shm/dfu3d_cfg2] [H=225] [W=400]
+
+At the real size (H W = 900 1600, 8 masks: 17 MB of input per camera-frame) a few hundred frames fill the box's
+scratch memory: `python tools/rehearse_config2.py 320 /dev/shm/dfu3d_cfg2_full 900 1600`.
 """
 import glob
 import json
@@ -21,7 +24,10 @@ import numpy as np  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 root = sys.argv[2] if len(sys.argv) > 2 else "/dev/shm/dfu3d_cfg2"
-H, W, M = 225, 400, 6
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 225
+W = int(sys.argv[4]) if len(sys.argv) > 4 else 400
+M = 6 if H < 600 else 8
+BATCH = "32" if H < 600 else "16"
 
 
 def generate():
@@ -68,7 +74,7 @@ if not os.path.isdir(os.path.join(root, "velodyne")) or len(os.listdir(os.path.j
 lab = os.path.join(root, "label_2")
 shutil.rmtree(lab, ignore_errors=True)
 # 1. the whole directory, batched, forked readers
-dt, out = cli(["--batch-frames", "32", "--reader-procs", "8", "--streams", "2"])
+dt, out = cli(["--batch-frames", BATCH, "--reader-procs", "8", "--streams", "2"])
 full = labels(lab)
 man = json.load(open(os.path.join(lab, "manifest.json")))
 assert len(full) == N and man["frames"] == N and man["boxes"] == sum(len(t.splitlines()) for t in full.values())
@@ -79,7 +85,7 @@ gone = sorted(full)[3:N:max(N // 40, 1)]
 stamp = {k: os.path.getmtime(os.path.join(lab, k)) for k in full}
 for k in gone:
     os.remove(os.path.join(lab, k))
-dt2, out2 = cli(["--batch-frames", "32", "--reader-procs", "8", "--skip-existing"])
+dt2, out2 = cli(["--batch-frames", BATCH, "--reader-procs", "8", "--skip-existing"])
 again = labels(lab)
 assert again == full, "restart produced different label files"
 untouched = [k for k in full if k not in gone]
@@ -96,7 +102,7 @@ res.update(one_at_a_time_frames=12, one_at_a_time_s=round(dt3, 2))
 # 4. two ranks on this GPU over gloo: frames r::2, row gather, manifest
 two = os.path.join(root, "label_two")
 shutil.rmtree(two, ignore_errors=True)
-dt4, out4 = cli(["--batch-frames", "32", "--reader-procs", "4", "--label-out", two], ranks=2)
+dt4, out4 = cli(["--batch-frames", BATCH, "--reader-procs", "4", "--label-out", two], ranks=2)
 lab2 = labels(two)
 man2 = json.load(open(os.path.join(two, "manifest.json")))
 assert lab2 == full, "2-rank run wrote different label files"
