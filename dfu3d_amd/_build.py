@@ -110,6 +110,8 @@ VARIANTS = {
     "rf_g8192_nopf": ["-DDFU3D_RF_GRID=8192", "-DDFU3D_RF_NO_PREFETCH"],
     "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
     "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
+    # short-list compaction: what of it takes the time (wrong results)
+    "cs0": ["-DDFU3D_DBG_CS_MODE=0"], "cs1": ["-DDFU3D_DBG_CS_MODE=1"], "cs2": ["-DDFU3D_DBG_CS_MODE=2"],
     "rf_ul4": ["-DDFU3D_RF_UL=4"],
     # radius filter, phase B: the points of two candidate ranges requested together (measurement for DESIGN §10 item 1)
     "rf2": ["-DDFU3D_RF_RANGES_PER_STEP=2"],

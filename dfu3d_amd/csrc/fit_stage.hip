@@ -1197,6 +1197,102 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
   }
 }
 
+// ---- the heading search in two tiers ----------------------------------------------------------------------------
+// rectangle_fitting.py:83-136 scores 89 headings by -var(E1) - var(E2) (np.var: mean, then squared deviations: three
+// sweeps over the points with the extents) and keeps the first strict maximum.  Only the arg-max matters, so:
+// tier 1 scores every heading in TWO sweeps (extents; then count, sum and sum of squares of D1 over E1 / D2 over E2,
+// variance = q/n - (s/n)^2) -- the same fp64 quantities, a different summation: its cost differs from the reference's
+// by at most ~3 n 2^-53 E[D^2] (n <= 10^6: 3e-10 relative to mag = E1[D1^2] + E2[D2^2] >= |cost|);
+// tier 2 re-scores, with the reference's own three sweeps, only the headings whose tier-1 cost lies within
+// FIT_TAU * (largest mag) of the best one -- one heading unless the point set has an exact or nearly exact symmetry.
+// A heading outside that band cannot be the reference's arg-max, and inside it the reference's formula decides.
+constexpr double FIT_TAU = 1e-8;
+struct FitAcc {                                   // tier 1, second sweep
+  double s1, s2, q1, q2;
+  int n1, n2;
+  __device__ __forceinline__ void clear() { s1 = s2 = q1 = q2 = 0.0; n1 = n2 = 0; }
+  __device__ __forceinline__ void add(double x, double y, double ct, double st, double a0, double a1, double b0, double b1) {
+    const double c1 = x * ct + y * st;
+    const double c2 = x * (-st) + y * ct;
+    const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+    const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+    if (d1 < d2) { s1 += d1; q1 += d1 * d1; n1++; } else { s2 += d2; q2 += d2 * d2; n2++; }
+  }
+  __device__ __forceinline__ void wave_reduce() {
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
+    n1 = wave_sum_i(n1); n2 = wave_sum_i(n2);
+  }
+  __device__ __forceinline__ double cost(double &mag) const {
+    double V1 = 0.0, V2 = 0.0, M1 = 0.0, M2 = 0.0;
+    if (n1) { const double mu = s1 / (double)n1; M1 = q1 / (double)n1; V1 = -(M1 - mu * mu); }
+    if (n2) { const double mu = s2 / (double)n2; M2 = q2 / (double)n2; V2 = -(M2 - mu * mu); }
+    mag = M1 + M2;
+    return V1 + V2;
+  }
+};
+// the reference's cost of one heading, a wave over the points (lanes take points lane, lane + 64, ...): three sweeps
+__device__ __forceinline__ double wave_exact_cost(const double *mx, const double *my, int m, double ct, double st) {
+  const int lane = lane_id();
+  double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+  for (int i = lane; i < m; i += 64) {
+    const double x = mx[i], y = my[i];
+    const double c1 = x * ct + y * st;
+    const double c2 = x * (-st) + y * ct;
+    a0 = fmin(a0, c1); a1 = fmax(a1, c1);
+    b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+  }
+  a0 = wave_min_d(a0); a1 = wave_max_d(a1);
+  b0 = wave_min_d(b0); b1 = wave_max_d(b1);
+  double s1 = 0.0, s2 = 0.0;
+  int n1 = 0, n2 = 0;
+  for (int i = lane; i < m; i += 64) {
+    const double x = mx[i], y = my[i];
+    const double c1 = x * ct + y * st;
+    const double c2 = x * (-st) + y * ct;
+    const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+    const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+    if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  n1 = wave_sum_i(n1); n2 = wave_sum_i(n2);
+  const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
+  double q1 = 0.0, q2 = 0.0;
+  for (int i = lane; i < m; i += 64) {
+    const double x = mx[i], y = my[i];
+    const double c1 = x * ct + y * st;
+    const double c2 = x * (-st) + y * ct;
+    const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+    const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+    if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
+    else { const double u = d2 - m2; q2 += u * u; }
+  }
+  q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
+  double V1 = 0.0, V2 = 0.0;
+  if (n1) V1 = -(q1 / (double)n1);
+  if (n2) V2 = -(q2 / (double)n2);
+  return V1 + V2;
+}
+// From the tier-1 costs of all headings (cost[th], th < n_theta) and the largest mag: the arg-max of the reference.
+// Whole wave, uniform; mx / my: the cluster's points (LDS or global); ctab / stab: cos / sin of the headings.
+__device__ __forceinline__ int wave_pick_heading(const double *cost, int n_theta, double mag_max, const double *mx,
+                                                 const double *my, int m, const double *ctab, const double *stab) {
+  double top = -INFINITY;
+  for (int th = 0; th < n_theta; th++) { const double c = cost[th]; if (top < c) top = c; }
+  const double band = top - FIT_TAU * mag_max;
+  int first = -1, ncand = 0;
+  for (int th = 0; th < n_theta; th++)
+    if (cost[th] >= band) { if (first < 0) first = th; ncand++; }
+  if (ncand <= 1) return first < 0 ? 0 : first;          // (no heading with a cost that is a number: the reference keeps heading 0)
+  int best = 0;
+  double bc = -INFINITY;
+  for (int th = first; th < n_theta; th++) {             // uniform: the candidates, with the reference's formula
+    if (!(cost[th] >= band)) continue;
+    const double c = wave_exact_cost(mx, my, m, ctab[th], stab[th]);
+    if (bc < c) { bc = c; best = th; }
+  }
+  return best;
+}
+
 // ---- F2a: clusters of at most 64 points, one wave each, one lane per heading -----
 // Members live in registers (lane i = member i) and are broadcast as scalar operands;
 // no reductions at all.  rectangle_fitting.py:83-136.
@@ -1217,9 +1313,14 @@ __global__ __launch_bounds__(256) void k_fit_tiny(
     if (m > 64) continue;
     const long long P = (long long)d[4];
     const double x = (lane < m) ? gsx[P + lane] : 0.0, y = (lane < m) ? gsy[P + lane] : 0.0;
-    double bestc = -INFINITY;
-    int bestth = 0x7FFFFFFF;
-    for (int th = lane; th < ((n_theta + 63) & ~63); th += 64) {
+    // tier 1: this lane's headings (lane, lane + 64), two sweeps each
+    constexpr int TH_PER_LANE = MAXTH / 64;
+    double c1t[TH_PER_LANE], magmax = 0.0, top = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < TH_PER_LANE; k++) {
+      const int th = lane + 64 * k;
+      c1t[k] = -INFINITY;
+      if (64 * k >= n_theta) continue;                 // uniform
       const double theta = (double)th * dtheta;
       const double ct = cos(theta), st = sin(theta);
       double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
@@ -1230,36 +1331,78 @@ __global__ __launch_bounds__(256) void k_fit_tiny(
         a0 = fmin(a0, c1); a1 = fmax(a1, c1);
         b0 = fmin(b0, c2); b1 = fmax(b1, c2);
       }
-      double s1 = 0.0, s2 = 0.0;
-      int n1 = 0, n2 = 0;
-      for (int j = 0; j < m; j++) {
-        const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
-        const double c1 = xj * ct + yj * st;
-        const double c2 = xj * (-st) + yj * ct;
-        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-        if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+      FitAcc A;
+      A.clear();
+      for (int j = 0; j < m; j++) A.add(readlane_f64(x, j), readlane_f64(y, j), ct, st, a0, a1, b0, b1);
+      double mag;
+      const double c = A.cost(mag);
+      if (th < n_theta) {
+        c1t[k] = c;
+        if (top < c) top = c;
+        if (mag > magmax) magmax = mag;                // (a NaN never wins)
       }
-      const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
-      double q1 = 0.0, q2 = 0.0;
-      for (int j = 0; j < m; j++) {
-        const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
-        const double c1 = xj * ct + yj * st;
-        const double c2 = xj * (-st) + yj * ct;
-        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-        if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
-        else { const double u = d2 - m2; q2 += u * u; }
-      }
-      double V1 = 0.0, V2 = 0.0;
-      if (n1) V1 = -(q1 / (double)n1);
-      if (n2) V2 = -(q2 / (double)n2);
-      const double c = V1 + V2;
-      // this lane's headings come in ascending order: keep the first strict maximum
-      if (th < n_theta && bestc < c) { bestc = c; bestth = th; }
     }
-    // first strict maximum over all headings (rectangle_fitting.py:135-136): the largest
-    // cost, the smallest heading among equals; a lane without any (NaN costs only) has
+    top = wave_max_d(top);
+    magmax = wave_max_d(magmax);
+    const double band = top - FIT_TAU * magmax;
+    double bestc = -INFINITY;
+    int bestth = 0x7FFFFFFF;
+    {
+      int ncand = 0;
+#pragma unroll
+      for (int k = 0; k < TH_PER_LANE; k++) ncand += __popcll(__ballot(c1t[k] >= band));
+      if (ncand <= 1) {                                // the usual case: one heading in the band -- it is the arg-max
+#pragma unroll
+        for (int k = 0; k < TH_PER_LANE; k++)
+          if (c1t[k] >= band) { bestc = c1t[k]; bestth = lane + 64 * k; }
+      } else {
+        // tier 2: the candidates with the reference's three sweeps, each on its own lane
+#pragma unroll
+        for (int k = 0; k < TH_PER_LANE; k++) {
+          if (__ballot(c1t[k] >= band) == 0ull) continue;    // uniform
+          const int th = lane + 64 * k;
+          const double theta = (double)th * dtheta;
+          const double ct = cos(theta), st = sin(theta);
+          double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+          for (int j = 0; j < m; j++) {
+            const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+            const double c1 = xj * ct + yj * st;
+            const double c2 = xj * (-st) + yj * ct;
+            a0 = fmin(a0, c1); a1 = fmax(a1, c1);
+            b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+          }
+          double s1 = 0.0, s2 = 0.0;
+          int n1 = 0, n2 = 0;
+          for (int j = 0; j < m; j++) {
+            const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+            const double c1 = xj * ct + yj * st;
+            const double c2 = xj * (-st) + yj * ct;
+            const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+            const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+            if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+          }
+          const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
+          double q1 = 0.0, q2 = 0.0;
+          for (int j = 0; j < m; j++) {
+            const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
+            const double c1 = xj * ct + yj * st;
+            const double c2 = xj * (-st) + yj * ct;
+            const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
+            const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
+            if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
+            else { const double u = d2 - m2; q2 += u * u; }
+          }
+          double V1 = 0.0, V2 = 0.0;
+          if (n1) V1 = -(q1 / (double)n1);
+          if (n2) V2 = -(q2 / (double)n2);
+          const double c = V1 + V2;
+          // this lane's headings come in ascending order: keep the first strict maximum
+          if (c1t[k] >= band && bestc < c) { bestc = c; bestth = th; }
+        }
+      }
+    }
+    // first strict maximum over the candidate headings (rectangle_fitting.py:135-136): the largest
+    // cost, the smallest heading among equals; a lane without any has
     // bestc = -inf / bestth = INT_MAX and loses against everything, and if nobody has one
     // the loop of the reference never updates its initial choice, heading 0
 #pragma unroll
@@ -1297,7 +1440,7 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
     int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
     uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_big) {
   __shared__ double lx[LDS_MEMBERS], ly[LDS_MEMBERS];
-  __shared__ double s_cost[MAXTH], s_ct[MAXTH], s_st[MAXTH];
+  __shared__ double s_cost[MAXTH], s_mag[MAXTH], s_ct[MAXTH], s_st[MAXTH];
   __shared__ double s_ext[FW][4];
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
   const int nq = min(W.counters[0], W.cap_q);
@@ -1317,59 +1460,43 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
     __syncthreads();
     const double *mx = lx;
     const double *my = ly;
-    // 89 headings, one wave each (rectangle_fitting.py:119-136)
-    for (int th = wave; th < n_theta; th += FW) {
-      const double ct = s_ct[th], st = s_st[th];
+    // tier 1: 89 headings, two per wave and sweep (every LDS read serves both), two sweeps
+    // (rectangle_fitting.py:119-136; see "the heading search in two tiers")
+    for (int th0 = 2 * wave; th0 < n_theta; th0 += 2 * FW) {
+      const int th1 = min(th0 + 1, n_theta - 1);       // (an odd heading count: the last one is scored twice)
+      const double ct0 = s_ct[th0], st0 = s_st[th0], ct1 = s_ct[th1], st1 = s_st[th1];
       double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+      double e0 = INFINITY, e1 = -INFINITY, f0 = INFINITY, f1 = -INFINITY;
       for (int i = lane; i < m; i += 64) {
         const double x = mx[i], y = my[i];
-        const double c1 = x * ct + y * st;
-        const double c2 = x * (-st) + y * ct;
+        double c1 = x * ct0 + y * st0;
+        double c2 = x * (-st0) + y * ct0;
         a0 = fmin(a0, c1); a1 = fmax(a1, c1);
         b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+        c1 = x * ct1 + y * st1;
+        c2 = x * (-st1) + y * ct1;
+        e0 = fmin(e0, c1); e1 = fmax(e1, c1);
+        f0 = fmin(f0, c2); f1 = fmax(f1, c2);
       }
-      a0 = wave_min_d(a0); a1 = wave_max_d(a1);
-      b0 = wave_min_d(b0); b1 = wave_max_d(b1);
-      // rectangle_fitting.py:89-99: D1/D2, split into E1/E2
-      double s1 = 0.0, s2 = 0.0;
-      int n1 = 0, n2 = 0;
+      a0 = wave_min_d(a0); a1 = wave_max_d(a1); b0 = wave_min_d(b0); b1 = wave_max_d(b1);
+      e0 = wave_min_d(e0); e1 = wave_max_d(e1); f0 = wave_min_d(f0); f1 = wave_max_d(f1);
+      FitAcc A, B;
+      A.clear(); B.clear();
       for (int i = lane; i < m; i += 64) {
         const double x = mx[i], y = my[i];
-        const double c1 = x * ct + y * st;
-        const double c2 = x * (-st) + y * ct;
-        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-        if (d1 < d2) { s1 += d1; n1++; } else { s2 += d2; n2++; }
+        A.add(x, y, ct0, st0, a0, a1, b0, b1);
+        B.add(x, y, ct1, st1, e0, e1, f0, f1);
       }
-      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-      n1 = wave_sum_i(n1); n2 = wave_sum_i(n2);
-      const double m1 = n1 ? s1 / (double)n1 : 0.0, m2 = n2 ? s2 / (double)n2 : 0.0;
-      double q1 = 0.0, q2 = 0.0;
-      for (int i = lane; i < m; i += 64) {
-        const double x = mx[i], y = my[i];
-        const double c1 = x * ct + y * st;
-        const double c2 = x * (-st) + y * ct;
-        const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
-        const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-        if (d1 < d2) { const double u = d1 - m1; q1 += u * u; }
-        else { const double u = d2 - m2; q2 += u * u; }
-      }
-      q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
-      double V1 = 0.0, V2 = 0.0;
-      if (n1) V1 = -(q1 / (double)n1);
-      if (n2) V2 = -(q2 / (double)n2);
-      if (lane == 0) s_cost[th] = V1 + V2;
+      A.wave_reduce(); B.wave_reduce();
+      double magA, magB;
+      const double cA = A.cost(magA), cB = B.cost(magB);
+      if (lane == 0) { s_cost[th0] = cA; s_mag[th0] = magA; s_cost[th1] = cB; s_mag[th1] = magB; }
     }
     __syncthreads();
-    // first strict maximum (rectangle_fitting.py:135-136)
-    int best = 0;
-    {
-      double bc = -INFINITY;
-      for (int th = 0; th < n_theta; th++) {
-        const double c = s_cost[th];
-        if (bc < c) { bc = c; best = th; }
-      }
-    }
+    // the arg-max of the reference (tier 2 only for headings within the band): every wave computes the same answer
+    double magmax = 0.0;
+    for (int th = 0; th < n_theta; th++) { const double g = s_mag[th]; if (g > magmax) magmax = g; }
+    const int best = wave_pick_heading(s_cost, n_theta, magmax, mx, my, m, s_ct, s_st);
     // extents at the best heading (rectangle_fitting.py:139-157)
     const double thb = (double)best * dtheta;
     const double sin_s = sin(thb), cos_s = cos(thb);
@@ -1484,10 +1611,9 @@ __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restric
       a0[h] = wave_min_d(a0[h]); a1[h] = wave_max_d(a1[h]);
       b0[h] = wave_min_d(b0[h]); b1[h] = wave_max_d(b1[h]);
     }
-    double s1[BIGC_HPW], s2[BIGC_HPW];
-    int n1[BIGC_HPW], n2[BIGC_HPW];
+    FitAcc A[BIGC_HPW];
 #pragma unroll
-    for (int h = 0; h < BIGC_HPW; h++) { s1[h] = 0.0; s2[h] = 0.0; n1[h] = 0; n2[h] = 0; }
+    for (int h = 0; h < BIGC_HPW; h++) A[h].clear();
     for (int c0 = 0; c0 < m; c0 += BIGC_CH) {
       const int cm = min(BIGC_CH, m - c0);
       __syncthreads();
@@ -1496,49 +1622,18 @@ __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restric
       for (int i = lane; i < cm; i += 64) {
         const double x = lx[i], y = ly[i];
 #pragma unroll
-        for (int h = 0; h < BIGC_HPW; h++) {
-          const double c1 = x * ct[h] + y * st[h];
-          const double c2 = x * nst[h] + y * ct[h];
-          const double d1 = fmin(fabs(a1[h] - c1), fabs(c1 - a0[h]));
-          const double d2 = fmin(fabs(b1[h] - c2), fabs(c2 - b0[h]));
-          if (d1 < d2) { s1[h] += d1; n1[h]++; } else { s2[h] += d2; n2[h]++; }
-        }
-      }
-    }
-    double m1[BIGC_HPW], m2[BIGC_HPW], q1[BIGC_HPW], q2[BIGC_HPW];
-#pragma unroll
-    for (int h = 0; h < BIGC_HPW; h++) {
-      s1[h] = wave_sum_d(s1[h]); s2[h] = wave_sum_d(s2[h]);
-      n1[h] = wave_sum_i(n1[h]); n2[h] = wave_sum_i(n2[h]);
-      m1[h] = n1[h] ? s1[h] / (double)n1[h] : 0.0;
-      m2[h] = n2[h] ? s2[h] / (double)n2[h] : 0.0;
-      q1[h] = 0.0; q2[h] = 0.0;
-    }
-    for (int c0 = 0; c0 < m; c0 += BIGC_CH) {
-      const int cm = min(BIGC_CH, m - c0);
-      __syncthreads();
-      for (int i = threadIdx.x; i < cm; i += BIGC_T) { lx[i] = mx[c0 + i]; ly[i] = my[c0 + i]; }
-      __syncthreads();
-      for (int i = lane; i < cm; i += 64) {
-        const double x = lx[i], y = ly[i];
-#pragma unroll
-        for (int h = 0; h < BIGC_HPW; h++) {
-          const double c1 = x * ct[h] + y * st[h];
-          const double c2 = x * nst[h] + y * ct[h];
-          const double d1 = fmin(fabs(a1[h] - c1), fabs(c1 - a0[h]));
-          const double d2 = fmin(fabs(b1[h] - c2), fabs(c2 - b0[h]));
-          if (d1 < d2) { const double u = d1 - m1[h]; q1[h] += u * u; }
-          else { const double u = d2 - m2[h]; q2[h] += u * u; }
-        }
+        for (int h = 0; h < BIGC_HPW; h++) A[h].add(x, y, ct[h], st[h], a0[h], a1[h], b0[h], b1[h]);
       }
     }
 #pragma unroll
     for (int h = 0; h < BIGC_HPW; h++) {
-      const double Q1 = wave_sum_d(q1[h]), Q2 = wave_sum_d(q2[h]);
-      double V1 = 0.0, V2 = 0.0;
-      if (n1[h]) V1 = -(Q1 / (double)n1[h]);
-      if (n2[h]) V2 = -(Q2 / (double)n2[h]);
-      if (lane == 0 && th[h] < n_theta) W.big_cost[(size_t)c * MAXTH + th[h]] = V1 + V2;
+      A[h].wave_reduce();
+      double mag;
+      const double cst = A[h].cost(mag);
+      if (lane == 0 && th[h] < n_theta) {
+        W.big_cost[(size_t)c * MAXTH + th[h]] = cst;     // tier 1 (k_fit_big_box re-scores the headings in the band)
+        if (mag > 0.0) atomicMax((unsigned long long *)(W.dsc + (size_t)8 * W.big_list[c] + 7), (unsigned long long)__double_as_longlong(mag));
+      }
     }
   }
 }
@@ -1551,8 +1646,14 @@ __global__ __launch_bounds__(FT) void k_fit_big_box(
     int cap_rows, double *__restrict__ rows, int *__restrict__ n_rows,
     uint32_t *__restrict__ status, double *__restrict__ fit_ws, int cap_big) {
   __shared__ double s_ext[FW][4];
+  __shared__ double s_ct[MAXTH], s_st[MAXTH];
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
   const int nbig = min(W.counters[1], cap_big);
+  if (threadIdx.x < MAXTH) {                   // heading table (rectangle_fitting.py:119-122)
+    const double theta = (double)threadIdx.x * dtheta;
+    s_ct[threadIdx.x] = cos(theta);
+    s_st[threadIdx.x] = sin(theta);
+  }
   for (int c = blockIdx.x; c < nbig; c += gridDim.x) {
   __syncthreads();
   const double *dsc = W.dsc + (size_t)8 * W.big_list[c];
@@ -1561,12 +1662,9 @@ __global__ __launch_bounds__(FT) void k_fit_big_box(
   const double *mx = gsx + (long long)dsc[4], *my = gsy + (long long)dsc[4];
   const double *cost = W.big_cost + (size_t)c * MAXTH;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  int best = 0;
-  double bc = -INFINITY;
-  for (int th = 0; th < n_theta; th++) {          // first strict maximum (rectangle_fitting.py:135-136)
-    const double cc = cost[th];
-    if (bc < cc) { bc = cc; best = th; }
-  }
+  // the arg-max of the reference: tier-1 costs of k_fit_big_cost, the headings within the band re-scored with the
+  // reference's three sweeps (one heading, unless the cluster has a symmetry); every wave computes the same answer
+  const int best = wave_pick_heading(cost, n_theta, dsc[7], mx, my, m, s_ct, s_st);
   const double thb = (double)best * dtheta;
   const double sin_s = sin(thb), cos_s = cos(thb);
   double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;

@@ -1082,48 +1082,62 @@ __global__ __launch_bounds__(QT) void k_shadow_build(
 }
 
 // in-place ordered compaction of SHORT lists (the per-instance LiDAR lists): one workgroup per segment, 2048
-// positions per step, a thread looks after 8 consecutive ones; flags and coordinates are requested together (no
-// load waits for another), one block scan gives the destinations.  History: one wave per segment walking 64 (later
-// 512) positions at a time was a chain of dependent round trips for the longest list (0.03 / 0.02 ms for 0.36 M points).
+// positions per step; lane l of wave w looks after positions u * 256 + w * 64 + l (u < 8), so consecutive lanes read
+// consecutive positions and -- the ranks coming from ballots and ONE exchange of the 32 per-wave counts -- write
+// consecutive destinations; flags and coordinates are requested together (no load waits for another).
+// History: one wave per segment walking 64 (later 512) positions at a time was a chain of dependent round trips for
+// the longest list (0.03 / 0.02 ms for 0.36 M points); a thread per 8 CONSECUTIVE positions made every store
+// instruction of a wave touch 64 different 64-byte segments (the stores were half of the kernel's 26 us).
 // A destination never lies ahead of a source of the same or a later step, and every source of a step is in registers
-// before the scan's barriers, i.e. before the first store of the step.
+// before the barrier, i.e. before the first store of the step.
 constexpr int CS_T = 256, CS_E = 8;
 __global__ __launch_bounds__(CS_T) void k_seg_compact_short(
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     const long long *__restrict__ seg_base, int *__restrict__ seg_cnt, const uint8_t *__restrict__ flags, int S) {
-  __shared__ int s_w[CS_T / 64];
+  __shared__ int s_c[CS_E][CS_T / 64];
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   if (n == 0) return;
   const long long base = seg_base[s];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   int running = 0;
   for (int t0 = 0; t0 < n; t0 += CS_T * CS_E) {
-    const int i0 = t0 + (int)threadIdx.x * CS_E;
     bool f[CS_E];
     double x[CS_E], y[CS_E], z[CS_E];
 #pragma unroll
     for (int u = 0; u < CS_E; u++) {
-      const int i = i0 + u;
+      const int i = t0 + u * CS_T + (int)threadIdx.x;
       const bool in = i < n;
       f[u] = in && flags[base + i];
       x[u] = in ? px[base + i] : 0.0;
       y[u] = in ? py[base + i] : 0.0;
       z[u] = in ? pz[base + i] : 0.0;
     }
-    int mine = 0;
-#pragma unroll
-    for (int u = 0; u < CS_E; u++) mine += f[u] ? 1 : 0;
-    int tot;
-    int r = block_excl_scan<CS_T / 64>(mine, s_w, tot);
+    unsigned long long m[CS_E];
 #pragma unroll
     for (int u = 0; u < CS_E; u++) {
-      if (f[u]) {
-        const long long d = base + running + r;
-        px[d] = x[u]; py[d] = y[u]; pz[d] = z[u];
-        r++;
+      m[u] = __ballot(f[u]);
+      if (lane == 0) s_c[u][wave] = __popcll(m[u]);
+    }
+    __syncthreads();
+    int before = 0, tot = 0;                       // kept points of the step before (u, wave) in position order | in the step
+#pragma unroll
+    for (int u = 0; u < CS_E; u++) {
+      int mine = before;
+#pragma unroll
+      for (int w = 0; w < CS_T / 64; w++) {
+        const int c = s_c[u][w];
+        mine += (w < wave) ? c : 0;
+        tot += c;
       }
+      if (f[u]) {
+        const long long d = base + running + mine + __popcll(m[u] & ((1ull << lane) - 1ull));
+        px[d] = x[u]; py[d] = y[u]; pz[d] = z[u];
+      }
+      before = tot;
     }
     running += tot;
+    __syncthreads();                               // s_c is rewritten by the next step
   }
   if (threadIdx.x == 0) seg_cnt[s] = running;
 }

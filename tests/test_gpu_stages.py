@@ -465,6 +465,84 @@ def test_lshape_fit_matches_oracle(st):
         np.testing.assert_allclose(got[4:16], r.as_vector(), rtol=1e-9, atol=1e-9)
 
 
+def test_lshape_fit_heading_ties_are_decided_like_the_reference(st):
+    """The heading search is two-tier (two-sweep variances for all 89 headings, the reference's three sweeps only for
+    the headings within 1e-8 of the best one): point sets with EXACT symmetries -- several headings share the best
+    cost, or differ from it in the last bits -- must still come out with the reference's arg-max (first strict
+    maximum, rectangle_fitting.py:135-136).  One case per kernel of the stage (<= 64 points: a lane per heading;
+    <= 2048: a wave per heading; larger: heading batches), plus shapes whose cost does not depend on the heading."""
+    from dfu3d_amd.params import Params
+    rng = np.random.default_rng(41)
+    p = Params()
+    n_theta, dtheta = p.thetas()
+    cal = _rand_calib(rng, 30.0)
+    oc = _oracle_calib(cal)
+    M = 4
+
+    def square_grid(k, side, cx, cy):                      # k x k lattice: invariant under 90-degree rotations and mirrors
+        g = (np.arange(k) - (k - 1) / 2.0) * (side / max(k - 1, 1))
+        xx, yy = np.meshgrid(g, g)
+        return np.stack([xx.ravel() + cx, yy.ravel() + cy], 1)
+
+    def ring(n, r, cx, cy):                                # regular n-gon: cost is the same for many headings
+        a = 2 * np.pi * np.arange(n) / n
+        return np.stack([cx + r * np.cos(a), cy + r * np.sin(a)], 1)
+
+    def mirrored_l(n, cx, cy):                             # an L shape and its mirror image about the diagonal: theta <-> 90 - theta
+        k = n // 4
+        t = rng.uniform(0.0, 4.0, k)
+        a = np.stack([t, np.zeros(k)], 1)
+        b = np.stack([np.zeros(k), rng.uniform(0.0, 1.5, k)], 1)
+        q = np.vstack([a, b])
+        return np.vstack([q, q[:, ::-1]]) + np.array([cx, cy])
+    shapes = [square_grid(7, 2.0, 10.0, 4.0),              # 49 points  -> k_fit_tiny
+              ring(60, 1.5, -12.0, 6.0),
+              square_grid(30, 2.5, 14.0, -7.0),            # 900 points -> k_fit_medium
+              ring(720, 2.0, 20.0, 11.0),
+              mirrored_l(400, -18.0, -9.0),
+              square_grid(60, 2.8, 25.0, 3.0),             # 3600 points -> k_fit_big_*
+              mirrored_l(5000, 8.0, 16.0),
+              np.array([[3.0, 3.0], [4.0, 4.0]])]          # two points: every heading but 45 degrees has zero variance
+    segs, classes, iscar, boxes = [], [], [], []
+    for i, xy in enumerate(shapes):
+        z = rng.uniform(-1.7, 0.3, len(xy))
+        segs.append(np.concatenate([xy, z[:, None]], 1))
+        classes.append(i % 10); iscar.append(0); boxes.append([10.0 + i, 5.5, 30.25, 20.0])
+    while len(segs) % M:
+        segs.append(np.zeros((0, 3))); classes.append(0); iscar.append(0); boxes.append([0, 0, 0, 0])
+    S = len(segs)
+    V = S // M
+    P, base, cnt, cap = _pool_from_segments(segs)
+    px, py, pz = _t(P[:, 0]), _t(P[:, 1]), _t(P[:, 2])
+    tb, tc = _t(base), _t(cnt)
+    label = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    st.range_cluster(px, py, tb, tc, S, p.R0, p.Rd, label, cap)
+    cap_rows = 64
+    rows = torch.zeros(cap_rows * st.ROW_DOUBLES, dtype=torch.float64, device=DEV)
+    n_rows = torch.zeros(1, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st.lshape_fit(px, py, pz, label, tb, tc, S, M, _t(np.stack([cal.record()] * V)), _t(np.array(classes, np.int32)),
+                  _t(np.array(iscar, np.int32)), _t(np.array(boxes, np.float32)),
+                  torch.ones(S, dtype=torch.float32, device=DEV), n_theta, dtheta,
+                  p.car_aspect_max, torch.zeros(cap, dtype=torch.float64, device=DEV),
+                  torch.zeros(cap, dtype=torch.float64, device=DEV),
+                  torch.zeros(cap, dtype=torch.int32, device=DEV), cap_rows, rows, n_rows, status, cap)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    n = int(n_rows.item())
+    R = rows.view(cap_rows, st.ROW_DOUBLES)[:n].cpu().numpy()
+    R = R[np.lexsort((R[:, 2], R[:, 1], R[:, 0]))]
+    exp = []
+    for s_, pts in enumerate(segs):
+        for r in O.generate_anns("Truck", pts, classes[s_], np.array(boxes[s_], np.float32), oc, O.Params(), inst=s_ % M):
+            exp.append((s_ // M, s_ % M, r.cluster, r))
+    assert n == len(exp) and n >= 8, (n, len(exp))
+    for got, (v, j, k, r) in zip(R, exp):
+        assert (int(got[0]), int(got[1]), int(got[2])) == (v, j, k)
+        # column 18 of the engine row is the chosen heading: the oracle's (= the reference's) arg-max, exactly
+        np.testing.assert_allclose(got[4:16], r.as_vector(), rtol=1e-9, atol=1e-9)
+
+
 # ------------------------------------------------------------------ a4/a5/a6
 def _lidar_setup(seed, n_frames=2, cams=3, H=225, W=400, M=4):
     from dfu3d_amd import synth
