@@ -1610,7 +1610,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_RESOLVE) {
-    hipLaunchKernelGGL(k_rf_resolve, dim3(4096), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
+    hipLaunchKernelGGL(k_rf_resolve, dim3(8192), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
                        (long long)pool_cap, (const long long *)seg_base, seg_cnt, radius, nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rf_ranges, dim3(512), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,

@@ -266,3 +266,117 @@ def get_official_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict
                     for l, level in enumerate(levels):
                         ret['%s_%s/%s_R40' % (name, kind, level)] = t[j, l, 0]
     return out.getvalue(), ret
+
+
+def do_coco_style_eval(gt_annos, dt_annos, current_classes, overlap_ranges, compute_aos):
+    """eval.py:675-690: AP averaged over ten min-overlaps per (metric, class).  overlap_ranges (3, metric, class) =
+    (first, last, count) for np.linspace.  The reference's version cannot run: it hands np.linspace a float count
+    (TypeError under any recent NumPy) and unpacks FOUR values from its own do_eval, which returns eight
+    (eval.py:645-673); golden G9 records the exception.  This one does what the statements mean."""
+    min_overlaps = np.zeros([10, *overlap_ranges.shape[1:]])
+    for i in range(overlap_ranges.shape[1]):
+        for j in range(overlap_ranges.shape[2]):
+            lo, hi, num = overlap_ranges[:, i, j]
+            min_overlaps[:, i, j] = np.linspace(lo, hi, int(num))
+    mAP_bbox, mAP_bev, mAP_3d, mAP_aos = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos)[:4]
+    mAP_bbox, mAP_bev, mAP_3d = mAP_bbox.mean(-1), mAP_bev.mean(-1), mAP_3d.mean(-1)
+    if mAP_aos is not None:
+        mAP_aos = mAP_aos.mean(-1)
+    return mAP_bbox, mAP_bev, mAP_3d, mAP_aos
+
+
+def _compute_aos(dt_annos):
+    for anno in dt_annos:                            # alpha == -10 marks "no orientation" (eval.py:768-773)
+        if anno['alpha'].shape[0] != 0:
+            return bool(anno['alpha'][0] != -10)
+    return False
+
+
+def get_coco_eval_result(gt_annos, dt_annos, current_classes):
+    """eval.py:836-894 -> report text.  The class table is the function's own (KITTI's five names by number), as in
+    the reference: a class NUMBER handed to do_eval still indexes the module's CLASS_NAMES (eval.py:32)."""
+    class_to_name = {0: 'Car', 1: 'Pedestrian', 2: 'Cyclist', 3: 'Van', 4: 'Person_sitting'}
+    class_to_range = {0: [0.5, 0.95, 10], 1: [0.25, 0.7, 10], 2: [0.25, 0.7, 10], 3: [0.5, 0.95, 10], 4: [0.25, 0.7, 10]}
+    name_to_class = {v: n for n, v in class_to_name.items()}
+    if not isinstance(current_classes, (list, tuple)):
+        current_classes = [current_classes]
+    current_classes = [name_to_class[c] if isinstance(c, str) else c for c in current_classes]
+    overlap_ranges = np.zeros([3, 3, len(current_classes)])
+    for i, curcls in enumerate(current_classes):
+        overlap_ranges[:, :, i] = np.array(class_to_range[curcls])[:, np.newaxis]
+    compute_aos = _compute_aos(dt_annos)
+    mAPbbox, mAPbev, mAP3d, mAPaos = do_coco_style_eval(gt_annos, dt_annos, current_classes, overlap_ranges, compute_aos)
+    out = io.StringIO()
+    for j, curcls in enumerate(current_classes):
+        o_range = np.array(class_to_range[curcls])[[0, 2, 1]]
+        o_range[1] = (o_range[2] - o_range[0]) / (o_range[1] - 1)
+        print("%s coco AP@%.2f:%.2f:%.2f:" % ((class_to_name[curcls],) + tuple(o_range)), file=out)
+        print("bbox AP:%.2f, %.2f, %.2f" % tuple(mAPbbox[j, :3]), file=out)
+        print("bev  AP:%.2f, %.2f, %.2f" % tuple(mAPbev[j, :3]), file=out)
+        print("3d   AP:%.2f, %.2f, %.2f" % tuple(mAP3d[j, :3]), file=out)
+        if compute_aos:
+            print("aos  AP:%.2f, %.2f, %.2f" % tuple(mAPaos[j, :3]), file=out)
+    return out.getvalue()
+
+
+def filter_det_range(dets, close, far):
+    """eval.py:897-913: the boxes of one frame whose |z_camera| lies in (close, far]."""
+    from copy import deepcopy
+    dets = deepcopy(dets)
+    if dets['location'].shape[0] == 0:
+        return dets
+    valid_idx = (np.abs(dets['location'][:, 2]) > close) * (np.abs(dets['location'][:, 2]) <= far)
+    for k in dets:
+        if k == 'frame_id' or k == 'gt_boxes_lidar':
+            continue
+        dets[k] = dets[k][valid_idx]
+    return dets
+
+
+def get_range_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict=None, ranges=(0, 30, 50, 80)):
+    """eval.py:916-1008 -> (report text, {'<Class>_<3d|bev>_iou<0.7|0.5>/<near>-<far>_R40': AP}): BEV / 3-D AP_R40 at
+    difficulty 3 per distance band (and over all bands).  Class table and min-overlaps are the function's own, as in
+    the reference (seven KITTI-style names by number)."""
+    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.7, 0.5]] * 3)
+    overlap_0_5 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.5, 0.25], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5, 0.25],
+                            [0.5, 0.25, 0.25, 0.5, 0.25, 0.5, 0.25]])
+    min_overlaps = np.stack([overlap_0_7, overlap_0_5], axis=0)
+    class_to_name = {0: 'Car', 1: 'Pedestrian', 2: 'Cyclist', 3: 'Van', 4: 'Person_sitting', 5: 'Truck', 6: 'Dynamic'}
+    name_to_class = {v: n for n, v in class_to_name.items()}
+    if not isinstance(current_classes, (list, tuple)):
+        current_classes = [current_classes]
+    current_classes = [name_to_class[c] if isinstance(c, str) else c for c in current_classes]
+    min_overlaps = min_overlaps[:, :, current_classes]
+    compute_aos = _compute_aos(dt_annos)
+    ret_dict = {}
+    range_pairs = [(ranges[i], ranges[i + 1]) for i in range(len(ranges) - 1)] + [(ranges[0], ranges[-1])]
+    for range_s, range_e in range_pairs:
+        dt_r = [filter_det_range(d, range_s, range_e) for d in dt_annos]
+        gt_r = [filter_det_range(d, range_s, range_e) for d in gt_annos]
+        res = do_eval(gt_r, dt_r, current_classes, min_overlaps, compute_aos, difficultys=[3], PR_detail_dict=PR_detail_dict)
+        mAPbev_R40, mAP3d_R40 = res[5], res[6]
+        for j, curcls in enumerate(current_classes):
+            name = class_to_name[curcls]
+            ret_dict['%s_3d_iou0.7/%02d-%02d_R40' % (name, range_s, range_e)] = mAP3d_R40[j, 0, 0]
+            ret_dict['%s_3d_iou0.5/%02d-%02d_R40' % (name, range_s, range_e)] = mAP3d_R40[j, 0, 1]
+            ret_dict['%s_bev_iou0.7/%02d-%02d_R40' % (name, range_s, range_e)] = mAPbev_R40[j, 0, 0]
+            ret_dict['%s_bev_iou0.5/%02d-%02d_R40' % (name, range_s, range_e)] = mAPbev_R40[j, 0, 1]
+    out = io.StringIO()
+    head = "RANGE " + "  ".join("%02d-%02d " % rp for rp in range_pairs)
+    for j, curcls in enumerate(current_classes):
+        name = class_to_name[curcls]
+        col = lambda kind, iou: [ret_dict['%s_%s_iou%s/%02d-%02d_R40' % (name, kind, iou, rs, re)] for rs, re in range_pairs]
+        bev07, d07, bev05, d05 = col('bev', '0.7'), col('3d', '0.7'), col('bev', '0.5'), col('3d', '0.5')
+        print("%s IoU 0.5:" % name, file=out)                        # (the reference's labels, eval.py:989-1006)
+        print(head, file=out)
+        print("BEV:  " + ", ".join("%6.3f" % x for x in bev07), file=out)
+        print("3D :  " + ", ".join("%6.3f" % x for x in d07), file=out)
+        print("%s IoU 0.25:" % name, file=out)
+        print(head, file=out)
+        print("BEV:  " + ", ".join("%6.3f" % x for x in bev05), file=out)
+        print("3D :  " + ", ".join("%6.3f" % x for x in d05), file=out)
+        print("%s IoU 0.7:" % name, file=out)
+        print(", ".join("%3.1f / %3.1f" % (x, y) for x, y in zip(bev07, d07)), file=out)
+        print("%s IoU 0.5:" % name, file=out)
+        print(", ".join("%3.1f / %3.1f" % (x, y) for x, y in zip(bev05, d05)) + "\n", file=out)
+    return out.getvalue(), ret_dict

@@ -73,7 +73,23 @@ def main():
         out['%s/official/keys' % tag] = np.array(keys)
         out['%s/official/values' % tag] = np.array([ret[k] for k in keys], np.float64)
         out['%s/official/text' % tag] = np.array(text)
-        print(tag, 'frames', frames, 'official keys', len(keys))
+        # get_range_eval_result (eval.py:916-1008): its own class table maps 'Car' / 'Pedestrian' to the numbers 0 / 1
+        with np.errstate(all='ignore'):
+            rtext, rret = ref_eval.get_range_eval_result(gts, dts, ['Car', 'Pedestrian'])
+        rkeys = sorted(rret)
+        out['%s/range/keys' % tag] = np.array(rkeys)
+        out['%s/range/values' % tag] = np.array([rret[k] for k in rkeys], np.float64)
+        out['%s/range/text' % tag] = np.array(rtext)
+        # get_coco_eval_result (eval.py:836-894) cannot run in the reference: np.linspace is handed a float count (TypeError under
+        # NumPy >= 1.18) and do_coco_style_eval unpacks four of do_eval's eight return values (ValueError)
+        try:
+            with np.errstate(all='ignore'):
+                ref_eval.get_coco_eval_result(gts, dts, ['Car'])
+            coco_raises = ''
+        except (ValueError, TypeError) as e:
+            coco_raises = '%s: %s' % (type(e).__name__, e)
+        out['%s/coco/raises' % tag] = np.array(coco_raises)
+        print(tag, 'frames', frames, 'official keys', len(keys), 'range keys', len(rkeys), 'coco:', coco_raises or 'ran')
     # get_thresholds on its own
     rng = np.random.default_rng(5)
     sc = np.round(rng.uniform(0, 1, 500), 3)

@@ -268,3 +268,31 @@ def test_pseudo_labels_score_full_marks_against_the_oracles_labels(tmp_path):
             want = float((h > 0).sum()) / len(h) if metric == 2 else 1.0
             assert r['recall'][m, 0, 0, 0] == want, (names[m], metric)         # the best recall reached
             assert r['precision'][m, 0, 0, 0] == want, (names[m], metric)
+
+
+@pytest.mark.parametrize('tag', sorted(CASES))
+def test_range_eval_reproduces_the_reference(tag):
+    """get_range_eval_result (eval.py:916-1008: AP_R40 at difficulty 3 per distance band, its own class table) against
+    the reference's own output in golden G9: numbers to 1e-9, report text identical."""
+    from dfu3d_amd.pcdet_kitti import eval as E
+    gts, dts = golden_annos(tag, 'gt'), golden_annos(tag, 'dt')
+    text, got = E.get_range_eval_result(gts, dts, ['Car', 'Pedestrian'])
+    keys = [str(k) for k in G9['%s/range/keys' % tag]]
+    assert sorted(got) == keys
+    np.testing.assert_allclose([got[k] for k in keys], G9['%s/range/values' % tag], rtol=0, atol=1e-9, equal_nan=True)
+    assert text == str(G9['%s/range/text' % tag])
+
+
+def test_coco_eval_runs_where_the_reference_raises():
+    """get_coco_eval_result (eval.py:836-894) raises in the reference (recorded in G9: np.linspace with a float count,
+    then four-of-eight unpacking).  Here it runs: AP averaged over ten min-overlaps = the mean of do_eval's columns."""
+    from dfu3d_amd.pcdet_kitti import eval as E
+    assert 'Error' in str(G9['a/coco/raises'])
+    gts, dts = golden_annos('a', 'gt'), golden_annos('a', 'dt')
+    text = E.get_coco_eval_result(gts, dts, ['Car', 'Pedestrian'])
+    assert text.count('coco AP@') == 2 and 'Car coco AP@0.50:0.05:0.95:' in text and 'bev  AP:' in text
+    mo = np.zeros((10, 3, 1))
+    mo[:, :, 0] = np.linspace(0.5, 0.95, 10)[:, None]
+    bbox, bev, d3, aos = E.do_eval(gts, dts, [0], mo, True)[:4]
+    line = [l for l in text.splitlines() if l.startswith('3d   AP:')][0]
+    assert line == "3d   AP:%.2f, %.2f, %.2f" % tuple(d3.mean(-1)[0, :3])
