@@ -151,3 +151,91 @@ def nms(boxes, scores, thresh, pre_maxsize=None, iou=None, normal=False):
         keep.append(i)
         dead[i + 1:] |= iou[i, i + 1:] > thresh
     return order[np.array(keep, np.int64)], iou
+
+
+# ---- the reference's OWN overlap construction, for measuring how far it is from the exact area -------------------------
+def overlap_reference_margin(box_a, box_b, margin=1e-2, eps=1e-8):
+    """Restatement (test infrastructure; float32 like the kernel) of the reference's `box_overlap`
+    (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:108-222): the polygon is assembled from (i) the intersections of the
+    4 x 4 edge pairs that cross strictly (`intersection`, :61-92), (ii) the corners of either box that lie inside
+    the other one ENLARGED BY `margin` = 1e-2 on every side (`check_in_box2d`, :49-59), then sorted by angle about their
+    mean (bubble sort with a strict `>`, :189-198) and summed as a triangle fan (:208-211).  A corner up to 1 cm OUTSIDE
+    the other box therefore joins the polygon: the result can exceed the true intersection by a sliver (bounded by
+    margin x the perimeter in play), and for boxes that share edges it can also fall short (collinear edges do not
+    "cross").  One pair per call: boxes (7,) [x y z dx dy dz heading].  Used only by tests that count how many
+    suppression decisions differ between this construction and the exact area the product computes."""
+    f = np.float32
+    a, b = np.asarray(box_a, f), np.asarray(box_b, f)
+
+    def corners(bx):
+        hx, hy = bx[3] / f(2), bx[4] / f(2)
+        pts = np.array([[bx[0] - hx, bx[1] - hy], [bx[0] + hx, bx[1] - hy], [bx[0] + hx, bx[1] + hy], [bx[0] - hx, bx[1] + hy]], f)
+        c, s = f(np.cos(bx[6])), f(np.sin(bx[6]))
+        out = np.empty((5, 2), f)
+        for k in range(4):
+            dx, dy = pts[k, 0] - bx[0], pts[k, 1] - bx[1]
+            out[k, 0] = dx * c + dy * (-s) + bx[0]
+            out[k, 1] = dx * s + dy * c + bx[1]
+        out[4] = out[0]
+        return out
+
+    def cross3(p1, p2, p0):
+        return (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1])
+
+    def intersection(p1, p0, q1, q0):
+        if not (min(p0[0], p1[0]) <= max(q0[0], q1[0]) and min(q0[0], q1[0]) <= max(p0[0], p1[0]) and
+                min(p0[1], p1[1]) <= max(q0[1], q1[1]) and min(q0[1], q1[1]) <= max(p0[1], p1[1])):
+            return None
+        s1, s2, s3, s4 = cross3(q0, p1, p0), cross3(p1, q1, p0), cross3(p0, q1, q0), cross3(q1, p1, q0)
+        if not (s1 * s2 > 0 and s3 * s4 > 0):
+            return None
+        s5 = cross3(q1, p1, p0)
+        if abs(s5 - s1) > eps:
+            return np.array([(s5 * q0[0] - s1 * q1[0]) / (s5 - s1), (s5 * q0[1] - s1 * q1[1]) / (s5 - s1)], f)
+        a0, b0, c0 = p0[1] - p1[1], p1[0] - p0[0], p0[0] * p1[1] - p1[0] * p0[1]
+        a1, b1, c1 = q0[1] - q1[1], q1[0] - q0[0], q0[0] * q1[1] - q1[0] * q0[1]
+        D = a0 * b1 - a1 * b0
+        return np.array([(b0 * c1 - b1 * c0) / D, (a1 * c0 - a0 * c1) / D], f)
+
+    def inside(bx, p):
+        c, s = f(np.cos(-bx[6])), f(np.sin(-bx[6]))
+        rx = (p[0] - bx[0]) * c + (p[1] - bx[1]) * (-s)
+        ry = (p[0] - bx[0]) * s + (p[1] - bx[1]) * c
+        return abs(rx) < bx[3] / f(2) + f(margin) and abs(ry) < bx[4] / f(2) + f(margin)
+
+    with np.errstate(all="ignore"):
+        ca, cb = corners(a), corners(b)
+        pts = []
+        for i in range(4):
+            for j in range(4):
+                p = intersection(ca[i + 1], ca[i], cb[j + 1], cb[j])
+                if p is not None:
+                    pts.append(p)
+        for k in range(4):
+            if inside(a, cb[k]):
+                pts.append(cb[k].copy())
+            if inside(b, ca[k]):
+                pts.append(ca[k].copy())
+        cnt = len(pts)
+        if cnt == 0:
+            return 0.0
+        P = np.array(pts, f)
+        ctr = P.sum(0) / f(cnt)
+        ang = [f(np.arctan2(p[1] - ctr[1], p[0] - ctr[0])) for p in P]
+        for j in range(cnt - 1):                       # the kernel's bubble sort (strict >: equal angles keep their order)
+            for i in range(cnt - j - 1):
+                if ang[i] > ang[i + 1]:
+                    P[[i, i + 1]] = P[[i + 1, i]]
+                    ang[i], ang[i + 1] = ang[i + 1], ang[i]
+        area = f(0)
+        for k in range(cnt - 1):
+            u, v = P[k] - P[0], P[k + 1] - P[0]
+            area += u[0] * v[1] - u[1] * v[0]
+        return float(abs(area) / f(2))
+
+
+def iou_bev_reference_margin(box_a, box_b):
+    """iou3d_nms_kernel.cu:224-231 on top of overlap_reference_margin."""
+    sa, sb = float(np.float32(box_a[3]) * np.float32(box_a[4])), float(np.float32(box_b[3]) * np.float32(box_b[4]))
+    s = overlap_reference_margin(box_a, box_b)
+    return s / max(sa + sb - s, 1e-8)
