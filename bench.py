@@ -388,6 +388,14 @@ def main():
         """k passes; pass i+1 is enqueued before the host waits for the rows of pass i (every pass is collected,
         sorted and gathered inside the loop -- nothing is left for after the timed region)."""
         rows, pending = None, None
+        if args.graphs:                          # one set of captured row buffers: no pipelining across passes
+            for _ in range(k):
+                r_, st_ = eng.run(batch)
+                if st_:
+                    from dfu3d_amd.stages import status_message
+                    raise SystemExit("device status: " + status_message(st_))
+                rows = D.allgather_rows(eng.gather_layout(r_, batch))
+            return rows
         for _ in range(k):
             h = eng.launch(batch)
             if pending is not None:

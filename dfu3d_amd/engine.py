@@ -491,7 +491,15 @@ class PseudoBoxEngine:
 
     def launch(self, b: ViewBatch):
         """Enqueue a pass and return a handle for collect(): the host can enqueue the NEXT pass before it waits for
-        this one (the row buffers are per pass; the workspace is reused in stream order)."""
+        this one (the row buffers are per pass; the workspace is reused in stream order).
+        Limits of the pipelining: with graphs=True every pass writes the SAME captured row buffers, so a
+        handle would be overwritten by the next launch -- refused; and a pass that raises DFU3D_ST_VOX_OVERFLOW leaves
+        its bin table dirty, which collect() repairs only after the NEXT pass may already have been enqueued on it:
+        collect() then reports the status, and the caller must not use the rows of the pass launched in between
+        (bench.py aborts on any status)."""
+        if self.graphs:
+            raise Dfu3dError("launch() / collect() pipelining is not available with graphs=True (one set of captured "
+                             "row buffers): use run()")
         self.run(b, sync=False)
         return self._last
 
