@@ -113,6 +113,27 @@ def pmc_traffic(kernels):
         return None, None
 
 
+def valu_limit(kernel, avg_ms):
+    """What actually limits the dominant kernel, from the committed SQ counters (profiles/rNN_pmc_sq.json): the share
+    of the launch during which the vector pipes issue (VALU wave-instructions x 4 cycles over 1024 SIMDs at 2.4 GHz).
+    The roofline the contract prices a gather / scatter pass against is HBM (`bound`); a kernel far below it with
+    busy vector pipes is issue-limited, and this field says so."""
+    import glob
+    try:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))
+        with open(files[-1]) as f:
+            sq = json.load(f)
+        v = sq.get(kernel)
+        if not v:
+            return None
+        busy = v["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) / (avg_ms * 1e-3)
+        return {"valu_busy_frac_est": round(busy, 3), "valu_insts_per_wave": round(v["valu_per_wave"], 1),
+                "wait_any_frac": round(v["wait_any_frac"], 3), "source": os.path.basename(files[-1]),
+                "reading": ("vector-instruction issue, not HBM" if busy > 0.5 else "latency / memory")}
+    except Exception:
+        return None
+
+
 def cpu_baseline(scenes_cpu, params, dense, max_seconds=18.0):
     """The oracle (NumPy + C restatement, single thread) on a bounded sample of
     the same workload, on this box's host cores.  Its box rows are kept: they are what the `parity` block of the
@@ -482,7 +503,8 @@ def main():
             dom = table[0]                              # the dominant kernel of the pass
             if "achieved_GBs" in dom:
                 traffic, tsrc = pmc_traffic(dom["kernels"])
-                out["roofline"] = {"bound": "hbm", "kernel": dom["kernels"][0], "stage": dom["stage"],
+                out["roofline"] = {"bound": "hbm", "limited_by": valu_limit(dom["kernels"][0], dom["avg_ms"]),
+                                   "kernel": dom["kernels"][0], "stage": dom["stage"],
                                    "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
                                    "frac_of_measured_copy": round(dom["achieved_GBs"] / copy_rate, 5),

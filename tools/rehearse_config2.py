@@ -5,7 +5,7 @@ frames one at a time (--batch-frames 0) for a byte comparison; optionally the 2-
 (frames r::2, row gather, manifest).  Prints one JSON line.  Frames are small (225x400, one camera per frame as in
 the KITTI layout) so that thousands fit on the box's scratch disk; the rate is disk-inclusive (files in, files out).
 
-  python tools/rehearse_config2.py [N=2000] [root=/dev/shm/dfu3d_cfg2] [H=225] [W=400]
+  python tools/rehearse_config2.py [N=2000] [root=/dev/shm/dfu3d_cfg2] [H=225] [W=400] [reader processes=8]
 
 At the real size (H W = 900 1600, 8 masks: 17 MB of input per camera-frame) a few hundred frames fill the box's
 scratch memory: `python tools/rehearse_config2.py 320 /dev/shm/dfu3d_cfg2_full 900 1600`.
@@ -28,6 +28,7 @@ H = int(sys.argv[3]) if len(sys.argv) > 3 else 225
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 400
 M = 6 if H < 600 else 8
 BATCH = "32" if H < 600 else "16"
+PROCS = sys.argv[5] if len(sys.argv) > 5 else "8"          # reader processes of the batched runs
 
 
 def generate():
@@ -67,25 +68,29 @@ def labels(d):
     return {os.path.basename(p): open(p).read() for p in sorted(glob.glob(os.path.join(d, "*.txt")))}
 
 
-res = {"frames": N, "image": "%dx%d" % (W, H), "root": root}
+res = {"frames": N, "image": "%dx%d" % (W, H), "root": root, "reader_procs": int(PROCS)}
 if not os.path.isdir(os.path.join(root, "velodyne")) or len(os.listdir(os.path.join(root, "velodyne"))) != N:
     shutil.rmtree(root, ignore_errors=True)
     res["generate_s"] = round(generate(), 1)
 lab = os.path.join(root, "label_2")
 shutil.rmtree(lab, ignore_errors=True)
 # 1. the whole directory, batched, forked readers
-dt, out = cli(["--batch-frames", BATCH, "--reader-procs", "8", "--streams", "2"])
+dt, out = cli(["--batch-frames", BATCH, "--reader-procs", PROCS, "--streams", "2"])
 full = labels(lab)
 man = json.load(open(os.path.join(lab, "manifest.json")))
 assert len(full) == N and man["frames"] == N and man["boxes"] == sum(len(t.splitlines()) for t in full.values())
-res.update(batched_s=round(dt, 2), frames_per_s_disk_inclusive=round(N / dt, 1), boxes=man["boxes"],
+import re
+m_ = re.search(r"([0-9.]+) frames/s \(files in, files out\)", out)
+res.update(batched_s=round(dt, 2), frames_per_s_disk_inclusive=round(N / dt, 1),
+           frames_per_s_inside_the_cli=float(m_.group(1)) if m_ else None,     # (without interpreter start-up and imports)
+           boxes=man["boxes"],
            manifest={k: man[k] for k in ("frames", "boxes", "boxes_per_rank", "frames_with_boxes")})
 # 2. restart: delete some label files, --skip-existing relabels exactly those
 gone = sorted(full)[3:N:max(N // 40, 1)]
 stamp = {k: os.path.getmtime(os.path.join(lab, k)) for k in full}
 for k in gone:
     os.remove(os.path.join(lab, k))
-dt2, out2 = cli(["--batch-frames", BATCH, "--reader-procs", "8", "--skip-existing"])
+dt2, out2 = cli(["--batch-frames", BATCH, "--reader-procs", PROCS, "--skip-existing"])
 again = labels(lab)
 assert again == full, "restart produced different label files"
 untouched = [k for k in full if k not in gone]
