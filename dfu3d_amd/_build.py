@@ -83,12 +83,14 @@ VARIANTS = {
     "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],
     "grid_timing": ["-DDFU3D_DBG_GRID_TIMING"],
     "grid_split": ["-DDFU3D_GRID_SPLIT_LAUNCH"],
-    # radius filter: cycles per phase of k_rf_stream / k_rf_resolve (tools/rf_timing.py)
+    # radius filter: cycles per phase of k_rf_stream / k_rf_pair / k_rf_resolve (tools/rf_timing.py)
     "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
     # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
     "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
     "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
-    # radius filter, phase A: tuning builds (correct results): list neighbours lane^1 / lane^2 or across the rows, no prefetch of the next tile, grids
+    # radius filter, tuning builds (correct results): the pairing of listed points inside k_rf_stream instead of k_rf_pair,
+    # list neighbours lane^1 / lane^2 or across the whole wave, grids, occupancy of phase B, ranges in flight
+    "rf_fused": ["-DDFU3D_RF_FUSED"],
     "rf_quad": ["-DDFU3D_RF_NBR=0"],
     "rf_wave": ["-DDFU3D_RF_NBR=2"],
     "rf_g2048": ["-DDFU3D_RF_GRID=2048"],
@@ -96,25 +98,11 @@ VARIANTS = {
     "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
     "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
     "rf_ul4": ["-DDFU3D_RF_UL=4"],
-    # radius filter: cycles per phase of k_rf_stream / k_rf_resolve (tools/rf_timing.py)
-    "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
-    # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
-    "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
-    "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
-    # radius filter, phase A: tuning builds (correct results): list neighbours lane^1 / lane^2 or across the rows, no prefetch of the next tile, grids
-    "rf_quad": ["-DDFU3D_RF_NBR=0"],
-    "rf_wave": ["-DDFU3D_RF_NBR=2"],
-    "rf_nopf": ["-DDFU3D_RF_NO_PREFETCH"],
-    "rf_g4096": ["-DDFU3D_RF_GRID=4096"],
-    "rf_g1536": ["-DDFU3D_RF_GRID=1536"],
-    "rf_g8192_nopf": ["-DDFU3D_RF_GRID=8192", "-DDFU3D_RF_NO_PREFETCH"],
-    "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
-    "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
-    # short-list compaction: what of it takes the time (wrong results)
-    "cs0": ["-DDFU3D_DBG_CS_MODE=0"], "cs1": ["-DDFU3D_DBG_CS_MODE=1"], "cs2": ["-DDFU3D_DBG_CS_MODE=2"],
-    "rf_ul4": ["-DDFU3D_RF_UL=4"],
-    # radius filter, phase B: the points of two candidate ranges requested together (measurement for DESIGN §10 item 1)
-    "rf2": ["-DDFU3D_RF_RANGES_PER_STEP=2"],
+    # k_bp_vox: which of its accesses cost what (wrong results; tools/vox_traffic.sh)
+    "vox_skip1": ["-DDFU3D_DBG_VOX_SKIP=1"], "vox_skip2": ["-DDFU3D_DBG_VOX_SKIP=2"],
+    "vox_skip8": ["-DDFU3D_DBG_VOX_SKIP=8"], "vox_skip11": ["-DDFU3D_DBG_VOX_SKIP=11"],
+    # k_bp_bin: register budgets for 6 / 8 workgroups per compute unit (the short LDS list of undecided pixels makes room)
+    "p1_occ6": ["-DDFU3D_P1_OCC=6"], "p1_occ8": ["-DDFU3D_P1_OCC=8"],
 }
 
 

@@ -172,28 +172,36 @@ __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix,
 // The reference bins theta = acos(z/r) and phi = atan(y/x) (my_loader.py:166-177).  Both functions are monotone, so
 // "theta lies in bin k" is the same statement as "q = -z/r lies between -cos of the bin's two edges", and likewise
 // for phi with q = t / (1 + |t|), t = y/x = tan(phi) -- computed as y sgn(x) / (|x| + |y|), stable for every
-// direction, and with 1/2 <= dq/dphi <= 1.  Tier 1 therefore never evaluates acos / atan: per axis a table
-// over q (uniform cells, built on the device in fp64 by k_bp_tables, float32 entries) gives for the cell of q
-// three CONSECUTIVE bin edges in q-space (prv < nxt < nxt2) and the index kn of the middle one; q is accepted for
-// bin kn-1 or kn only when it is farther than delta from the edges around it, delta bounding |q - q of the fp64
-// reference| (see pixel_bin_fast).  Correctness needs only that the three edges are consecutive -- how well the cell
-// matches q merely decides how often the answer is "undecided".  Edges outside the range of the angle are +-inf.
-constexpr int TAB_T_MAX = 65536, TAB_P_MAX = 16384;    // cells per axis (16 B each)
+// direction, and with 1/2 <= dq/dphi <= 1.  Tier 1 therefore never evaluates acos / atan: per axis a table over q
+// (uniform cells of width w, built on the device in fp64 by k_bp_tables, float32 entries) gives for the cell of q the
+// ONE bin edge E nearest to the cell's centre (in q-space) and its index k: q is above or below E, hence in bin k or
+// k-1, and the answer is taken only when |q - E| > delta, delta bounding |q - q of the fp64 reference| (see
+// classify_fast).  That is enough because the builder keeps an entry only if every OTHER edge is farther than
+// reach + TAB_DMAX from the cell's centre, reach = (1/2 + TAB_SLOP_W) w covering the cell and the rounding of the cell
+// index (<= 0.02 cells: one FMA on |q| <= 1; make_fast_geom checks the bound): with delta < TAB_DMAX -- tested once
+// per pixel -- no other edge is within delta of q.  Cells that fail (bins narrower than about 2.5e-4 in q-space: theta
+// within ~0.1 rad of a pole for the product's 0.002 rad bins), and the two sentinel cells around the table (q outside
+// it, NaN) hold E = NaN: every comparison fails, "undecided".  Edges outside the range of the angle are +-inf.
+// (Round 2's cells held three consecutive edges and took four comparisons per axis in a 1 MB table; this form takes
+// one, from ~80 KB.)
+constexpr int TAB_T_MAX = 65534, TAB_P_MAX = 16382;    // cells per axis (8 B each, + 2 sentinels)
+constexpr double TAB_SLOP_W = 1.0 / 16;
+constexpr float TAB_DMAX = 1.0e-4f;
 constexpr uint32_t AMBIG = 0xFFFFFFFEu;
-constexpr int TB_AMBIG = (int)0x80000000;
 
 struct FastGeom {
   float r_lo, r_hi, z_max, q_tmin;       // q_tmin = -cos(theta_min) (-inf / +inf outside (0, pi))
-  float tq0, tinv, pq0, pinv;            // cell of q: (q - q0) * inv
-  int tJ, pJ;
-  double tq0d, twd, pq0d, pwd;           // the same origins and the cell widths in fp64, for the table builder
+  float tinv, tc1, pinv, pc1;            // table index of q: (int)(q * inv + c1), c1 = 1 - q0 * inv (cell 0 is a sentinel)
+  float dmax, pad0;                      // deltas at or above this are "undecided" (TAB_DMAX, or 0: no tier 1)
+  int tJ, pJ;                            // cells per axis without the sentinels
+  double tq0d, twd, pq0d, pwd;           // origins and cell widths in fp64, for the table builder
 };
 inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   const double pi = 3.14159265358979323846;
   FastGeom f;
   // r certain only for the 1-cell grid and well inside it; otherwise an empty interval
-  f.r_lo = (g.grid_r == 1) ? (float)(g.rmin_r + 2e-3) : 1.0f;
-  f.r_hi = (g.grid_r == 1) ? (float)((g.rmin_r + g.vsize_r) * 0.9998) : 0.0f;
+  f.r_lo = (g.grid_r == 1) ? __builtin_fmaxf((float)(g.rmin_r + 2e-3), 1e-3f) : 1.0f;
+  f.r_hi = (g.grid_r == 1) ? __builtin_fminf((float)((g.rmin_r + g.vsize_r) * 0.9998), 1e15f) : 0.0f;
   f.z_max = (float)g.z_max;
   f.q_tmin = g.theta_min <= 0.0 ? -INFINITY : (g.theta_min >= pi ? INFINITY : (float)-__builtin_cos(g.theta_min));
   auto cells = [](double lo, double hi, double min_width, int cap, double &q0, double &w) {
@@ -207,7 +215,9 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   {   // theta: the window's edges, clipped to where tier 1 works at all (sin(theta)^2 > 1e-4)
     const double a_lo = __builtin_fmax(g.rmin_t + (double)g.t_lo * g.vsize_t, 0.0100002);
     const double a_hi = __builtin_fmin(g.rmin_t + (double)(g.t_lo + g.t_n) * g.vsize_t, pi - 0.0100002);
-    const double smin = __builtin_fmin(__builtin_sin(a_lo), __builtin_sin(a_hi));
+    // cells half as wide as a bin at sin(theta) = 0.2 or at the window's narrowest bin, whichever is wider (narrower
+    // bins get cells that hold no decision)
+    const double smin = __builtin_fmax(__builtin_fmin(__builtin_sin(a_lo), __builtin_sin(a_hi)), 0.2);
     f.tJ = cells(-__builtin_cos(a_lo), -__builtin_cos(a_hi), g.vsize_t * smin, TAB_T_MAX, f.tq0d, f.twd);
   }
   {   // phi: q = tan(phi) / (1 + |tan(phi)|) in (-1, 1); dq/dphi lies in [1/2, 1]
@@ -216,46 +226,60 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
     auto qphi = [](double P) { return __builtin_sin(P) / (__builtin_fabs(__builtin_cos(P)) + __builtin_fabs(__builtin_sin(P))); };
     f.pJ = cells(qphi(b_lo), qphi(b_hi), 0.5 * g.vsize_p, TAB_P_MAX, f.pq0d, f.pwd);
   }
-  f.tq0 = (float)f.tq0d; f.tinv = (float)(1.0 / f.twd);
-  f.pq0 = (float)f.pq0d; f.pinv = (float)(1.0 / f.pwd);
+  f.tinv = (float)(1.0 / f.twd); f.tc1 = (float)(1.0 - f.tq0d / f.twd);
+  f.pinv = (float)(1.0 / f.pwd); f.pc1 = (float)(1.0 - f.pq0d / f.pwd);
+  f.dmax = TAB_DMAX;
+  // rounding of the cell index, in cells: the float32 constants and the FMA, each 2^-24 relative to a magnitude of at
+  // most (1 + |q0|) / w + 1.  A geometry with bins so narrow that this eats the slop gets no tier 1 at all.
+  const double slop_t = 1.8e-7 * ((1.0 + __builtin_fabs(f.tq0d)) / f.twd + 1.0), slop_p = 1.8e-7 * ((1.0 + __builtin_fabs(f.pq0d)) / f.pwd + 1.0);
+  if (!(__builtin_fmax(slop_t, slop_p) <= TAB_SLOP_W)) f.dmax = 0.0f;
+  f.pad0 = 0.0f;
   return f;
 }
 
-// one thread per cell: entry = (prv, nxt, nxt2, kn) with nxt the first edge at or above the cell's start
-__global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float4 *__restrict__ tab) {
+// one thread per table entry (tJ + 2 of theta, then pJ + 2 of phi): (E, k) = the edge nearest to the cell's centre and
+// its index, or (NaN, 0)
+__global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float2 *__restrict__ tab) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= fg.tJ + fg.pJ) return;
+  if (i >= fg.tJ + fg.pJ + 4) return;
   const double pi = 3.14159265358979323846;
-  const bool is_t = i < fg.tJ;
-  const int j = is_t ? i : i - fg.tJ;
-  const double s = is_t ? fg.tq0d + (double)j * fg.twd : fg.pq0d + (double)j * fg.pwd;
+  const bool is_t = i < fg.tJ + 2;
+  const int jj = is_t ? i : i - (fg.tJ + 2);
+  const int J = is_t ? fg.tJ : fg.pJ;
+  if (jj == 0 || jj == J + 1) { tab[i] = make_float2(__int_as_float(0x7FC00000), __int_as_float(0)); return; }
+  const double w = is_t ? fg.twd : fg.pwd;
+  const double c = (is_t ? fg.tq0d : fg.pq0d) + ((double)(jj - 1) + 0.5) * w;
   const double rmin = is_t ? g.rmin_t : g.rmin_p, vs = is_t ? g.vsize_t : g.vsize_p;
   auto edge = [&](long long k) -> double {          // edge k of the axis in q-space
     const double B = rmin + (double)k * vs;
     if (is_t) return B <= 0.0 ? -INFINITY : (B >= pi ? INFINITY : -cos(B));
     return B <= -pi / 2 ? -INFINITY : (B >= pi / 2 ? INFINITY : sin(B) / (fabs(cos(B)) + fabs(sin(B))));
   };
-  // the angle at the cell's start: theta = acos(-q); phi = atan(q / (1 - |q|))
-  const double a = is_t ? acos(fmin(fmax(-s, -1.0), 1.0)) : (fabs(s) < 1.0 ? atan(s / (1.0 - fabs(s))) : copysign(pi / 2, s));
-  double kf = ceil((a - rmin) / vs);
+  // the angle at the centre: theta = acos(-q); phi = atan(q / (1 - |q|))
+  const double a = is_t ? acos(fmin(fmax(-c, -1.0), 1.0)) : (fabs(c) < 1.0 ? atan(c / (1.0 - fabs(c))) : copysign(pi / 2, c));
+  double kf = floor((a - rmin) / vs);
   kf = fmin(fmax(kf, -1.0e9), 1.0e9);
-  long long kn = (long long)kf;
-  for (int r = 0; r < 8 && edge(kn) < s; r++) kn++;
-  for (int r = 0; r < 8 && edge(kn - 1) >= s; r++) kn--;
-  tab[i] = make_float4((float)edge(kn - 1), (float)edge(kn), (float)edge(kn + 1), __int_as_float((int)kn));
+  long long kn = (long long)kf;                     // edge(kn) <= c < edge(kn + 1), up to rounding:
+  for (int r = 0; r < 8 && edge(kn) > c; r++) kn--;
+  for (int r = 0; r < 8 && edge(kn + 1) <= c; r++) kn++;
+  const double below = c - edge(kn), above = edge(kn + 1) - c;        // >= 0 (inf for an edge outside the range)
+  const bool up = above < below;
+  const long long k1 = up ? kn + 1 : kn;
+  const double others = fmin(up ? below : above, up ? edge(kn + 2) - c : c - edge(kn - 1));
+  const bool ok = (edge(kn) <= c) && (c < edge(kn + 1)) && others >= (0.5 + TAB_SLOP_W) * w + 1.001 * (double)TAB_DMAX;
+  tab[i] = ok ? make_float2((float)edge(k1), __int_as_float((int)k1)) : make_float2(__int_as_float(0x7FC00000), __int_as_float(0));
 }
 
-// bin of q from the axis' table, or TB_AMBIG (no branches: garbage in -- NaN, an index off the table -- comes out
-// as TB_AMBIG through the comparisons)
-__device__ __forceinline__ int tab_bin(const float4 *__restrict__ tab, float q0, float inv_w, int J, float q,
-                                       float delta) {
-  const int j = (int)((q - q0) * inv_w);
-  const float4 e = tab[min((unsigned)max(j, 0), (unsigned)(J - 1))];
-  const int kn = __float_as_int(e.w);
-  const bool above = q > e.x + delta;
-  const bool low = q < e.y - delta;
-  const bool high = (q > e.y + delta) && (q < e.z - delta);
-  return (above && (low || high)) ? (low ? kn - 1 : kn) : TB_AMBIG;
+// bin of q from the axis' table; false = undecided (no branches: garbage in -- NaN, an index off the table -- meets
+// a NaN entry and fails the comparison).  The index is clamped as an unsigned number: a negative one lands on the upper
+// sentinel like one that is too large.
+__device__ __forceinline__ bool tab_bin(const float2 *__restrict__ tab, float inv_w, float c1, int J, float q,
+                                        float delta, uint32_t &k) {
+  const uint32_t j = min((uint32_t)(int)__fmaf_rn(q, inv_w, c1), (uint32_t)(J + 1));
+  const float2 e = *(const float2 *)((const char *)tab + (j << 3));      // 32-bit offset from a uniform base
+  const float t = q - e.x;
+  k = (uint32_t)(__float_as_int(e.y) + (__float_as_int(t) >> 31));       // below the edge: the bin under it
+  return fabsf(t) > delta;
 }
 
 // ---- float32 back-projection estimate ------------------------------------------------------------
@@ -271,8 +295,14 @@ __device__ __forceinline__ int tab_bin(const float4 *__restrict__ tab, float q0,
 struct FastCal {
   float a[3], b[3], c[3], e[3];
   float wsum, esum, pad0, pad1;
+  double rfu, rfv;                       // make_recip() of the view, formed once here instead of by every thread
 };
-static_assert(sizeof(FastCal) == 64, "FastCal");
+static_assert(sizeof(FastCal) == 80, "FastCal");
+__device__ __forceinline__ Recip recip_of(const FastCal &f) {
+  Recip r;
+  r.rfu = f.rfu; r.rfv = f.rfv;
+  return r;
+}
 
 __global__ void k_bp_prep(const ViewCalib *__restrict__ calib, int V, int H, int W, FastCal *__restrict__ out) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +323,8 @@ __global__ void k_bp_prep(const ViewCalib *__restrict__ calib, int V, int H, int
   f.wsum = (float)(wsum * 1.0000002);
   f.esum = (float)(esum * 1.0000002);
   f.pad0 = f.pad1 = 0.0f;
+  const Recip r = make_recip(c);
+  f.rfu = r.rfu; f.rfv = r.rfv;
   out[v] = f;
 }
 
@@ -313,7 +345,7 @@ __device__ __forceinline__ void backproject_f32(const FastCal &fc, int col, int 
 // is taken only when the estimate is farther from every boundary involved (z_max, theta_min, the r range, the bin
 // edges) than a bound on |estimate - fp64 value|, in which case the fp64 path of pixel_bin() decides identically;
 // everything else returns AMBIG and is classified by pixel_bin() (k_bp_bin_amb).  Error budget:
-//   q_t   v_sqrt, v_rcp at 1 ulp, the sum of squares and one product: <= 5.1e-7 relative, i.e. 5.1e-7 absolute
+//   q_t   v_rsq at 1 ulp, the sum of squares and one product: <= 5.1e-7 relative, i.e. 5.1e-7 absolute
 //         (|q_t| <= 1); the coordinate error turns the direction by at most turn = sqrt(3) err / r, which moves the
 //         cosine by at most turn; table entries are rounded to float32 (6e-8).  delta_t = 1.5e-6 + 1.05 turn.
 //   q_p   one sum, v_rcp, one product: <= 2.4e-7 (|q_p| < 1), table rounding 6e-8; the coordinate error moves phi by
@@ -327,7 +359,7 @@ __device__ __forceinline__ void backproject_f32(const FastCal &fc, int col, int 
 // (certainly not binned), AMBIG (tier 2 decides) or the table index, with it / ip the window coordinates of the bin.
 template <int N>
 __device__ __forceinline__ void classify_fast(const FastCal &fc, const dfu3d_bin_geom &g, const FastGeom &fg,
-                                              const float4 *__restrict__ tab, int row, const int (&col)[N],
+                                              const float2 *__restrict__ tab, int row, const int (&col)[N],
                                               const float (&d)[N], uint32_t (&res)[N], int (&it)[N], int (&ip)[N]) {
   float xf[N], yf[N], zf[N], err[N];
   bool dead[N];
@@ -343,39 +375,44 @@ __device__ __forceinline__ void classify_fast(const FastCal &fc, const dfu3d_bin
   if (!any_live) return;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    bool amb = !(zf[k] < fg.z_max - err[k]);
+    // `ok` collects the conditions of a decision with & (no short circuits: the masks are combined on the scalar
+    // unit); a NaN anywhere makes one of them false
+    bool ok = zf[k] < fg.z_max - err[k];
     const float r2 = xf[k] * xf[k] + yf[k] * yf[k] + zf[k] * zf[k];
-    const float rf = __builtin_amdgcn_sqrtf(r2);
-    const bool rok = (rf > 1e-3f) && (rf < 1e15f);
-    // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid
-    const float er = 2.0f * err[k];                                      // |rf - r| <= sqrt(3) err + rounding
-    amb = amb || !rok || !(rf - er > fg.r_lo && rf + er < fg.r_hi);
-    const float ir = __builtin_amdgcn_rcpf(rf);
+    const float ir = __builtin_amdgcn_rsqf(r2);
+    const float rf = r2 * ir;                                            // (NaN for r2 = 0 or inf)
+    // r bin: certain only well inside [rmin_r, rmin_r + vsize_r) and for the 1-cell grid; r_lo >= 1e-3 and
+    // r_hi <= 1e15 (make_fast_geom), so `rin` also says that r is an ordinary number
+    const float er = 2.5f * err[k];                                      // |rf - r| <= sqrt(3) err + rounding (3 ulp of r <= 0.75 err)
+    const bool rin = (rf - er > fg.r_lo) & (rf + er < fg.r_hi);
+    ok = ok & rin;
     const float cz = zf[k] * ir;
-    const float s2 = 1.0f - cz * cz;
-    amb = amb || !(s2 > 1e-4f);                                          // near the poles
+    const float s2 = __fmaf_rn(-cz, cz, 1.0f);
+    ok = ok & (s2 > 1e-4f);                                              // near the poles
     const float turn = err[k] * ir * 1.7320510f;                         // direction error: |(dx,dy,dz)| <= sqrt(3) err
     const float dq = 1.5e-6f + 1.05f * turn;
     const float qt = -cz;
-    const bool th_out = rok && (qt < fg.q_tmin - dq);                    // certainly theta <= theta_min (my_loader.py:175)
-    amb = amb || !(qt > fg.q_tmin + dq);
-    const int kt = tab_bin(tab, fg.tq0, fg.tinv, fg.tJ, qt, dq);
-    amb = amb || !(fabsf(xf[k]) > 8.0f * err[k] + 1e-20f);               // the sign of x decides the branch of atan(y/x)
+    const bool th_out = rin & (qt < fg.q_tmin - dq);                     // certainly theta <= theta_min (my_loader.py:175)
+    ok = ok & (qt > fg.q_tmin + dq);
+    uint32_t kt, kp;
+    ok = ok & tab_bin(tab, fg.tinv, fg.tc1, fg.tJ, qt, dq, kt);
+    ok = ok & (fabsf(xf[k]) > __fmaf_rn(8.0f, err[k], 1e-20f));          // the sign of x decides the branch of atan(y/x)
     const float qa = yf[k] * __builtin_amdgcn_rcpf(fabsf(xf[k]) + fabsf(yf[k]));
     const float qp = xf[k] < 0.0f ? -qa : qa;
-    const int kp = tab_bin(tab + fg.tJ, fg.pq0, fg.pinv, fg.pJ, qp, 1.5e-6f + 1.1f * turn * __builtin_amdgcn_rsqf(s2));   // (s2 > 1e-4 or amb)
-    amb = amb || kt == TB_AMBIG || kp == TB_AMBIG;
-    const int itk = (amb ? g.t_lo : kt) - g.t_lo, ipk = (amb ? g.p_lo : kp) - g.p_lo;   // |kt|, |kp| <= 1e9: no wrap
-    amb = amb || itk < 0 || itk >= g.t_n || ipk < 0 || ipk >= g.p_n;
-    it[k] = itk;
-    ip[k] = ipk;
-    res[k] = (dead[k] || th_out) ? NOBIN : (amb ? AMBIG : (uint32_t)(itk * g.p_n + ipk));
+    const float dp = 1.5e-6f + 1.1f * turn * __builtin_amdgcn_rsqf(s2);  // (s2 > 1e-4 or not ok); dp >= dq
+    ok = ok & tab_bin(tab + fg.tJ + 2, fg.pinv, fg.pc1, fg.pJ, qp, dp, kp);
+    ok = ok & (dp < fg.dmax);
+    const uint32_t itk = kt - (uint32_t)g.t_lo, ipk = kp - (uint32_t)g.p_lo;      // (wraps for a bin below the window)
+    ok = ok & (itk < (uint32_t)g.t_n) & (ipk < (uint32_t)g.p_n);
+    it[k] = (int)itk;                                                    // (meaningful only for a decided, binned pixel)
+    ip[k] = (int)ipk;
+    res[k] = (dead[k] | th_out) ? NOBIN : (ok ? itk * (uint32_t)g.p_n + ipk : AMBIG);
   }
 }
 
 __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Recip &rc, const FastCal &fc,
                                                    const dfu3d_bin_geom &g, const FastGeom &fg,
-                                                   const float4 *__restrict__ tab,
+                                                   const float2 *__restrict__ tab,
                                                    int row, int col, float d, const KeyCol &kc, bool want_key,
                                                    double &key, int &it_out, int &ip_out) {
   const int cols[1] = {col};
@@ -405,16 +442,25 @@ __device__ unsigned long long g_p1_dbg[16];
 #else
 #define P1_T(k) do {} while (0)
 #endif
+#ifndef DFU3D_P1_AMB
+#define DFU3D_P1_AMB 256
+#endif
+constexpr int P1_AMB = DFU3D_P1_AMB;               // undecided pixels a workgroup of k_bp_bin lists in LDS
+#ifndef DFU3D_P1_OCC
+#define DFU3D_P1_OCC 1
+#endif
 constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
                                                    // the window set-up, its flush and the reductions are paid once per 2048 pixels
-__global__ __launch_bounds__(PB) void k_bp_bin(
+__global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
-    const FastCal *__restrict__ fastcal, const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
+    const FastCal *__restrict__ fastcal, const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
     int tiles_x, int tiles_y, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
     int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
   __shared__ uint32_t s_bits[32 * RPT];           // this workgroup's piece of the first-pixel bit map (RPT bit-map tiles)
-  __shared__ uint32_t s_amb[PBLK * RPT];
+  // the workgroup's undecided pixels: a short list (0.7 % of the pixels are undecided: 14 of a tile's 2048; a list for
+  // all 2048 took 8 KB of the workgroup's LDS); what does not fit goes to the global list one pixel at a time
+  __shared__ uint32_t s_amb[P1_AMB];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
   __shared__ int s_namb, s_base, s_t0, s_p0;
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
   const int HW = H * W;
   const ViewCalib c = calib[v];
   const FastCal fc = fastcal[v];
-  const Recip rc = make_recip(c);
+  const Recip rc = recip_of(fc);
   const KeyCol kcol = load_key_col(calib + v, key_axis);
   const Table T = table_view(table, E_total);
   const int64_t tb0 = (int64_t)v * E_view;
@@ -471,7 +517,9 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = res[k];
       if (b == AMBIG) {
-        s_amb[atomicAdd(&s_namb, 1)] = (uint32_t)(base + k);   // block-local list (LDS)
+        const int slot = atomicAdd(&s_namb, 1);                // block-local list (LDS)
+        if (slot < P1_AMB) s_amb[slot] = (uint32_t)(base + k);
+        else amb_list[(size_t)v * HW + atomicAdd(&n_amb[v], 1)] = (uint32_t)(base + k);
       } else if (b != NOBIN) {
         bins[r][k] = b;
         tmin = min(tmin, its[r][k]); pmin = min(pmin, ips[r][k]);
@@ -578,7 +626,7 @@ __global__ __launch_bounds__(PB) void k_bp_bin(
     if (ty * RPT + sub < tiles_y)
       atomicXor(&bitmap_v[((size_t)(ty * RPT + sub) * tiles_x + tx) * 32 + (threadIdx.x & 31)], s_bits[threadIdx.x]);
   }
-  const int na = s_namb;
+  const int na = min(s_namb, P1_AMB);
   P1_T(7);                                        // bit-map flush
   if (na == 0) return;
   if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
@@ -703,22 +751,39 @@ __device__ __forceinline__ VoxCtx make_vox_ctx(const ViewCalib *calib, int v, vo
 
 // voxel k of view v lives in bin b: representative, outputs, table entry left clean (or queued for the repair)
 __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, int v, int k, uint32_t b,
-                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status) {
+                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status, uint32_t f_dbg = 0u) {
   const Table &T = X.T;
   const int64_t e = X.tb0 + b;
   // the three planes of the entry are requested together, and so are the two reads that hang on the representative
   // pixel (its depth and its mask word): four dependent round trips per voxel instead of six
+#ifndef DFU3D_DBG_VOX_SKIP
+#define DFU3D_DBG_VOX_SKIP 0       /* dev builds (wrong results): which accesses of P4 cost what -- 1: no table reads, 2: no reads at the
+                                      representative pixel, 8: no table reset (tools/vox_traffic.sh) */
+#endif
+#if DFU3D_DBG_VOX_SKIP & 1
+  const uint32_t cw = 1u;
+  unsigned long long e_combo = (unsigned long long)f_dbg, e_kmin = 0ull;
+#else
   const uint32_t cw = T.cnt[e];
-  const unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
+  unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
+#endif
   const uint32_t pix = (uint32_t)(e_combo & ((1ull << X.pix_bits) - 1ull));
   const int row = (int)pix / X.W, col = (int)pix - row * X.W;
+#if DFU3D_DBG_VOX_SKIP & 2
+  const float d_pix = 10.0f + (float)(pix & 1023u) * 0.01f;
+  const uint32_t m_bits = pix & 1u;
+#else
   const float d_pix = X.dv[pix];
   const uint32_t m_bits = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
+#endif
   double x, yy, z;
   pixel_to_lidar(X.c, X.rc, col, row, d_pix, x, yy, z);
   double key = (X.key_axis == 2) ? z : yy;
   key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
+#if DFU3D_DBG_VOX_SKIP & 1
+  e_kmin = ordered_key(key);
+#endif
   if (cw > (uint32_t)X.max_points || ordered_key(key) != e_kmin) {
     const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
     if (slot < X.cap_q) { q_bins[(size_t)v * X.cap_q + slot] = b; q_rank[(size_t)v * X.cap_q + slot] = k; }
@@ -734,10 +799,12 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
     out.it_z[at] = z;
   }
   // leave the table clean for the next pass (rep is only ever written by the repair)
+#if !(DFU3D_DBG_VOX_SKIP & 8)
   T.kmin[e] = ~0ull;
   T.combo[e] = ~0ull;
   T.cnt[e] = 0u;
   T.first[e] = NOBIN;
+#endif
 }
 
 // ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
@@ -745,7 +812,7 @@ constexpr int VXB = 256;
 constexpr int VX_PIECES = 64;                 // rows of a workgroup's 64-pixel-wide tile = 4096 pixels
 __global__ __launch_bounds__(VXB) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
-    const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
+    const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
     uint32_t *__restrict__ status) {
@@ -781,9 +848,10 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     s_rank[off++] = rank_q++;
   }
   __syncthreads();
-  const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
-                                key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
   const FastCal fc = fastcal[v];
+  VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
+                          key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
+  X.rc = recip_of(fc);
   const KeyCol kcol = load_key_col(calib + v, key_axis);
   bool rerr = false;
   for (int idx = threadIdx.x; idx < tot; idx += VXB) {
@@ -799,7 +867,7 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     uint32_t b = pixel_bin_fast(X.c, X.rc, fc, g, fg, tab, fr, fcol, X.dv[f], kcol, false, key_f, it_, ip_);
     if (b == AMBIG) b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
+    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status, f);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -988,7 +1056,7 @@ __global__ void k_bp_finalize(int V, int max_voxels, int cap_vox, int *__restric
 // out[0] pixels tried, out[1] undecided by tier 1, out[2] DISAGREEMENTS among the decided (bin, or the key of a kept
 // pixel), out[3] pixels tier 1 kept.  Depths in [d_lo, d_hi), every fourth one 50x closer.
 __global__ void k_selftest_classify(const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
-                                    const float4 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int H, int W,
+                                    const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int H, int W,
                                     int key_axis, long long n, unsigned long long seed, double d_lo, double d_hi,
                                     unsigned long long *out) {
   const ViewCalib c = calib[0];
@@ -1063,11 +1131,11 @@ extern "C" int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W,
   hipStream_t st = (hipStream_t)stream;
   const FastGeom fg = make_fast_geom(*geom);
   FastCal *fastcal = (FastCal *)scratch;
-  float4 *tab = (float4 *)((char *)scratch + 64);
+  float2 *tab = (float2 *)((char *)scratch + 128);
   if (hipMemsetAsync(out4, 0, 32, st) != hipSuccess) return DFU3D_ELAUNCH;
   hipLaunchKernelGGL(k_bp_prep, dim3(1), dim3(64), 0, st, (const ViewCalib *)calib, 1, H, W, fastcal);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 255) / 256), dim3(256), 0, st, *geom, fg, tab);
+  hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 4 + 255) / 256), dim3(256), 0, st, *geom, fg, tab);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_selftest_classify, dim3(2048), dim3(256), 0, st, (const ViewCalib *)calib, fastcal, tab,
                      *geom, fg, H, W, key_axis, (long long)n, (unsigned long long)seed, d_lo, d_hi,
@@ -1125,7 +1193,7 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 // Scratch carve-up.
 // blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], pad[V], bitmap[V*BW] -- everything up to here is
 //   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
-//   calibration constants (64 B per view) and the edge tables of tier 1 (16 B x (TAB_T_MAX + TAB_P_MAX) at most)
+//   calibration constants (80 B per view) and the edge tables of tier 1 (8 B x (TAB_T_MAX + TAB_P_MAX + 4) at most; the carve-up keeps round 2's 16 B)
 //   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
@@ -1148,7 +1216,7 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW;
-  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 16 * (int64_t)V + 16 +
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 20 * (int64_t)V + 16 +
                               4 * (int64_t)(TAB_T_MAX + TAB_P_MAX) + 16;
   return 0;
 }
@@ -1188,8 +1256,8 @@ extern "C" int dfu3d_backproject_bin(
   int *q_cnt = (int *)(wpre + (size_t)V * NJ);
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int *q_rank = (int *)(q_bins + (size_t)V * cap_q);
-  FastCal *fastcal = (FastCal *)(((uintptr_t)(q_rank + (size_t)V * cap_q) + 15) & ~(uintptr_t)15);   // 64 B per view
-  const float4 *tab = (const float4 *)(fastcal + V);                  // edge tables of tier 1: (tJ + pJ) x 16 B
+  FastCal *fastcal = (FastCal *)(((uintptr_t)(q_rank + (size_t)V * cap_q) + 15) & ~(uintptr_t)15);   // 80 B per view
+  const float2 *tab = (const float2 *)(fastcal + V);                  // edge tables of tier 1: (tJ + pJ + 4) x 8 B
   const FastGeom fg = make_fast_geom(*geom);
   int pix_bits = 1;
   while ((1ll << pix_bits) < HW64) pix_bits++;
@@ -1202,7 +1270,7 @@ extern "C" int dfu3d_backproject_bin(
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
     DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 255) / 256), dim3(256), 0, st, *geom, fg, (float4 *)tab);
+    hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 4 + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
                        fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,

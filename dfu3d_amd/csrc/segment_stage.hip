@@ -360,6 +360,8 @@ constexpr int RF_OCC = DFU3D_RF_OCC;   // phase-A workgroups per compute unit th
 #endif
 constexpr int RF_GRID = DFU3D_RF_GRID; // phase-A workgroups at most (2048 fit the chip at once)
 constexpr int RF_WLIST = 128;      // U slots of a range
+constexpr int RF_WIN = 16;         // the pairing looks at this many listed points before / behind a listed point
+constexpr int RF_PLDS = RF_WLIST + 2 * RF_WIN;
 constexpr uint32_t RF_NOSEG = 0xFFFFu;
 constexpr int BOX_FLOATS = 16;     // per range: coherent min xyz, #listed | coherent max xyz, - | incoherent min xyz, - | incoherent max xyz, -
 constexpr int BOX_SHIFT = 9;       // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
@@ -498,6 +500,10 @@ __device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recP[RF_DBG_
 template <bool NB1>
 __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S, RfScratch W) {
+#ifdef DFU3D_RF_FUSED              /* tuning build: the pairing of the listed points at the end of the streaming wave (no k_rf_pair) */
+  __shared__ float4 s_e[RFB / 64][RF_PLDS];
+  __shared__ uint32_t s_p[RFB / 64][RF_WLIST];
+#endif
   long long n_used = n_max;
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
   const int lane = lane_id();
@@ -568,6 +574,10 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
           if (slot < RF_WLIST) {
             my_ent[slot] = make_float4(x, y, z, __uint_as_float(wb));
             my_pos[slot] = (uint32_t)i | (coh ? 0u : RF_INCOH);
+#ifdef DFU3D_RF_FUSED
+            s_e[wave][RF_WIN + slot] = make_float4(x, y, z, __uint_as_float(wb));
+            s_p[wave][slot] = (uint32_t)i | (coh ? 0u : RF_INCOH);
+#endif
           } else {                     // slots full (a pathological range): the segment's overflow list and the queue
             const uint32_t seg = wb >> 16;
             if (!coh) {
@@ -591,6 +601,69 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
       o[0] = make_float4(lx, ly, lz, __int_as_float(min(run, RF_WLIST)));
       o[1] = make_float4(hx, hy, hz, 0.0f);
     }
+#ifdef DFU3D_RF_FUSED
+    {
+      // the listed points of this range against the RF_WIN listed points before / behind them (k_rf_pair's loop,
+      // without the neighbours' ranges), the box around the incoherent ones, flags, queue
+      const int n_own = min(run, RF_WLIST);
+      float4 *rec = (float4 *)(W.rrec + (size_t)rg * BOX_FLOATS);
+      __builtin_amdgcn_wave_barrier();
+      const bool v0 = lane < n_own, v1 = lane + 64 < n_own;
+      const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 q0 = v0 ? s_e[wave][RF_WIN + lane] : none;
+      const uint32_t p0 = v0 ? s_p[wave][lane] : 0u;
+      float4 q1 = none;
+      uint32_t p1 = 0u;
+      if (n_own > 64) {                              // uniform
+        if (v1) { q1 = s_e[wave][RF_WIN + 64 + lane]; p1 = s_p[wave][64 + lane]; }
+      }
+      {
+        const bool i0 = (p0 & RF_INCOH) != 0u, i1 = (p1 & RF_INCOH) != 0u;
+        float ux = min_raw(i0 ? q0.x : BOX_EMPTY, i1 ? q1.x : BOX_EMPTY), uy = min_raw(i0 ? q0.y : BOX_EMPTY, i1 ? q1.y : BOX_EMPTY),
+              uz = min_raw(i0 ? q0.z : BOX_EMPTY, i1 ? q1.z : BOX_EMPTY);
+        float vx = max_raw(i0 ? q0.x : -BOX_EMPTY, i1 ? q1.x : -BOX_EMPTY), vy = max_raw(i0 ? q0.y : -BOX_EMPTY, i1 ? q1.y : -BOX_EMPTY),
+              vz = max_raw(i0 ? q0.z : -BOX_EMPTY, i1 ? q1.z : -BOX_EMPTY);
+        if (n_own > 0) {                             // uniform
+          ux = wave_min63(ux); uy = wave_min63(uy); uz = wave_min63(uz);
+          vx = wave_max63(vx); vy = wave_max63(vy); vz = wave_max63(vz);
+        }
+        if (lane == 63) {
+          rec[2] = make_float4(ux, uy, uz, 0.0f);
+          rec[3] = make_float4(vx, vy, vz, 0.0f);
+        }
+      }
+      const int lo = RF_WIN, hi = RF_WIN + n_own;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (n_own <= h * 64) break;                  // uniform
+        const bool v = h ? v1 : v0;
+        const float4 q = h ? q1 : q0;
+        const uint32_t wa = __float_as_uint(q.w);
+        const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
+        const int ci = RF_WIN + h * 64 + lane;
+        int cnt = 0;
+#pragma unroll 1
+        for (int d0 = -RF_WIN; d0 <= RF_WIN; d0 += 4) {
+          float4 o[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) o[u] = s_e[wave][min(max(ci + d0 + u, 0), RF_PLDS - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int k = ci + d0 + u;
+            const float dx = q.x - o[u].x, dy = q.y - o[u].y, dz = q.z - o[u].z;
+            cnt += ((d0 + u <= RF_WIN) & (k >= lo) & (k < hi) & (__float_as_uint(o[u].w) == wa) & (dx * dx + dy * dy + dz * dz < thr2)) ? 1 : 0;
+          }
+          if (__ballot(v && cnt <= nb) == 0ull) break;
+        }
+        const bool pend = v && cnt <= nb;
+        const uint32_t gpos = (h ? p1 : p0) & ~RF_INCOH;
+        if (v) W.flags[gpos] = pend ? 0 : 1;
+        const unsigned long long mp = __ballot(pend);
+        if (mp) rf_queue_push(W, rg, mp, pend, gpos);
+      }
+      __builtin_amdgcn_wave_barrier();               // the next tile of this wave rewrites the list
+    }
+#endif
 #ifdef DFU3D_DBG_RF_TIMING
     RF_T(2);
     if (lane == 0 && rg < RF_DBG_WG) {
@@ -608,8 +681,6 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
 // steps whatever the number of listed points.  Measured before this: a wave per FOUR ranges with all pairs in LDS
 // (ranges of sparse or noisy lists have a hundred listed points: single waves ran for 60 us, the pass took 72 us);
 // a wave per range, all pairs, partners broadcast with v_readlane (64 us, 43 us with the partners capped).
-constexpr int RF_WIN = 16;
-constexpr int RF_PLDS = RF_WLIST + 2 * RF_WIN;
 __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n_used_ptr, long long n_max, int nb, RfScratch W) {
   __shared__ float4 s_e[4][RF_PLDS];
   long long n_used = n_max;
@@ -921,6 +992,9 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
         while (mu && cnt <= nb) cnt += rf_count_slots(Q, W, mu, n_lo, nl, px, py, pz);
       }
       RF_T(1);
+#ifdef DFU3D_DBG_RF_TIMING
+      rf_rec[3] = (cnt > nb) ? 1u : 0u;              // the ranges next door were enough
+#endif
       int n_inline = 0;
       for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
         const long long rg = r0 + lane;
@@ -1013,6 +1087,7 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
       for (int k = 0; k < 3; k++) o_[k] += rf_rec[k];
       o_[3] += 1; o_[4] += (n <= RF_DIRECT) ? 1 : 0; o_[5] += (unsigned long long)dbg_cand;
       o_[6] += (unsigned long long)((n + 511) / 512); o_[7] += (cnt > nb) ? 1 : 0; o_[8] += (unsigned long long)n;
+      o_[9] += rf_rec[3];
     }
 #endif
   }
@@ -1604,10 +1679,12 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
       hipLaunchKernelGGL(k_rf_stream<false>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
                          nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
+#ifndef DFU3D_RF_FUSED
     const long long g_pair = ((long long)n_ranges + 3) / 4;                     // a wave per range
     hipLaunchKernelGGL(k_rf_pair, dim3((unsigned)(g_pair < 4096 ? g_pair : 4096)), dim3(256), 0, st, (const long long *)n_used,
                        (long long)pool_cap, nb_points, W);
     DFU3D_LAUNCH_CHECK();
+#endif
   }
   if (phases & DFU3D_RF_RESOLVE) {
     hipLaunchKernelGGL(k_rf_resolve, dim3(8192), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,

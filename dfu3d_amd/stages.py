@@ -506,7 +506,7 @@ def nms_bev(boxes, thresh, normal=False):
     return keep, int(num.item())
 
 
-SELFTEST_SCRATCH_BYTES = 64 + 16 * (65536 + 16384) + 64
+SELFTEST_SCRATCH_BYTES = 128 + 16 * (65536 + 16384)
 
 
 def selftest_classify(calib_record, H, W, geom, key_axis, n, seed=1, d_lo=0.5, d_hi=120.0, device="cuda:0"):
@@ -527,11 +527,11 @@ def selftest_classify(calib_record, H, W, geom, key_axis, n, seed=1, d_lo=0.5, d
 def selftest_backproject(calib_record, H, W, n, seed=1, d_lo=0.5, d_hi=120.0, device="cuda:0"):
     """-> max |float32 back-projection - fp64| / bound over n random pixels under one 48-float calibration record."""
     cal = torch.as_tensor(np.asarray(calib_record, np.float32).reshape(CALIB_FLOATS)).to(device).contiguous()
-    scratch = torch.zeros(16, dtype=torch.float32, device=device)
+    scratch = torch.zeros(32, dtype=torch.float32, device=device)
     out = torch.zeros(1, dtype=torch.float64, device=device)
     rc = _lib.lib().dfu3d_selftest_backproject(_chk(cal, "calib", torch.float32, numel=CALIB_FLOATS), int(H), int(W),
                                                int(n), int(seed), float(d_lo), float(d_hi),
-                                               _chk(scratch, "scratch", torch.float32, numel=16),
+                                               _chk(scratch, "scratch", torch.float32, numel=32),
                                                _chk(out, "out", torch.float64, numel=1), _stream())
     _lib.check(rc, "dfu3d_selftest_backproject")
     return float(out.item())

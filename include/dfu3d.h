@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 140          /* 0.1.4: radius-filter scratch sizes (DFU3D_SHADOW_BYTES, DFU3D_RF_QUEUE_INTS) */
+#define DFU3D_VERSION 141          /* 0.1.4: radius-filter scratch sizes (DFU3D_SHADOW_BYTES, DFU3D_RF_QUEUE_INTS) */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -399,14 +399,15 @@ int dfu3d_la_sampling(const float *points, int32_t n_cols, const int64_t *obj_of
  * dfu3d_bin_table_geometry): out4 (device) = { pixels tried, undecided in float32, DISAGREEMENTS among the decided
  * (bin or voxel key), kept by float32 }.  out4[2] must be 0.  scratch: DFU3D_SELFTEST_SCRATCH_BYTES, 16-byte
  * aligned. */
-#define DFU3D_SELFTEST_SCRATCH_BYTES (64 + 16 * (65536 + 16384) + 64)
+#define DFU3D_SELFTEST_SCRATCH_BYTES (128 + 16 * (65536 + 16384))
 int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
                             int32_t key_axis, int64_t n, uint64_t seed, double d_lo, double d_hi,
                             void *scratch, uint64_t *out4, void *stream);
 /* The same classification starts from a float32 back-projection of the pixel (nine FMAs) with a bound on its
  * error.  This entry point measures, over n pseudo-random pixels of an H x W image with depths in [d_lo, d_hi)
  * (every fourth one 50x closer) under the ONE calibration record `calib`, out1[0] = max over pixels and
- * coordinates of |float32 estimate - fp64 back-projection| / bound.  scratch64: 64 bytes of device scratch. */
+ * coordinates of |float32 estimate - fp64 back-projection| / bound.  scratch64: 128 bytes of device scratch
+ * (64 up to version 140), 16-byte aligned. */
 int dfu3d_selftest_backproject(const float *calib, int32_t H, int32_t W, int64_t n, uint64_t seed,
                                double d_lo, double d_hi, void *scratch64, double *out1, void *stream);
 

@@ -61,6 +61,8 @@ for i, nm in enumerate(["records, slots", "box, pairwise, flags, queue"]):
 q = max(int(B[:, 3].sum()), 1)
 print("phase B: %d queries (%d kept, %d of short segments read whole) on %d waves, %.1f ranges, %.2f candidate ranges on average (most %d)"
       % (q, B[:, 7].sum(), B[:, 4].sum(), len(B), B[:, 6].sum() / q, B[:, 5].sum() / q, B[:, 5].max()))
+nd = B[B[:, 4] == 0]
+print("  long segments: %d queries, %d settled by the ranges next door, %d kept in the end" % (len(nd), nd[:, 9].sum(), nd[:, 7].sum()))
 for i, nm in enumerate(["set-up (queue, point, tables)", "whole segment / slots next door", "all ranges, candidates, flag"]):
     print("  %-32s mean %8.0f   median %8.0f   p99 %8.0f   max %8d cycles / wave" % (nm, B[:, i].mean(), np.median(B[:, i]), np.percentile(B[:, i], 99), B[:, i].max()))
 tot = B[:, 0:3].sum(1)
