@@ -482,13 +482,16 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
   if (threadIdx.x < 32 * RPT) s_bits[threadIdx.x] = 0u;
   uint32_t *bitmap_v = bitmap + (size_t)v * BW;
-  // pixel f of THIS workgroup's tile became a bin's first pixel; oldf is what it displaced
-  auto new_first = [&](uint32_t f, uint32_t oldf) {
-    const int fr = (int)f / W, fc = (int)f - fr * W;
-    const int local = (fr - ty * (RPT * TILE_H)) * TILE_W + (fc - tx * TILE_W);
-    atomicOr(&s_bits[local >> 5], 1u << (local & 31));
+  // The window keeps a bin's first pixel as its index INSIDE the workgroup's tile (row-major over the tile's
+  // RPT * TILE_H rows of TILE_W pixels: the same order as the global index for pixels of one tile), which is also the
+  // bit it has in s_bits; pixel `loc` of this tile became a bin's first pixel, oldf (global) is what it displaced
+  auto new_first = [&](uint32_t loc, uint32_t oldf) {
+    atomicOr(&s_bits[loc >> 5], 1u << (loc & 31));
     if (oldf != NOBIN) toggle_first_bit(bitmap_v, W, tiles_x, oldf);
   };
+  const uint32_t pix00 = (uint32_t)(ty * (RPT * TILE_H) * W + tx * TILE_W);        // the tile's first pixel
+  auto global_pix = [&](uint32_t loc) { return pix00 + (loc >> 6) * (uint32_t)W + (loc & 63u); };
+  static_assert(TILE_W == 64, "tile-local pixel index");
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
   P1_T(0);                                        // set-up: records, window reset, barrier
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   int its[RPT][PPT], ips[RPT][PPT];
   bool inside[RPT];
   int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
+  uint32_t amb_mask = 0u;                         // bit r * PPT + k: pixel k of the thread's row r is undecided
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
     const int row = row0 + r * TILE_H;
@@ -504,7 +508,6 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
 #pragma unroll
     for (int k = 0; k < PPT; k++) { bins[r][k] = NOBIN; keys[r][k] = 0.0; its[r][k] = 0; ips[r][k] = 0; }
     if (!inside[r]) continue;
-    const int base = row * W + col;
     const float *dv = depth + (size_t)v * HW;
     float d[PPT];
     load4(dv + (size_t)row * W, col, W, d);          // (columns past the image come back as depth 0: not binned)
@@ -517,15 +520,25 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = res[k];
       if (b == AMBIG) {
-        const int slot = atomicAdd(&s_namb, 1);                // block-local list (LDS)
-        if (slot < P1_AMB) s_amb[slot] = (uint32_t)(base + k);
-        else amb_list[(size_t)v * HW + atomicAdd(&n_amb[v], 1)] = (uint32_t)(base + k);
+        amb_mask |= 1u << (r * PPT + k);
       } else if (b != NOBIN) {
         bins[r][k] = b;
         tmin = min(tmin, its[r][k]); pmin = min(pmin, ips[r][k]);
         keys[r][k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
         keys[r][k] += 0.0;                                    // -0.0 -> +0.0, every other value unchanged
       }
+    }
+  }
+  // the thread's undecided pixels (0.7 % of the pixels): one request for list slots per thread, not one per pixel
+  if (amb_mask) {
+    int slot = atomicAdd(&s_namb, (int)__popc(amb_mask));      // block-local list (LDS)
+    while (amb_mask) {
+      const int bit = __ffs((int)amb_mask) - 1;
+      amb_mask &= amb_mask - 1u;
+      const uint32_t pix = (uint32_t)((row0 + (bit / PPT) * TILE_H) * W + col + (bit % PPT));
+      if (slot < P1_AMB) s_amb[slot] = pix;
+      else amb_list[(size_t)v * HW + atomicAdd(&n_amb[v], 1)] = pix;
+      slot++;
     }
   }
   P1_T(1);                                        // depth loads, classification, exact keys (thread 0's wave)
@@ -540,66 +553,53 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
   P1_T(2);                                        // origin reduction + barrier (= waiting for the slowest wave's classification)
-  // runs of equal bins among a thread's four consecutive pixels are merged first
-  auto commit = [&](uint32_t b, int it, int ip, uint32_t cn, uint32_t f, unsigned long long ok,
-                    unsigned long long cm) {
-    const int lt = it - t0, lp = ip - p0;
-#ifdef DFU3D_DBG_P1_NO_COMMIT         /* timing experiment only: results are wrong */
-    if (lt == 12345) s_cnt[0] = cn;
-    return;
-#endif
-    if (lt < WIN_T && lp < WIN_P) {                             // aggregate in the LDS window
-      const int w = lt * WIN_P + lp;
-      atomicAdd(&s_cnt[w], cn);
-      atomicMin(&s_first[w], f);
-      atomicMin(&s_kmin[w], ok);
-      atomicMin(&s_combo[w], cm);
-    } else {                                                    // outside the window: direct
-      const int64_t e = tb0 + b;
-      atomicAdd(&T.cnt[e], cn);
-      const uint32_t oldf = atomicMin(&T.first[e], f);
-      atomicMin(&T.kmin[e], ok);
-      atomicMin(&T.combo[e], cm);
-      if (oldf > f) new_first(f, oldf);
-    }
-  };
+  // every kept pixel goes to the LDS window on its own.  (Round 2 merged the runs of equal bins among a thread's four
+  // consecutive pixels first: fewer LDS atomics, but the bookkeeping of the runs took more vector instructions than the
+  // atomics it saved -- the kernel is bound by vector issue, not by the LDS.)
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
     if (!inside[r]) continue;
-    const int base = (row0 + r * TILE_H) * W + col;
-    uint32_t rb = NOBIN, rcn = 0u, rfirst = 0u;
-    unsigned long long rk = ~0ull, rcm = ~0ull;
-    int rit = 0, rip = 0;
+    const uint32_t base = (uint32_t)((row0 + r * TILE_H) * W + col);
+    const uint32_t loc0 = (uint32_t)(((threadIdx.x >> 4) + r * TILE_H) * TILE_W + (threadIdx.x & 15) * PPT);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = bins[r][k];
-      if (b != rb) {
-        if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
-        rb = b; rcn = 0u; rk = ~0ull; rcm = ~0ull;
-        rfirst = (uint32_t)(base + k); rit = its[r][k]; rip = ips[r][k];
-      }
-      if (b != NOBIN) {
-        const unsigned long long ok = ordered_key(keys[r][k]);
-        const unsigned long long cm = combo_word(ok, (uint32_t)(base + k), pix_bits);
-        rcn++;
-        rk = ok < rk ? ok : rk;
-        rcm = cm < rcm ? cm : rcm;
+      if (b == NOBIN) continue;
+      const unsigned long long ok = ordered_key(keys[r][k]);
+      const unsigned long long cm = combo_word(ok, base + k, pix_bits);
+      const uint32_t lt = (uint32_t)(its[r][k] - t0), lp = (uint32_t)(ips[r][k] - p0);
+#ifdef DFU3D_DBG_P1_NO_COMMIT         /* timing experiment only: results are wrong */
+      if (lt == 12345u) s_cnt[0] = (uint32_t)cm;
+      continue;
+#endif
+      if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {      // aggregate in the LDS window
+        const uint32_t w = lt * WIN_P + lp;
+        atomicAdd(&s_cnt[w], 1u);
+        atomicMin(&s_first[w], loc0 + k);
+        atomicMin(&s_kmin[w], ok);
+        atomicMin(&s_combo[w], cm);
+      } else {                                                    // outside the window: direct
+        const int64_t e = tb0 + b;
+        atomicAdd(&T.cnt[e], 1u);
+        const uint32_t oldf = atomicMin(&T.first[e], base + k);
+        atomicMin(&T.kmin[e], ok);
+        atomicMin(&T.combo[e], cm);
+        if (oldf > base + k) new_first(loc0 + k, oldf);
       }
     }
-    if (rb != NOBIN) commit(rb, rit, rip, rcn, rfirst, rk, rcm);
   }
-  P1_T(3);                                        // run merging + LDS window atomics
+  P1_T(3);                                        // LDS window atomics
   __syncthreads();
   P1_T(4);                                        // barrier
   // flush the window: one set of global atomics per touched bin.  The atomic on `first` returns the value it replaced
   // (the bit-map update below needs it): all of a thread's atomics are issued before the first returned value is looked
   // at -- one memory round trip per workgroup instead of one per slot of the thread.
   constexpr int FL = (WIN_T * WIN_P + PB - 1) / PB;
-  uint32_t f_new[FL], f_old[FL];
+  uint32_t f_loc[FL], f_new[FL], f_old[FL];
 #pragma unroll
   for (int i = 0; i < FL; i++) {
     const int w = threadIdx.x + i * PB;
-    f_new[i] = NOBIN; f_old[i] = 0u;
+    f_loc[i] = 0u; f_new[i] = NOBIN; f_old[i] = 0u;
     const uint32_t cw = (w < WIN_T * WIN_P) ? s_cnt[w] : 0u;
     if (cw == 0u) continue;
 #ifdef DFU3D_DBG_P1_NO_FLUSH          /* timing experiment only: results are wrong */
@@ -607,7 +607,8 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
 #endif
     const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
     const int64_t e = tb0 + b;
-    f_new[i] = s_first[w];
+    f_loc[i] = s_first[w];
+    f_new[i] = global_pix(f_loc[i]);
     atomicAdd(&T.cnt[e], cw);
     f_old[i] = atomicMin(&T.first[e], f_new[i]);
     atomicMin(&T.kmin[e], s_kmin[w]);
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   }
 #pragma unroll
   for (int i = 0; i < FL; i++)
-    if (f_old[i] > f_new[i]) new_first(f_new[i], f_old[i]);      // (f_new = NOBIN, the largest value, for an idle slot)
+    if (f_old[i] > f_new[i]) new_first(f_loc[i], f_old[i]);      // (f_new = NOBIN, the largest value, for an idle slot)
   P1_T(5);                                        // flush loop (issue of the global atomics)
   __syncthreads();
   P1_T(6);                                        // barrier
