@@ -42,7 +42,7 @@ STAGE_KERNELS = {
     "bp_bin": ["k_bp_bin", "k_bp_prep", "k_bp_tables"], "bp_amb": ["k_bp_bin_amb"], "bp_mark": ["k_bp_scan"],
     "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
                                           "k_bp_finalize"],
-    "segments_build": ["k_seg_count", "k_seg_alloc", "k_seg_write"],
+    "segments_build": ["k_seg_count", "k_seg_scan", "k_seg_alloc", "k_seg_write"],
     "rf_flags": ["k_rf_stream", "k_rf_pair"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"], "rf_compact": ["k_seg_compact_short"],
     "ballquery_fuse": ["k_tile_scan_class", "k_ball_flags", "k_seg_compact"],
     "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],

@@ -34,16 +34,21 @@ __device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
 
 
 // ---------------------------------------------------------------- build
-// A view's items are cut into chunks of SEG_CH; every (view, chunk) is one workgroup in the counting and in the
-// writing pass.  The workgroup walks its chunk in steps of SEG_SUB items, and inside a step every WAVE owns SEG_WI
-// consecutive items: lane j of a wave keeps the wave's count of instance j in a register, so a step costs two
-// barriers per 8192 items.  History: a workgroup per view stepping through 1024 items at a time with two barriers
-// per step was bound by the latency of that chain (0.70 ms for 0.2 GB); a workgroup per 8192 items made 12 000
-// workgroups pay the prologue (item count -> list sizes -> bases -> earlier chunks) and was slower still (1.05 ms).
-constexpr int SEG_WAVES = 8, SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
-constexpr int SEG_SUB = SEG_WAVES * SEG_WI;         // 2048 items per step of a workgroup (4 per lane: 62 VGPRs, four workgroups per CU)
-constexpr int SEG_CH = 16 * SEG_SUB;                // 32768 items per workgroup
+// A view's items are cut into RANGES of SEG_WI = 256 consecutive items, one wave each, in three passes without a barrier
+// or a word of LDS in the two that touch the items:
+//   k_seg_count  wave per range: lane j counts the range's items of instance j (ballots) -> range_cnt[v][range][j]
+//   k_seg_scan   workgroup per (view, side): exclusive prefix over the ranges, in place; the totals are the list lengths
+//   k_seg_alloc  list bases in the pool
+//   k_seg_write  wave per range: list j of the view starts at base + prefix for this wave; ballots give the order inside
+// History: a workgroup per view stepping through 1024 items at a time with two barriers per step was bound by the
+// latency of that chain (0.70 ms for 0.2 GB); a workgroup per 32768 items with lane j keeping the instance's running
+// count across 16 steps of 2048 items (two barriers each) had 1152 workgroups of sixteen dependent steps on the
+// bench workload -- 0.31 ms per launch, the time of that chain and not of the 1 GB it moved (round 2 .. mid round 3).
+constexpr int SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
+constexpr int SEG_WPB = 4;                          // waves (ranges) per workgroup
+constexpr int SEG_GX = 128;                         // workgroups per view at most (each loops over its ranges)
 static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
+inline int seg_ranges(int cap_item) { return (cap_item + SEG_WI - 1) / SEG_WI; }
 
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
 #pragma unroll
@@ -67,39 +72,60 @@ __device__ __forceinline__ int wave_instance_counts(const uint32_t (&b)[SEG_STEP
   return mine;
 }
 
-__global__ __launch_bounds__(SEG_WAVES * 64) void k_seg_count(const uint32_t *__restrict__ bits,
-                                                             const int *__restrict__ n_item,
-                                                             int cap_item, int max_inst,
-                                                             int *__restrict__ cnt, int *__restrict__ chunk_cnt) {
-  __shared__ int s_c[DFU3D_MAX_INST];
-  const int v = blockIdx.y, ch = blockIdx.x;
+__global__ __launch_bounds__(SEG_WPB * 64) void k_seg_count(const uint32_t *__restrict__ bits,
+                                                            const int *__restrict__ n_item, int cap_item, int NR,
+                                                            int *__restrict__ range_cnt) {
+  const int v = blockIdx.y;
   const int lane = lane_id();
-  const int n = min(min(n_item[v], cap_item), (ch + 1) * SEG_CH);
-  int *cc = chunk_cnt + ((size_t)v * gridDim.x + ch) * DFU3D_MAX_INST;
-  if (ch * SEG_CH >= n) {                          // (uniform) nothing in this chunk
-    if (threadIdx.x < DFU3D_MAX_INST) cc[threadIdx.x] = 0;
-    return;
-  }
-  if (threadIdx.x < DFU3D_MAX_INST) s_c[threadIdx.x] = 0;
-  __syncthreads();
-  int mine = 0;
-  for (int sub = ch * SEG_CH; sub < n; sub += SEG_SUB) {            // uniform
-    const int w0 = sub + (int)(threadIdx.x >> 6) * SEG_WI;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n = min(n_item[v], cap_item);
+  const int nr = (n + SEG_WI - 1) / SEG_WI;
+  for (int r = blockIdx.x * SEG_WPB + wave; r < nr; r += gridDim.x * SEG_WPB) {       // uniform per wave
     uint32_t b[SEG_STEPS], wany[SEG_STEPS];
 #pragma unroll
     for (int k = 0; k < SEG_STEPS; k++) {
-      const int t = w0 + k * 64 + lane;
+      const int t = r * SEG_WI + k * 64 + lane;
       b[k] = (t < n) ? bits[(size_t)v * cap_item + t] : 0u;
     }
-    mine += wave_instance_counts(b, wany);
+    const int mine = wave_instance_counts(b, wany);
+    if (lane < DFU3D_MAX_INST) range_cnt[((size_t)v * NR + r) * DFU3D_MAX_INST + lane] = mine;
   }
-  if (lane < DFU3D_MAX_INST && mine) atomicAdd(&s_c[lane], mine);
+}
+
+// blockIdx.y = 0: side a, 1: side b.  Thread (g, j) = (threadIdx.x / 32, threadIdx.x % 32) owns rows [g * per, (g + 1) * per)
+// of column j of the view's nr x 32 matrix of range counts.
+struct SegSide {
+  const int *n_item;
+  int cap_item, NR;
+  int *range_cnt, *cnt;
+};
+__global__ __launch_bounds__(1024) void k_seg_scan(SegSide A, SegSide B, int max_inst) {
+  __shared__ int s_g[32][DFU3D_MAX_INST + 1];
+  const SegSide X = blockIdx.y ? B : A;
+  const int v = blockIdx.x;
+  const int j = threadIdx.x & (DFU3D_MAX_INST - 1), g = threadIdx.x / DFU3D_MAX_INST;
+  const int n = min(X.n_item[v], X.cap_item);
+  const int nr = (n + SEG_WI - 1) / SEG_WI;
+  const int per = (nr + 31) / 32;
+  int *col = X.range_cnt + (size_t)v * X.NR * DFU3D_MAX_INST + j;
+  const int r0 = g * per, r1 = min(r0 + per, nr);
+  int sum = 0;
+  for (int r = r0; r < r1; r++) sum += col[(size_t)r * DFU3D_MAX_INST];
+  s_g[g][j] = sum;
   __syncthreads();
-  if (threadIdx.x < DFU3D_MAX_INST) {
-    const int c = s_c[threadIdx.x];
-    cc[threadIdx.x] = c;
-    if (c && (int)threadIdx.x < max_inst) atomicAdd(&cnt[v * max_inst + threadIdx.x], c);
+  int run = 0, tot = 0;
+#pragma unroll 8
+  for (int q = 0; q < 32; q++) {
+    const int c = s_g[q][j];
+    run += (q < g) ? c : 0;
+    tot += c;
   }
+  for (int r = r0; r < r1; r++) {
+    const int c = col[(size_t)r * DFU3D_MAX_INST];
+    col[(size_t)r * DFU3D_MAX_INST] = run;
+    run += c;
+  }
+  if (g == 0 && j < max_inst) X.cnt[v * max_inst + j] = tot;
 }
 
 // joint view of the 2S lists for the one-pass radius filter: s < S the LiDAR lists, S + s the pseudo lists
@@ -157,62 +183,32 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(int S, int *__restrict__ cnt
   if (threadIdx.x == 0) *cursor = (s_end >= 0) ? s_end : (running < pool_cap ? running : pool_cap);
 }
 
-// One workgroup per (view, chunk) writes its part of the ordered lists of all the view's instances: a list starts
-// where the earlier chunks of the view end (their counts), a wave's part of it where the earlier waves of the step
-// end, and inside the wave ballots give the order.  The bit words stay in registers between the counting and the
-// writing sweep of a step; the coordinates of all SEG_STEPS sub-steps are requested before the first is used.
-#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of thread 0 per phase of k_seg_write, summed over workgroups */
-__device__ unsigned long long g_seg_dbg[16];
-#define SEG_T(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_seg_dbg[k], (unsigned long long)(t_ - sg_t)); sg_t = t_; } } while (0)
-#else
-#define SEG_T(k) do {} while (0)
-#endif
-constexpr int SWT = SEG_WAVES * 64;
-__global__ __launch_bounds__(SWT) void k_seg_write(
+// One wave per range writes its part of the ordered lists of all the view's instances: lane j knows where list j
+// continues for this range (base + the prefix of k_seg_scan), and inside the wave ballots give the order.  The
+// coordinates of all SEG_STEPS sub-steps are requested before the first is used.
+__global__ __launch_bounds__(SEG_WPB * 64) void k_seg_write(
     const uint32_t *__restrict__ bits, const double *__restrict__ ix,
     const double *__restrict__ iy, const double *__restrict__ iz,
-    const int *__restrict__ n_item, int cap_item, int max_inst,
-    const long long *__restrict__ base, const int *__restrict__ cnt, const int *__restrict__ chunk_cnt,
+    const int *__restrict__ n_item, int cap_item, int max_inst, int NR,
+    const long long *__restrict__ base, const int *__restrict__ cnt, const int *__restrict__ range_cnt,
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off) {
-  __shared__ int s_wc[SEG_WAVES][DFU3D_MAX_INST];     // per wave: items of instance j in this step
-  __shared__ int s_run[DFU3D_MAX_INST];               // per instance: items of the earlier chunks
-  const int v = blockIdx.y, ch = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-#ifdef DFU3D_DBG_GRID_TIMING
-  long long sg_t = clock64();
-  if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[8], 1ull);
-#endif
-  // the first-level loads are requested together (one memory round trip instead of a chain)
-  const int n_raw = n_item[v];
+  const int v = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n = min(n_item[v], cap_item);
+  const int nr = (n + SEG_WI - 1) / SEG_WI;
+  if (blockIdx.x * SEG_WPB + wave >= nr) return;
   const bool lj = lane < max_inst;                     // lane j < max_inst: the facts of instance j
   const int cj = lj ? cnt[v * max_inst + lane] : 0;    // (0 also for the lists that did not fit the pool)
-  long long off = lj ? base[v * max_inst + lane] : 0;
+  const long long bj = lj ? base[v * max_inst + lane] : 0;
   const double rj = (lj && pq) ? rad[v * max_inst + lane] : 0.0;
-  const int *cc = chunk_cnt + (size_t)v * gridDim.x * DFU3D_MAX_INST;
-  const int jj = threadIdx.x & (DFU3D_MAX_INST - 1), c_first = threadIdx.x / DFU3D_MAX_INST;
-  int q_first = 0;                                     // chunks 0..31 in one go, the rest (if any) in the loop below
-  if (c_first < ch) q_first = cc[(size_t)c_first * DFU3D_MAX_INST + jj];
-  const int n = min(min(n_raw, cap_item), (ch + 1) * SEG_CH);
-  if (ch * SEG_CH >= n) { SEG_T(0); return; }
   const uint32_t live = (uint32_t)__ballot(cj > 0);   // instances of this view with a non-empty list
   if (live == 0u) return;
-#ifdef DFU3D_DBG_GRID_TIMING
-  if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[9], 1ull);
-#endif
   const uint32_t sw = (lj && pq) ? shadow_word(seg_off + v * max_inst + lane, rj) : 0u;
-  if (threadIdx.x < DFU3D_MAX_INST) s_run[threadIdx.x] = 0;
-  __syncthreads();
-  if (q_first) atomicAdd(&s_run[jj], q_first);
-  for (int c = c_first + SWT / DFU3D_MAX_INST; c < ch; c += SWT / DFU3D_MAX_INST) {
-    const int q = cc[(size_t)c * DFU3D_MAX_INST + jj];
-    if (q) atomicAdd(&s_run[jj], q);
-  }
-  __syncthreads();
-  if (lane < DFU3D_MAX_INST) off += s_run[lane];       // every wave: where the chunk's part of list `lane` starts
-  SEG_T(1);
-  for (int sub = ch * SEG_CH; sub < n; sub += SEG_SUB) {            // uniform
-    const int w0 = sub + wave * SEG_WI;
+  for (int r = blockIdx.x * SEG_WPB + wave; r < nr; r += gridDim.x * SEG_WPB) {       // uniform per wave
+    const int w0 = r * SEG_WI;
+    long long woff = bj + ((lane < DFU3D_MAX_INST) ? range_cnt[((size_t)v * NR + r) * DFU3D_MAX_INST + lane] : 0);
     uint32_t b[SEG_STEPS], wany[SEG_STEPS];
 #pragma unroll
     for (int k = 0; k < SEG_STEPS; k++) {
@@ -226,27 +222,8 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
       x[k] = 0.0; y[k] = 0.0; z[k] = 0.0;
       if (b[k]) { x[k] = ix[o]; y[k] = iy[o]; z[k] = iz[o]; }
     }
-    const int mine = wave_instance_counts(b, wany);
-    SEG_T(2);
-#ifdef DFU3D_DBG_GRID_TIMING
-    if (threadIdx.x == 0) atomicAdd(&g_seg_dbg[10], 1ull);
-#endif
-    if (sub > ch * SEG_CH) __syncthreads();            // the previous step's s_wc has been read by every wave
-    if (lane < DFU3D_MAX_INST) s_wc[wave][lane] = mine;
-    __syncthreads();
-    long long woff = off;                              // lane j: where THIS wave's part of list j starts in this step
-    if (lane < DFU3D_MAX_INST) {
-      int before = 0, total = 0;
 #pragma unroll
-      for (int ww = 0; ww < SEG_WAVES; ww++) {
-        const int c = s_wc[ww][lane];
-        before += (ww < wave) ? c : 0;
-        total += c;
-      }
-      woff += before;
-      off += total;
-    }
-    SEG_T(3);
+    for (int k = 0; k < SEG_STEPS; k++) wany[k] = wave_or_u32(b[k]);
 #pragma unroll
     for (int k = 0; k < SEG_STEPS; k++) {
       for (uint32_t w = wany[k]; w; w &= w - 1u) {     // uniform per wave
@@ -266,20 +243,8 @@ __global__ __launch_bounds__(SWT) void k_seg_write(
         if (lane == j) woff += __popcll(m);
       }
     }
-    SEG_T(4);
   }
 }
-
-#ifdef DFU3D_DBG_GRID_TIMING
-extern "C" int dfu3d_debug_seg_timing(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seg_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
 
 // ---------------------------------------------------------------- tiles
 __global__ __launch_bounds__(1024) void k_tile_scan(int S, const int *__restrict__ cnt,
@@ -1581,7 +1546,7 @@ inline int tile_grid(int64_t pool_cap, int S) {
 
 extern "C" int64_t dfu3d_segments_scratch_words(int32_t V, int32_t a_cap, int32_t b_cap) {
   if (V <= 0 || a_cap <= 0 || b_cap <= 0) return DFU3D_EINVAL;
-  return (int64_t)V * DFU3D_MAX_INST * ((a_cap + SEG_CH - 1) / SEG_CH + (b_cap + SEG_CH - 1) / SEG_CH);
+  return (int64_t)V * DFU3D_MAX_INST * ((int64_t)seg_ranges(a_cap) + seg_ranges(b_cap));
 }
 
 extern "C" int dfu3d_segments_build(
@@ -1604,24 +1569,26 @@ extern "C" int dfu3d_segments_build(
   if (shadow && 2 * (int64_t)S >= (int64_t)RF_NOSEG) return DFU3D_ERANGE;   // 16-bit segment ids in the shadow
   if (shadow && ((uintptr_t)shadow & 15u)) return DFU3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nca = (a_cap + SEG_CH - 1) / SEG_CH, ncb = (b_cap + SEG_CH - 1) / SEG_CH;
-  int32_t *cc_a = chunk_cnt, *cc_b = chunk_cnt + (size_t)V * nca * DFU3D_MAX_INST;
-  if (hipMemsetAsync(cnt_a, 0, sizeof(int32_t) * S, st) != hipSuccess) return DFU3D_ELAUNCH;
-  if (hipMemsetAsync(cnt_b, 0, sizeof(int32_t) * S, st) != hipSuccess) return DFU3D_ELAUNCH;
-  hipLaunchKernelGGL(k_seg_count, dim3(nca, V), dim3(SEG_WAVES * 64), 0, st, a_bits, a_n, a_cap, max_inst, cnt_a, cc_a);
+  const int nra = seg_ranges(a_cap), nrb = seg_ranges(b_cap);
+  int32_t *rc_a = chunk_cnt, *rc_b = chunk_cnt + (size_t)V * nra * DFU3D_MAX_INST;
+  const int gxa = std::min((nra + SEG_WPB - 1) / SEG_WPB, SEG_GX), gxb = std::min((nrb + SEG_WPB - 1) / SEG_WPB, SEG_GX);
+  hipLaunchKernelGGL(k_seg_count, dim3(gxa, V), dim3(SEG_WPB * 64), 0, st, a_bits, a_n, a_cap, nra, rc_a);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_count, dim3(ncb, V), dim3(SEG_WAVES * 64), 0, st, b_bits, b_n, b_cap, max_inst, cnt_b, cc_b);
+  hipLaunchKernelGGL(k_seg_count, dim3(gxb, V), dim3(SEG_WPB * 64), 0, st, b_bits, b_n, b_cap, nrb, rc_b);
+  DFU3D_LAUNCH_CHECK();
+  const SegSide SA = {a_n, a_cap, nra, rc_a, cnt_a}, SB = {b_n, b_cap, nrb, rc_b, cnt_b};
+  hipLaunchKernelGGL(k_seg_scan, dim3(V, 2), dim3(1024), 0, st, SA, SB, max_inst);
   DFU3D_LAUNCH_CHECK();
   const JointSegs J = {(long long *)base_ab, cnt_ab, rad_ab, rad_a, rad_b};
   hipLaunchKernelGGL(k_seg_alloc, dim3(1), dim3(1024), 0, st, S, cnt_a, cnt_b,
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
                      (long long *)pool_cursor, status, J);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(nca, V), dim3(SWT), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
-                     max_inst, (const long long *)base_a, cnt_a, cc_a, px, py, pz, (float4 *)shadow, rad_a, 0);
+  hipLaunchKernelGGL(k_seg_write, dim3(gxa, V), dim3(SEG_WPB * 64), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
+                     max_inst, nra, (const long long *)base_a, cnt_a, rc_a, px, py, pz, (float4 *)shadow, rad_a, 0);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(ncb, V), dim3(SWT), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
-                     max_inst, (const long long *)base_b, cnt_b, cc_b, px, py, pz, (float4 *)shadow, rad_b, S);
+  hipLaunchKernelGGL(k_seg_write, dim3(gxb, V), dim3(SEG_WPB * 64), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
+                     max_inst, nrb, (const long long *)base_b, cnt_b, rc_b, px, py, pz, (float4 *)shadow, rad_b, S);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }

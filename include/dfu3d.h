@@ -204,7 +204,8 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
  *   rad_a / rad_b fp64 (S): the filter radii of the LiDAR / pseudo lists;
  *   shadow: DFU3D_SHADOW_BYTES(pool_cap), the float32 shadow the filter streams (x, y, z, list | radius);
  *   base_ab / cnt_ab / rad_ab (2S each): the joint segment table, s < S = LiDAR lists, S+s = pseudo lists.
- * Scratch: chunk_cnt int32 (dfu3d_segments_scratch_words): member counts per (view, 8192-item chunk, instance). */
+ * Scratch: chunk_cnt int32 (dfu3d_segments_scratch_words): member counts per (view, 256-item range, instance),
+ * turned into their running sums along the view by the call. */
 int64_t dfu3d_segments_scratch_words(int32_t V, int32_t a_cap, int32_t b_cap);
 int dfu3d_segments_build(const uint32_t *a_bits, const double *a_x,
                          const double *a_y, const double *a_z,

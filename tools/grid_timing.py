@@ -21,7 +21,6 @@ out = (ctypes.c_ulonglong * 16)()
 eng.run(batch); torch.cuda.synchronize()
 L.dfu3d_debug_grid_timing(out, 1)
 L.dfu3d_debug_grid_max(out, 1)
-L.dfu3d_debug_seg_timing(out, 1)
 eng.run(batch); torch.cuda.synchronize()
 L.dfu3d_debug_grid_timing(out, 1)
 v = list(out)
@@ -34,8 +33,3 @@ for i, nm in enumerate(names):
     print("%-14s %10.1f cycles/WG   max %9d cycles (n = %d)" % (nm, v[i] / wg, mx[i] >> 24, mx[i] & 0xFFFFFF))
 print("slowest workgroup: %d cycles, n = %d;   largest instance: n = %d, %d cycles"
       % (v[12] >> 24, v[12] & 0xFFFFFF, v[13] >> 32, v[13] & 0xFFFFFFFF))
-L.dfu3d_debug_seg_timing(out, 1)
-g = list(out)
-print("seg_write: workgroups %d, with work %d, steps %d" % (g[8], g[9], g[10]))
-print("  empty-exit cycles/WG %.0f; prologue %.0f cycles/working WG; per step: loads+count %.0f, barrier+prefix %.0f, writes %.0f"
-      % (g[0] / max(g[8] - g[9], 1), g[1] / max(g[9], 1), g[2] / max(g[10], 1), g[3] / max(g[10], 1), g[4] / max(g[10], 1)))
