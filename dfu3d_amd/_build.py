@@ -101,6 +101,9 @@ VARIANTS = {
     # k_bp_vox: which of its accesses cost what (wrong results; tools/vox_traffic.sh)
     "vox_skip1": ["-DDFU3D_DBG_VOX_SKIP=1"], "vox_skip2": ["-DDFU3D_DBG_VOX_SKIP=2"],
     "vox_skip8": ["-DDFU3D_DBG_VOX_SKIP=8"], "vox_skip11": ["-DDFU3D_DBG_VOX_SKIP=11"],
+    # k_bp_vox: two / one workgroup per compute unit instead of three (correct results)
+    "vox_2wg": ["-DDFU3D_VOX_LDS_PAD=40960"], "vox_1wg": ["-DDFU3D_VOX_LDS_PAD=65536"],
+    "vox_occ6": ["-DDFU3D_VOX_OCC=6"], "vox_occ8": ["-DDFU3D_VOX_OCC=8"],
     # k_bp_bin: register budgets for 6 / 8 workgroups per compute unit (the short LDS list of undecided pixels makes room)
     "p1_occ6": ["-DDFU3D_P1_OCC=6"], "p1_occ8": ["-DDFU3D_P1_OCC=8"],
 }

@@ -195,6 +195,8 @@ struct FastGeom {
   float dmax, pad0;                      // deltas at or above this are "undecided" (TAB_DMAX, or 0: no tier 1)
   int tJ, pJ;                            // cells per axis without the sentinels
   double tq0d, twd, pq0d, pwd;           // origins and cell widths in fp64, for the table builder
+  double q_tmin_d;                       // -cos(theta_min) in fp64 (tier 1.5)
+  int mid_ok, pad1;                      // the fp64 edge tables of tier 1.5 fit the scratch
 };
 inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   const double pi = 3.14159265358979323846;
@@ -204,6 +206,7 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   f.r_hi = (g.grid_r == 1) ? __builtin_fminf((float)((g.rmin_r + g.vsize_r) * 0.9998), 1e15f) : 0.0f;
   f.z_max = (float)g.z_max;
   f.q_tmin = g.theta_min <= 0.0 ? -INFINITY : (g.theta_min >= pi ? INFINITY : (float)-__builtin_cos(g.theta_min));
+  f.q_tmin_d = g.theta_min <= 0.0 ? -(double)INFINITY : (g.theta_min >= pi ? (double)INFINITY : -__builtin_cos(g.theta_min));
   auto cells = [](double lo, double hi, double min_width, int cap, double &q0, double &w) {
     if (!(hi > lo) || !(min_width > 0.0)) { q0 = lo; w = 1.0; return 1; }
     double J = __builtin_ceil((hi - lo) / (0.5 * min_width));
@@ -233,16 +236,40 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   // most (1 + |q0|) / w + 1.  A geometry with bins so narrow that this eats the slop gets no tier 1 at all.
   const double slop_t = 1.8e-7 * ((1.0 + __builtin_fabs(f.tq0d)) / f.twd + 1.0), slop_p = 1.8e-7 * ((1.0 + __builtin_fabs(f.pq0d)) / f.pwd + 1.0);
   if (!(__builtin_fmax(slop_t, slop_p) <= TAB_SLOP_W)) f.dmax = 0.0f;
+  // tier 1.5: one fp64 edge per bin boundary of the window behind the float32 tables, if the scratch holds them
+  f.mid_ok = (f.dmax > 0.0f) && ((int64_t)f.tJ + f.pJ + 4 + (int64_t)g.t_n + g.p_n + 2 <= 2 * (int64_t)(TAB_T_MAX + TAB_P_MAX));
+  f.pad1 = 0;
   f.pad0 = 0.0f;
   return f;
 }
 
 // one thread per table entry (tJ + 2 of theta, then pJ + 2 of phi): (E, k) = the edge nearest to the cell's centre and
 // its index, or (NaN, 0)
+__device__ __forceinline__ const double *edge_tab_t(const float2 *tab, const FastGeom &fg) { return (const double *)(tab + fg.tJ + fg.pJ + 4); }
+__device__ __forceinline__ const double *edge_tab_p(const float2 *tab, const FastGeom &fg, const dfu3d_bin_geom &g) {
+  return edge_tab_t(tab, fg) + g.t_n + 1;
+}
+inline int tables_threads(const FastGeom &fg, const dfu3d_bin_geom &g) {
+  return fg.tJ + fg.pJ + 4 + (fg.mid_ok ? g.t_n + g.p_n + 2 : 0);
+}
 __global__ void k_bp_tables(dfu3d_bin_geom g, FastGeom fg, float2 *__restrict__ tab) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= fg.tJ + fg.pJ + 4) return;
   const double pi = 3.14159265358979323846;
+  if (i >= fg.tJ + fg.pJ + 4) {
+    // tier 1.5 (pixel_bin_mid): edge k of the window in the space the fp64 test works in -- -cos(B) for theta,
+    // tan(B) for phi (B = rmin + k * vsize as the reference's floor((angle - rmin) / vsize) implies it)
+    const int e = i - (fg.tJ + fg.pJ + 4);
+    if (!fg.mid_ok || e >= g.t_n + g.p_n + 2) return;
+    double *et = (double *)(tab + fg.tJ + fg.pJ + 4);
+    if (e <= g.t_n) {
+      const double B = g.rmin_t + (double)(g.t_lo + e) * g.vsize_t;
+      et[e] = B <= 0.0 ? -(double)INFINITY : (B >= pi ? (double)INFINITY : -cos(B));
+    } else {
+      const double B = g.rmin_p + (double)(g.p_lo + (e - g.t_n - 1)) * g.vsize_p;
+      et[e] = B <= -pi / 2 ? -(double)INFINITY : (B >= pi / 2 ? (double)INFINITY : tan(B));
+    }
+    return;
+  }
   const bool is_t = i < fg.tJ + 2;
   const int jj = is_t ? i : i - (fg.tJ + 2);
   const int J = is_t ? fg.tJ : fg.pJ;
@@ -427,6 +454,60 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
     key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   }
   return res[0];
+}
+
+// Tier 1.5, for the first pixels of P4 that tier 1 leaves undecided (0.7 %): the reference's own fp64 coordinates, r
+// and z/r, y/x -- everything but acos and atan, which cost ten times the rest and 150 vector registers -- and the
+// comparison moved to the other side of the monotone function: theta >= B <=> -z/r >= -cos(B), phi >= B <=> y/x >=
+// tan(B), against one fp64 edge per bin boundary (k_bp_tables).  Which boundary: the float32 tables of tier 1, looked
+// up with the float32 image of the fp64 q -- the pixel's bin is one of the two that meet at the edge the cell holds
+// (the cell's validity rule with delta = 1e-7 << TAB_DMAX).  What can make the reference's floor((angle - rmin) /
+// vsize) disagree with the comparison in q-space is rounding: of acos / atan (1 ulp), of the subtraction and the
+// division (< 2e-15 rad for |angle - rmin| <= 10), of cos / tan in the table (1-2 ulp), of the quotient (1 ulp):
+// < 1e-14 in all.  A decision is taken only when q is farther than 1e-12 from the edge (1e-12 (1 + t^2) for
+// t = tan(phi): d phi = dt / (1 + t^2)), one hundred times that; the rest (1e-9 of the undecided pixels), NaN /
+// infinite quotients, cells without a decision and bins outside the window are left to pixel_bin().  z_max, the r
+// bin and depth_min are the reference's own comparisons on the reference's own numbers.
+// dfu3d_selftest_classify counts a tier-1.5 decision that differs from pixel_bin() as a disagreement.
+__device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Recip &rc, const dfu3d_bin_geom &g,
+                                                  const FastGeom &fg, const float2 *__restrict__ tab, int W, int pix,
+                                                  float d, bool &decided) {
+  decided = true;
+  if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
+  const int row = pix / W, col = pix - row * W;
+  double x, y, z;
+  pixel_to_lidar(c, rc, col, row, d, x, y, z);
+  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540
+  double s = x * x;                                              // my_loader.py:167
+  s = s + y * y;
+  s = s + z * z;
+  const double r = sqrt(s);
+  const double qt = -(z / r);
+  if (qt < fg.q_tmin_d - 1e-12) return NOBIN;                    // theta <= theta_min for certain (:175)
+  decided = qt > fg.q_tmin_d + 1e-12;                            // (false for NaN)
+  const double cr = floor((r - g.rmin_r) / g.vsize_r);
+  if (decided && !(cr >= 0.0 && cr < (double)g.grid_r)) return NOBIN;
+  // theta
+  const uint32_t jt = min((uint32_t)(int)__fmaf_rn((float)qt, fg.tinv, fg.tc1), (uint32_t)(fg.tJ + 1));
+  const float2 et = tab[jt];
+  const uint32_t i_t = (uint32_t)(__float_as_int(et.y) - g.t_lo);        // edge index inside the window: 0 .. t_n
+  decided = decided && (et.x == et.x) && (i_t <= (uint32_t)g.t_n);
+  const double dt = qt - edge_tab_t(tab, fg)[decided ? i_t : 0u];
+  decided = decided && (fabs(dt) > 1e-12);
+  const uint32_t it = i_t - (dt < 0.0 ? 1u : 0u);
+  // phi
+  const double t = y / x;
+  const float tf = (float)t;
+  const float qpf = tf * __builtin_amdgcn_rcpf(1.0f + fabsf(tf));        // (NaN for an infinite quotient: no decision)
+  const uint32_t jp = min((uint32_t)(int)__fmaf_rn(qpf, fg.pinv, fg.pc1), (uint32_t)(fg.pJ + 1));
+  const float2 ep = tab[fg.tJ + 2 + jp];
+  const uint32_t i_p = (uint32_t)(__float_as_int(ep.y) - g.p_lo);
+  decided = decided && (ep.x == ep.x) && (i_p <= (uint32_t)g.p_n);
+  const double dp = t - edge_tab_p(tab, fg, g)[decided ? i_p : 0u];
+  decided = decided && (fabs(dp) > 1e-12 * fma(t, t, 1.0));
+  const uint32_t ip = i_p - (dp < 0.0 ? 1u : 0u);
+  decided = decided && (it < (uint32_t)g.t_n) && (ip < (uint32_t)g.p_n);  // (a bin below / above the window: pixel_bin reports it)
+  return it * (uint32_t)g.p_n + ip;
 }
 
 // Pass 1 works on 2-D image tiles (TILE_W x TILE_H pixels, one float4 per
@@ -809,16 +890,29 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
 }
 
 // ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
+// The pass is a chain of four dependent memory round trips per voxel (first pixel's depth -> table entry ->
+// representative's depth and mask word -> stores): with fewer workgroups per compute unit it slows down in proportion
+// (measured: 3 / 2 / 1 workgroups per CU: 1.67 / 2.2 / 3.7 ms), so lanes in flight are what it runs on.  The first
+// pixels tier 1 cannot classify go through tier 1.5 (pixel_bin_mid) here; what even that leaves (in practice
+// nothing) is PARKED for k_bp_vox_amb: pixel_bin() inline cost 150 vector registers, i.e. three waves per SIMD.  A
+// voxel of the workgroup's list is one packed word (local row | local column | place in its row piece): 16 KB of LDS.
 constexpr int VXB = 256;
 constexpr int VX_PIECES = 64;                 // rows of a workgroup's 64-pixel-wide tile = 4096 pixels
-__global__ __launch_bounds__(VXB) void k_bp_vox(
+struct VoxPark {
+  int *n;                                     // per view: parked voxels
+  uint32_t *f, *k;                            // per view, HW slots each: first pixel, rank
+};
+#ifndef DFU3D_VOX_OCC
+#define DFU3D_VOX_OCC 1            /* waves per SIMD the register budget of P4 is cut for (1: whatever the code needs) */
+#endif
+__global__ __launch_bounds__(VXB, DFU3D_VOX_OCC) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
     const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
-    uint32_t *__restrict__ status) {
-  __shared__ uint32_t s_pix[VX_PIECES * 64];
-  __shared__ int s_rank[VX_PIECES * 64];
+    uint32_t *__restrict__ status, VoxPark park) {
+  __shared__ uint32_t s_vox[VX_PIECES * 64];
+  __shared__ int s_wp[VX_PIECES];             // rank of the first voxel of each of the tile's row pieces
   __shared__ int s_w[VXB / 64];
   const int v = blockIdx.y;
   // A workgroup takes a 64-pixel-wide, VX_PIECES-row-high tile of the image, not a run of VX_PIECES row pieces of one
@@ -830,14 +924,15 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   const int tx = blockIdx.x % R.tiles_x, ty = blockIdx.x / R.tiles_x;
   const int H = R.NJ / R.tiles_x;
   // every thread takes a quarter (16 pixels) of a row piece
-  const int y = ty * VX_PIECES + (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
+  const int lrow = (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
+  const int y = ty * VX_PIECES + lrow;
   uint32_t m16 = 0u;
-  int x0 = tx * 64 + quarter * 16, rank_q = 0;
+  uint32_t ord = 0u;
   if (y < H) {
     const unsigned long long word = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
     m16 = (uint32_t)(word >> (16 * quarter)) & 0xFFFFu;
-    if (m16) rank_q = (int)R.wpre[(size_t)v * R.NJ + (size_t)y * R.tiles_x + tx] +
-                      __popcll(word & ((1ull << (16 * quarter)) - 1ull));
+    ord = (uint32_t)__popcll(word & ((1ull << (16 * quarter)) - 1ull));
+    if (quarter == 0) s_wp[lrow] = word ? (int)R.wpre[(size_t)v * R.NJ + (size_t)y * R.tiles_x + tx] : 0;
   }
   int tot;
   int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);
@@ -845,8 +940,7 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   while (m16) {
     const int bpos = __ffs((int)m16) - 1;
     m16 &= m16 - 1u;
-    s_pix[off] = (uint32_t)(y * W + x0 + bpos);
-    s_rank[off++] = rank_q++;
+    s_vox[off++] = ((uint32_t)lrow << 12) | ((uint32_t)(quarter * 16 + bpos) << 6) | ord++;
   }
   __syncthreads();
   const FastCal fc = fastcal[v];
@@ -854,19 +948,50 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
                           key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
   X.rc = recip_of(fc);
   const KeyCol kcol = load_key_col(calib + v, key_axis);
-  bool rerr = false;
   for (int idx = threadIdx.x; idx < tot; idx += VXB) {
-    const int k = s_rank[idx];
+    const uint32_t e = s_vox[idx];
+    const int k = s_wp[e >> 12] + (int)(e & 63u);
     if (k >= cap_vox) continue;                    // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
-    const uint32_t f = s_pix[idx];
-    // the bin of the first pixel: the same two-tier classification as in P1.  (Parking the undecided voxels for a
-    // second kernel doubled the occupancy of this one and made the pass slower: it runs at the memory system's
-    // rate for its scattered sector reads -- 4.3 TB/s of fetch + write traffic -- not at a latency limit.)
+    const int fr = ty * VX_PIECES + (int)(e >> 12), fcol = tx * 64 + (int)((e >> 6) & 63u);
+    const uint32_t f = (uint32_t)(fr * W + fcol);
+    // the bin of the first pixel: tier 1 of the classification of P1, then tier 1.5
     double key_f;
     int it_, ip_;
-    const int fr = (int)f / W, fcol = (int)f - fr * W;
-    uint32_t b = pixel_bin_fast(X.c, X.rc, fc, g, fg, tab, fr, fcol, X.dv[f], kcol, false, key_f, it_, ip_);
-    if (b == AMBIG) b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
+    const float d_f = X.dv[f];
+    uint32_t b = pixel_bin_fast(X.c, X.rc, fc, g, fg, tab, fr, fcol, d_f, kcol, false, key_f, it_, ip_);
+    if (b == AMBIG) {                              // (0.7 % of the voxels)
+      bool decided = false;
+      if (fg.mid_ok) b = pixel_bin_mid(X.c, X.rc, g, fg, tab, W, (int)f, d_f, decided);
+      if (!decided) {                              // -> k_bp_vox_amb
+        const int slot = atomicAdd(&park.n[v], 1);
+        park.f[(size_t)v * HW + slot] = f;
+        park.k[(size_t)v * HW + slot] = (uint32_t)k;
+        continue;
+      }
+    }
+    if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
+    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status, f);
+  }
+}
+
+// the voxels k_bp_vox parked: bin of the first pixel by the full fp64 classification
+__global__ __launch_bounds__(256) void k_bp_vox_amb(
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g,
+    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
+    int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, VoxOut out, int key_axis,
+    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
+    uint32_t *__restrict__ status, VoxPark park) {
+  const int v = blockIdx.y;
+  const int n = park.n[v];
+  if ((int)(blockIdx.x * 256) >= n) return;
+  const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
+                                key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
+  bool rerr = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t f = park.f[(size_t)v * HW + i];
+    const int k = (int)park.k[(size_t)v * HW + i];
+    double key_f;
+    const uint32_t b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
     vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status, f);
   }
@@ -1079,7 +1204,15 @@ __global__ void k_selftest_classify(const ViewCalib *__restrict__ calib, const F
     const uint32_t b1 = pixel_bin_fast(c, rc, fc, g, fg, tab, row, col, d, kcol, true, k1, it_, ip_);
     const uint32_t b2 = pixel_bin(c, rc, g, W, row * W + col, d, key_axis, k2, rerr);
     tried++;
-    if (b1 == AMBIG) { undecided++; continue; }
+    if (b1 == AMBIG) {                              // tier 1.5 takes it in P4: a decision of its own must be pixel_bin's
+      undecided++;
+      if (fg.mid_ok) {
+        bool dec = false;
+        const uint32_t b3 = pixel_bin_mid(c, rc, g, fg, tab, W, row * W + col, d, dec);
+        if (dec && b3 != b2) wrong++;
+      }
+      continue;
+    }
     if (b1 != b2 || (b1 != NOBIN && __double_as_longlong(k1) != __double_as_longlong(k2))) wrong++;
     if (b1 != NOBIN) kept++;
   }
@@ -1136,7 +1269,7 @@ extern "C" int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W,
   if (hipMemsetAsync(out4, 0, 32, st) != hipSuccess) return DFU3D_ELAUNCH;
   hipLaunchKernelGGL(k_bp_prep, dim3(1), dim3(64), 0, st, (const ViewCalib *)calib, 1, H, W, fastcal);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 4 + 255) / 256), dim3(256), 0, st, *geom, fg, tab);
+  hipLaunchKernelGGL(k_bp_tables, dim3((tables_threads(fg, *geom) + 255) / 256), dim3(256), 0, st, *geom, fg, tab);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_selftest_classify, dim3(2048), dim3(256), 0, st, (const ViewCalib *)calib, fastcal, tab,
                      *geom, fg, H, W, key_axis, (long long)n, (unsigned long long)seed, d_lo, d_hi,
@@ -1192,7 +1325,7 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 }
 
 // Scratch carve-up.
-// blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], pad[V], bitmap[V*BW] -- everything up to here is
+// blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], n_park[V], bitmap[V*BW] -- everything up to here is
 //   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
 //   calibration constants (80 B per view) and the edge tables of tier 1 (8 B x (TAB_T_MAX + TAB_P_MAX + 4) at most; the carve-up keeps round 2's 16 B)
 //   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
@@ -1266,12 +1399,15 @@ extern "C" int dfu3d_backproject_bin(
   const ViewCalib *cal = (const ViewCalib *)calib;
   const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
   const RankMap R = {bitmap, wpre, BW, NJ, tiles_x, W};
+  // voxels parked by k_bp_vox: the counter is the fourth per-view word of the header, the lists sit where the bin ids
+  // and pixel lists of the repair go (written after P4, read before it only by k_bp_bin_amb: free in between)
+  const VoxPark park = {q_cursor + V, pix_bin, q_list};
 
   if (phases & DFU3D_BP_BIN) {
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
     DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bp_tables, dim3((fg.tJ + fg.pJ + 4 + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);
+    hipLaunchKernelGGL(k_bp_tables, dim3((tables_threads(fg, *geom) + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
                        fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
@@ -1288,9 +1424,16 @@ extern "C" int dfu3d_backproject_bin(
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
+#ifndef DFU3D_VOX_LDS_PAD
+#define DFU3D_VOX_LDS_PAD 0        /* tuning builds: unused dynamic LDS, i.e. fewer workgroups of P4 per compute unit */
+#endif
+    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), DFU3D_VOX_LDS_PAD, st, depth, cal, fastcal, tab, *geom,
                        fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
-                       cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status);
+                       cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status, park);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_vox_amb, dim3(4, V), dim3(256), 0, st, depth, cal, *geom, masks, mask_format, n_inst, max_inst,
+                       W, HW, E_view, table, E_total, cap_vox, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status,
+                       park);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {

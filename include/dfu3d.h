@@ -398,7 +398,9 @@ int dfu3d_la_sampling(const float *points, int32_t n_cols, const int64_t *obj_of
  * classifications over n pseudo-random pixels of an H x W image with depths in [d_lo, d_hi) (every fourth one
  * 50x closer) under the ONE calibration record `calib` and the bin geometry `geom` (host pointer, after
  * dfu3d_bin_table_geometry): out4 (device) = { pixels tried, undecided in float32, DISAGREEMENTS among the decided
- * (bin or voxel key), kept by float32 }.  out4[2] must be 0.  scratch: DFU3D_SELFTEST_SCRATCH_BYTES, 16-byte
+ * (bin or voxel key), kept by float32 }.  The pixels float32 leaves undecided also go through the middle tier the
+ * voxel pass uses for them (fp64 coordinates against fp64 bin edges in cos / tan space, no acos / atan); a decision
+ * of that tier that differs from the full fp64 classification counts as a disagreement too.  out4[2] must be 0.  scratch: DFU3D_SELFTEST_SCRATCH_BYTES, 16-byte
  * aligned. */
 #define DFU3D_SELFTEST_SCRATCH_BYTES (128 + 16 * (65536 + 16384))
 int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
