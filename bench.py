@@ -296,10 +296,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--chunk-frames", type=int, default=16, help="frames per kernel-launch chunk (0 = all frames of the step)")
-    ap.add_argument("--lanes", type=int, default=4,
-                    help="concurrent HIP streams, one chunk each.  Default: 4 streams x 16-frame chunks, the engine's throughput "
-                         "configuration (stages of different chunks overlap: +18 %% over one stream).  The kernel table and the "
+    ap.add_argument("--chunk-frames", type=int, default=32, help="frames per kernel-launch chunk (0 = all frames of the step)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="concurrent HIP streams, one chunk each.  Default: 2 streams x 32-frame chunks, the engine's throughput "
+                         "configuration (stages of different chunks overlap; measured in round 3 against 4 x 16, 1 x 64, 4 x 32, "
+                         "2 x 16, 4 x 8: 2 x 32 is 1-3 %% ahead of 4 x 16 and 6 %% ahead of one stream).  The kernel table and the "
                          "roofline block never come from these contended launches: they are timed in extra single-stream "
                          "passes after the timed region (see --single-stream)")
     ap.add_argument("--single-stream", action="store_true",

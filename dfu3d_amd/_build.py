@@ -91,6 +91,7 @@ VARIANTS = {
     # radius filter, tuning builds (correct results): the pairing of listed points inside k_rf_stream instead of k_rf_pair,
     # list neighbours lane^1 / lane^2 or across the whole wave, grids, occupancy of phase B, ranges in flight
     "rf_fused": ["-DDFU3D_RF_FUSED"],
+    "rf_forward": ["-DDFU3D_RF_REVERSE=0"],
     "rf_quad": ["-DDFU3D_RF_NBR=0"],
     "rf_wave": ["-DDFU3D_RF_NBR=2"],
     "rf_g2048": ["-DDFU3D_RF_GRID=2048"],

@@ -1207,6 +1207,18 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
 // FIT_TAU * (largest mag) of the best one -- one heading unless the point set has an exact or nearly exact symmetry.
 // A heading outside that band cannot be the reference's arg-max, and inside it the reference's formula decides.
 constexpr double FIT_TAU = 1e-8;
+// v_min_f64 / v_max_f64 as they are: fmin() / fmax() on a loop-carried value make the compiler canonicalise it first
+// (v_max_f64 x, x, x per use -- a quarter of the first sweep's instructions); no signalling NaN can reach these loops
+__device__ __forceinline__ double min_raw_d(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_raw_d(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 struct FitAcc {                                   // tier 1, second sweep
   double s1, s2, q1, q2;
   int n1, n2;
@@ -1216,7 +1228,10 @@ struct FitAcc {                                   // tier 1, second sweep
     const double c2 = x * (-st) + y * ct;
     const double d1 = fmin(fabs(a1 - c1), fabs(c1 - a0));
     const double d2 = fmin(fabs(b1 - c2), fabs(c2 - b0));
-    if (d1 < d2) { s1 += d1; q1 += d1 * d1; n1++; } else { s2 += d2; q2 += d2 * d2; n2++; }
+    // the squares are summed with an FMA: the SPLIT is the reference's to the bit, the summation of the variance is
+    // tier 1's own (the band covers it).  (An fp64 comparison issues at the rate of an addition -- tools/micro/
+    // cmp_rates.hip -- so the sign of d1 - d2 instead of the comparison only added an instruction.)
+    if (d1 < d2) { s1 += d1; q1 = fma(d1, d1, q1); n1++; } else { s2 += d2; q2 = fma(d2, d2, q2); n2++; }
   }
   __device__ __forceinline__ void wave_reduce() {
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
@@ -1328,8 +1343,8 @@ __global__ __launch_bounds__(256) void k_fit_tiny(
         const double xj = readlane_f64(x, j), yj = readlane_f64(y, j);
         const double c1 = xj * ct + yj * st;
         const double c2 = xj * (-st) + yj * ct;
-        a0 = fmin(a0, c1); a1 = fmax(a1, c1);
-        b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+        a0 = min_raw_d(a0, c1); a1 = max_raw_d(a1, c1);
+        b0 = min_raw_d(b0, c2); b1 = max_raw_d(b1, c2);
       }
       FitAcc A;
       A.clear();
@@ -1471,12 +1486,12 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
         const double x = mx[i], y = my[i];
         double c1 = x * ct0 + y * st0;
         double c2 = x * (-st0) + y * ct0;
-        a0 = fmin(a0, c1); a1 = fmax(a1, c1);
-        b0 = fmin(b0, c2); b1 = fmax(b1, c2);
+        a0 = min_raw_d(a0, c1); a1 = max_raw_d(a1, c1);
+        b0 = min_raw_d(b0, c2); b1 = max_raw_d(b1, c2);
         c1 = x * ct1 + y * st1;
         c2 = x * (-st1) + y * ct1;
-        e0 = fmin(e0, c1); e1 = fmax(e1, c1);
-        f0 = fmin(f0, c2); f1 = fmax(f1, c2);
+        e0 = min_raw_d(e0, c1); e1 = max_raw_d(e1, c1);
+        f0 = min_raw_d(f0, c2); f1 = max_raw_d(f1, c2);
       }
       a0 = wave_min_d(a0); a1 = wave_max_d(a1); b0 = wave_min_d(b0); b1 = wave_max_d(b1);
       e0 = wave_min_d(e0); e1 = wave_max_d(e1); f0 = wave_min_d(f0); f1 = wave_max_d(f1);
@@ -1601,8 +1616,8 @@ __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restric
         for (int h = 0; h < BIGC_HPW; h++) {
           const double c1 = x * ct[h] + y * st[h];
           const double c2 = x * nst[h] + y * ct[h];
-          a0[h] = fmin(a0[h], c1); a1[h] = fmax(a1[h], c1);
-          b0[h] = fmin(b0[h], c2); b1[h] = fmax(b1[h], c2);
+          a0[h] = min_raw_d(a0[h], c1); a1[h] = max_raw_d(a1[h], c1);
+          b0[h] = min_raw_d(b0[h], c2); b1[h] = max_raw_d(b1[h], c2);
         }
       }
     }

@@ -473,10 +473,18 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the wave's addresses are SGPR base + lane)
-  // the grid is capped (a pool is sized for the worst case); a workgroup walks its tiles
-  for (long long wg0 = (long long)blockIdx.x * RF_WG; wg0 < n_used; wg0 += (long long)gridDim.x * RF_WG) {
+  // the grid is capped (a pool is sized for the worst case); a workgroup walks its tiles -- from the END of the pool
+  // (DFU3D_RF_REVERSE, default): k_seg_write has just written the shadow front to back, so the memory-side cache
+  // holds its tail; a walk from the front misses, and what it brings in pushes out exactly the lines it would have
+  // hit next (44 -> 52 us when the writer became a sequential pass); from the end the most recent lines are read first
+#ifndef DFU3D_RF_REVERSE
+#define DFU3D_RF_REVERSE 1
+#endif
+  const long long n_tiles = (n_used + RF_WG - 1) / RF_WG;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long wg0 = (DFU3D_RF_REVERSE ? n_tiles - 1 - tile : tile) * RF_WG;
     const long long w0 = wg0 + (long long)wave * (64 * RF_IT);
-    if (w0 >= n_used) break;
+    if (w0 >= n_used) continue;
 #ifdef DFU3D_DBG_RF_TIMING
     unsigned int rf_rec[5] = {0};
     long long rf_t = clock64();

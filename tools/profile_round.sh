@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf /tmp/pp /tmp/pf /tmp/pw
-# (1) the default command (4 streams x 16-frame chunks in the timed region): launches overlap, durations are contended
+# (1) the default command (2 streams x 32-frame chunks in the timed region): launches overlap, durations are contended
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o ks -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/gpurun_out/${R}_bench_under_rocprof.json 2> $ROOT/gpurun_out/${R}_bench_under_rocprof.err
 # (2) one stream, one chunk: the durations the kernel table / roofline block of bench.py report
 rm -rf /tmp/ps
