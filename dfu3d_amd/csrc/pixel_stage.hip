@@ -469,9 +469,10 @@ __device__ __forceinline__ uint32_t pixel_bin_fast(const ViewCalib &c, const Rec
 // infinite quotients, cells without a decision and bins outside the window are left to pixel_bin().  z_max, the r
 // bin and depth_min are the reference's own comparisons on the reference's own numbers.
 // dfu3d_selftest_classify counts a tier-1.5 decision that differs from pixel_bin() as a disagreement.
+struct MidOut { uint32_t it, ip; double y, z; };    // window coordinates of the bin, the two coordinates a key can be
 __device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Recip &rc, const dfu3d_bin_geom &g,
                                                   const FastGeom &fg, const float2 *__restrict__ tab, int W, int pix,
-                                                  float d, bool &decided) {
+                                                  float d, bool &decided, MidOut *mo = nullptr) {
   decided = true;
   if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
   const int row = pix / W, col = pix - row * W;
@@ -507,6 +508,7 @@ __device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Reci
   decided = decided && (fabs(dp) > 1e-12 * fma(t, t, 1.0));
   const uint32_t ip = i_p - (dp < 0.0 ? 1u : 0u);
   decided = decided && (it < (uint32_t)g.t_n) && (ip < (uint32_t)g.p_n);  // (a bin below / above the window: pixel_bin reports it)
+  if (mo) { mo->it = it; mo->ip = ip; mo->y = y; mo->z = z; }
   return it * (uint32_t)g.p_n + ip;
 }
 
@@ -528,7 +530,7 @@ __device__ unsigned long long g_p1_dbg[16];
 #endif
 constexpr int P1_AMB = DFU3D_P1_AMB;               // undecided pixels a workgroup of k_bp_bin lists in LDS
 #ifndef DFU3D_P1_OCC
-#define DFU3D_P1_OCC 1
+#define DFU3D_P1_OCC 5
 #endif
 constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
                                                    // the window set-up, its flush and the reductions are paid once per 2048 pixels
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   __shared__ uint32_t s_amb[P1_AMB];
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
-  __shared__ int s_namb, s_base, s_t0, s_p0;
+  __shared__ int s_namb, s_t0, s_p0;
 #ifdef DFU3D_DBG_GRID_TIMING
   long long p1_t = clock64();
   if (threadIdx.x == 0) atomicAdd(&g_p1_dbg[8], 1ull);
@@ -669,6 +671,45 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       }
     }
   }
+  // The tile's undecided pixels (14 of 2048 on average, listed in s_amb before the origin's barrier): the middle tier
+  // decides nearly all of them (2 139 of 3.9 M are left on the bench workload), and a decided pixel joins the window
+  // like any other.  As pixels of k_bp_bin_amb they cost five scattered global atomics each (20 M per launch: 0.43 ms);
+  // here they cost this kernel 0.23 ms (one wave per workgroup works while three wait at the barrier below; doing it
+  // at the very end of the workgroup with direct commits instead measured 0.34 ms).  What is left stays listed.
+  {
+    const int na_l = min(s_namb, P1_AMB);
+    for (int i = threadIdx.x; i < na_l; i += PB) {
+      const uint32_t pix = s_amb[i];
+      bool decided = false;
+      MidOut mo;
+      uint32_t b = NOBIN;
+      if (fg.mid_ok) b = pixel_bin_mid(c, rc, g, fg, tab, W, (int)pix, depth[(size_t)v * HW + pix], decided, &mo);
+      if (!decided) continue;
+      s_amb[i] = NOBIN;                                           // done
+      if (b == NOBIN) continue;                                   // certainly not binned
+      double key = (key_axis == 2) ? mo.z : mo.y;
+      key += 0.0;                                                 // -0.0 -> +0.0, every other value unchanged
+      const unsigned long long ok = ordered_key(key);
+      const unsigned long long cm = combo_word(ok, pix, pix_bits);
+      const int prow = (int)pix / W, pcol = (int)pix - prow * W;
+      const uint32_t loc = (uint32_t)((prow - ty * (RPT * TILE_H)) * TILE_W + (pcol - tx * TILE_W));
+      const uint32_t lt = mo.it - (uint32_t)t0, lp = mo.ip - (uint32_t)p0;
+      if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {
+        const uint32_t w = lt * WIN_P + lp;
+        atomicAdd(&s_cnt[w], 1u);
+        atomicMin(&s_first[w], loc);
+        atomicMin(&s_kmin[w], ok);
+        atomicMin(&s_combo[w], cm);
+      } else {
+        const int64_t e = tb0 + b;
+        atomicAdd(&T.cnt[e], 1u);
+        const uint32_t oldf = atomicMin(&T.first[e], pix);
+        atomicMin(&T.kmin[e], ok);
+        atomicMin(&T.combo[e], cm);
+        if (oldf > pix) new_first(loc, oldf);
+      }
+    }
+  }
   P1_T(3);                                        // LDS window atomics
   __syncthreads();
   P1_T(4);                                        // barrier
@@ -710,10 +751,8 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   }
   const int na = min(s_namb, P1_AMB);
   P1_T(7);                                        // bit-map flush
-  if (na == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&n_amb[v], na);        // one global atomic per block
-  __syncthreads();
-  for (int i = threadIdx.x; i < na; i += PB) amb_list[(size_t)v * HW + s_base + i] = s_amb[i];
+  for (int i = threadIdx.x; i < na; i += PB)      // (what the middle tier left: in practice nothing)
+    if (s_amb[i] != NOBIN) amb_list[(size_t)v * HW + atomicAdd(&n_amb[v], 1)] = s_amb[i];
 }
 
 #ifdef DFU3D_DBG_GRID_TIMING
