@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 141          /* 0.1.4: radius-filter scratch sizes (DFU3D_SHADOW_BYTES, DFU3D_RF_QUEUE_INTS) */
+#define DFU3D_VERSION 141          /* 0.1.4.1: 128-byte scratch of dfu3d_selftest_backproject; 140 = 0.1.4: radius-filter scratch sizes */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
