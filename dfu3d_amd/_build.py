@@ -92,6 +92,8 @@ VARIANTS = {
     # list neighbours lane^1 / lane^2 or across the whole wave, grids, occupancy of phase B, ranges in flight
     "rf_fused": ["-DDFU3D_RF_FUSED"],
     "rf_forward": ["-DDFU3D_RF_REVERSE=0"],
+    # ball query: two / four consecutive query tiles per workgroup (one table build for them when they share the instance)
+    "ball_tpw2": ["-DDFU3D_BALL_TPW=2"], "ball_tpw4": ["-DDFU3D_BALL_TPW=4"],
     "rf_quad": ["-DDFU3D_RF_NBR=0"],
     "rf_wave": ["-DDFU3D_RF_NBR=2"],
     "rf_g2048": ["-DDFU3D_RF_GRID=2048"],

@@ -1251,10 +1251,13 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
   __shared__ unsigned long long s_node[BH_MAX];
   __shared__ uint32_t s_head[BH_HEADS];
   __shared__ int s_pending;
+#ifndef DFU3D_BALL_TPW
+#define DFU3D_BALL_TPW 1           /* consecutive query tiles per workgroup (tuning builds: 2, 4) */
+#endif
   const int ntile = tile_off[S];
-  int t = blockIdx.x;
+  int t = blockIdx.x * DFU3D_BALL_TPW;
   if (t >= ntile) return;
-  const int t_end = t + 1;
+  const int t_end = min(t + DFU3D_BALL_TPW, ntile);
   int s = find_segment(tile_off, S, t);
   const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
   const double Cq = C * (1.0 + 1e-6);
@@ -1734,12 +1737,12 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, BH_MAX_SMALL, 0x7FFFFFFF, tile_big, BT_BIG);
   DFU3D_LAUNCH_CHECK();
-  const int g_small = (int)((pool_cap + BT_SMALL - 1) / BT_SMALL + S);
+  const int g_small = (int)(((pool_cap + BT_SMALL - 1) / BT_SMALL + S + DFU3D_BALL_TPW - 1) / DFU3D_BALL_TPW);
   hipLaunchKernelGGL((k_ball_flags<BT_SMALL, BH_MAX_SMALL, BH_HEADS_SMALL>), dim3(g_small), dim3(BT_SMALL), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_small, flags, masked);
   DFU3D_LAUNCH_CHECK();
-  const int g_big = (int)((pool_cap + BT_BIG - 1) / BT_BIG + S);
+  const int g_big = (int)(((pool_cap + BT_BIG - 1) / BT_BIG + S + DFU3D_BALL_TPW - 1) / DFU3D_BALL_TPW);
   hipLaunchKernelGGL((k_ball_flags<BT_BIG, BH_MAX_BIG, BH_HEADS_BIG>), dim3(g_big), dim3(BT_BIG), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_big, flags, masked);
