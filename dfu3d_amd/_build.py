@@ -94,6 +94,8 @@ VARIANTS = {
     "rf_forward": ["-DDFU3D_RF_REVERSE=0"],
     # ball query: two / four consecutive query tiles per workgroup (one table build for them when they share the instance)
     "ball_tpw2": ["-DDFU3D_BALL_TPW=2"], "ball_tpw4": ["-DDFU3D_BALL_TPW=4"],
+    # ball query: one record per workgroup -- start, duration, the instance's sizes, longest chain walk (tools/ball_timing.py)
+    "ball_timing": ["-DDFU3D_DBG_BALL_TIMING"],
     "rf_quad": ["-DDFU3D_RF_NBR=0"],
     "rf_wave": ["-DDFU3D_RF_NBR=2"],
     "rf_g2048": ["-DDFU3D_RF_GRID=2048"],

@@ -1241,6 +1241,10 @@ __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t i
   return h;
 }
 
+#ifdef DFU3D_DBG_BALL_TIMING       /* dev build (tools/ball_timing.py): one record per workgroup with a tile, plain stores */
+constexpr int BALL_REC = 1 << 17;
+__device__ unsigned long long g_ball_rec[2][BALL_REC][4];      // [build][tile]: start | cycles, na | nq | walked chain nodes (max over lanes)
+#endif
 template <int BT, int BH_MAX, int BH_HEADS>
 __global__ __launch_bounds__(BT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
@@ -1257,6 +1261,13 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
   const int ntile = tile_off[S];
   int t = blockIdx.x * DFU3D_BALL_TPW;
   if (t >= ntile) return;
+#ifdef DFU3D_DBG_BALL_TIMING
+  const long long bt0 = wall_clock64();
+  long long bt1 = bt0, bt2 = bt0, bt3 = bt0;     // segment facts and query point loaded | table built | queries done
+  __shared__ unsigned int s_dbg_walk;
+  if (threadIdx.x == 0) s_dbg_walk = 0u;
+  unsigned int dbg_walk = 0u;
+#endif
   const int t_end = min(t + DFU3D_BALL_TPW, ntile);
   int s = find_segment(tile_off, S, t);
   const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
@@ -1280,6 +1291,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     }
     double x = 0.0, y = 0.0, z = 0.0;
     if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
+#ifdef DFU3D_DBG_BALL_TIMING
+    if (__ballot(x != 12345.678)) bt1 = wall_clock64();      // (after the loads have arrived)
+#endif
     if (na <= BH_MAX && hashed_s != s) {         // (re)build the table -- uniform per workgroup
       int slots = 256;
       while (slots < 2 * na) slots <<= 1;
@@ -1305,6 +1319,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
       __syncthreads();
       hash_ok = (s_pending == 0);
       hashed_s = s;
+#ifdef DFU3D_DBG_BALL_TIMING
+      bt2 = wall_clock64();
+#endif
     }
     bool found = false;
     if (na <= BH_MAX && hash_ok) {
@@ -1324,25 +1341,36 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
           const double fqx = floor(x * inv) + OFF, fqy = floor(y * inv) + OFF, fqz = floor(z * inv) + OFF;
           const bool qin = fqx >= 0.0 && fqy >= 0.0 && fqz >= 0.0 && fqx <= 131071.0 && fqy <= 131071.0 && fqz <= 131071.0;
           const int qx = qin ? (int)fqx : 0, qy = qin ? (int)fqy : 0, qz = qin ? (int)fqz : 0;
+          // one node of a chain (word `wv` of node `node`) against the query
+          auto test_node = [&](uint32_t node, unsigned long long wv) {
+            const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
+                      az = (int)((wv >> 34) & 0x1FFFFull);
+            // each quantised difference is within 1 (+3e-11) unit of the true one, so the
+            // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
+            // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
+            const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
+                      ez_ = max(abs(az - qz) - 1, 0);
+            if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
+              const int j = (int)node - 1;
+#ifdef DFU3D_DBG_BALL_TIMING
+              dbg_walk += 1u << 12;                          // exact tests in the upper bits
+#endif
+              const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
+              double d = ex * ex;
+              d += ey * ey;
+              d += ez * ez;
+              if (d < T) found = true;                       // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
+            }
+          };
           // walk a chain from `node`, whose word `wv` the caller has read already
           auto walk_from = [&](uint32_t node, unsigned long long wv) {
             while (true) {
-              const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
-                        az = (int)((wv >> 34) & 0x1FFFFull);
-              // each quantised difference is within 1 (+3e-11) unit of the true one, so the
-              // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
-              // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
-              const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
-                        ez_ = max(abs(az - qz) - 1, 0);
-              if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
-                const int j = (int)node - 1;
-                const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
-                double d = ex * ex;
-                d += ey * ey;
-                d += ez * ez;
-                if (d < T) { found = true; return; }         // <=> sqrt(d) < C, see dfu3d_ballquery_fuse
-              }
+              test_node(node, wv);
+              if (found) return;
               node = (uint32_t)(wv >> 51);
+#ifdef DFU3D_DBG_BALL_TIMING
+              dbg_walk++;
+#endif
               if (!node) return;
               wv = s_node[node - 1u];
             }
@@ -1358,9 +1386,32 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
               const bool there = ux <= x1 && uy <= y1 && uz <= z1;
               heads[cidx] = there ? s_head[bh_hash((uint32_t)ux, (uint32_t)uy, (uint32_t)uz) & mask] : 0u;
             }
+            // Four chains at a time.  A chain is a run of DEPENDENT LDS reads (the link sits in the node), a dense
+            // instance has a hundred LiDAR points per cell, and a query with no neighbour walks all eight chains to
+            // their ends: 200-300 reads in a row per lane were most of a workgroup's 22 us (tools/ball_timing.py) with
+            // the vector pipes a third busy at eight waves per SIMD.  The four next-node reads of a step are independent.
 #pragma unroll
-            for (int cidx = 0; cidx < 8; cidx++)               // (reading the chains' first nodes ahead as well gained nothing)
-              if (!found) walk(heads[cidx]);
+            for (int g4 = 0; g4 < 8; g4 += 4) {
+              if (found) break;
+              uint32_t nd[4];
+              unsigned long long wv[4];
+#pragma unroll
+              for (int c4 = 0; c4 < 4; c4++) { nd[c4] = heads[g4 + c4]; wv[c4] = nd[c4] ? s_node[nd[c4] - 1u] : 0ull; }
+              while ((nd[0] | nd[1] | nd[2] | nd[3]) != 0u) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++)
+                  if (nd[c4]) {
+                    test_node(nd[c4], wv[c4]);
+                    nd[c4] = (uint32_t)(wv[c4] >> 51);
+#ifdef DFU3D_DBG_BALL_TIMING
+                    dbg_walk++;
+#endif
+                  }
+                if (found) break;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) wv[c4] = nd[c4] ? s_node[nd[c4] - 1u] : 0ull;
+              }
+            }
           } else {
             for (int uz = z0; uz <= z1 && !found; uz++)
               for (int uy = y0; uy <= y1 && !found; uy++)
@@ -1370,6 +1421,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
         }
         flags[bq + q] = found ? 1 : 0;
       }
+#ifdef DFU3D_DBG_BALL_TIMING
+      bt3 = wall_clock64();
+#endif
       continue;
     }
     // brute force over LDS tiles (more LiDAR points than the table holds, or a huge extent)
@@ -1401,7 +1455,29 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     }
     if (valid) flags[bq + q] = found ? 1 : 0;
   }
+#ifdef DFU3D_DBG_BALL_TIMING
+  atomicMax(&s_dbg_walk, (dbg_walk >> 12) << 12 | min(dbg_walk & 0xFFFu, 0xFFFu));   // (ordered by exact tests first)
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < BALL_REC) {
+    const int s_ = find_segment(tile_off, S, blockIdx.x * DFU3D_BALL_TPW);
+    const int b_ = BT == BT_BIG ? 1 : 0;
+    g_ball_rec[b_][blockIdx.x][0] = ((unsigned long long)(bt0 & 0xFFFFFFFFll) << 32) | (unsigned long long)((wall_clock64() - bt0) & 0xFFFFFFFFll);
+    g_ball_rec[b_][blockIdx.x][2] = ((unsigned long long)((bt1 - bt0) & 0xFFFFFll) << 40) | ((unsigned long long)((bt2 - bt1) & 0xFFFFFll) << 20) | (unsigned long long)((bt3 - bt2) & 0xFFFFFll);
+    g_ball_rec[b_][blockIdx.x][1] = ((unsigned long long)(unsigned)cnt_a[s_] << 40) | ((unsigned long long)(unsigned)(cnt_b[s_] & 0xFFFFF) << 20) | (unsigned long long)(s_dbg_walk & 0xFFFFF);
+  }
+#endif
 }
+
+#ifdef DFU3D_DBG_BALL_TIMING
+extern "C" int dfu3d_debug_ball_timing(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ball_rec), sizeof(g_ball_rec)) != hipSuccess) return DFU3D_ELAUNCH;
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ball_rec)) != hipSuccess || hipMemset(p, 0, sizeof(g_ball_rec)) != hipSuccess) return DFU3D_ELAUNCH;
+  }
+  return DFU3D_OK;
+}
+#endif
 
 // ---------------------------------------------------------------- compaction
 // In-order compaction of segment s by flags.  dst = src (in place) or, when
