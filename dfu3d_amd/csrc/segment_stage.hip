@@ -1235,6 +1235,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan_class(int S, const int *__re
   if (threadIdx.x == 0) tile_off[S] = running;
 }
 
+// |a - b| in one instruction (the compiler expands __sad() into subtract, negate, max)
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
   uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
   h ^= h >> 15;
@@ -1343,14 +1349,18 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
           const int qx = qin ? (int)fqx : 0, qy = qin ? (int)fqy : 0, qz = qin ? (int)fqz : 0;
           // one node of a chain (word `wv` of node `node`) against the query
           auto test_node = [&](uint32_t node, unsigned long long wv) {
-            const int ax = (int)(wv & 0x1FFFFull), ay = (int)((wv >> 17) & 0x1FFFFull),
-                      az = (int)((wv >> 34) & 0x1FFFFull);
+            const uint32_t ax = (uint32_t)(wv & 0x1FFFFull), ay = (uint32_t)((wv >> 17) & 0x1FFFFull),
+                           az = (uint32_t)((wv >> 34) & 0x1FFFFull);
             // each quantised difference is within 1 (+3e-11) unit of the true one, so the
             // true distance is at least |max(|d|-1, 0)| units, and C is 16/(1+1e-5) < 16 units:
-            // 258 > 16.06^2 leaves room for the rounding of the quantisation itself
-            const int ex_ = max(abs(ax - qx) - 1, 0), ey_ = max(abs(ay - qy) - 1, 0),
-                      ez_ = max(abs(az - qz) - 1, 0);
-            if (!qin || ex_ * ex_ + ey_ * ey_ + ez_ * ez_ <= 257) {
+            // 258 > 16.06^2 leaves room for the rounding of the quantisation itself.
+            // |a - q| by v_sad_u32, the terms capped at 31 (one capped term alone is 961 > 257) so that the squares are
+            // 24-bit multiplies: a 32-bit v_mul_lo_u32 issues at a quarter of the rate, and three of them were 40 % of a
+            // node's 120 clocks -- the node test is what the query phase runs on (tools/ball_timing.py)
+            const uint32_t sx_ = sad_u32(ax, (uint32_t)qx), sy_ = sad_u32(ay, (uint32_t)qy), sz_ = sad_u32(az, (uint32_t)qz);
+            const uint32_t ex_ = min(sx_ ? sx_ - 1u : 0u, 31u), ey_ = min(sy_ ? sy_ - 1u : 0u, 31u),
+                           ez_ = min(sz_ ? sz_ - 1u : 0u, 31u);
+            if (!qin || __umul24(ex_, ex_) + __umul24(ey_, ey_) + __umul24(ez_, ez_) <= 257u) {
               const int j = (int)node - 1;
 #ifdef DFU3D_DBG_BALL_TIMING
               dbg_walk += 1u << 12;                          // exact tests in the upper bits
