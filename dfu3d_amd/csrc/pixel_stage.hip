@@ -236,6 +236,7 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   // most (1 + |q0|) / w + 1.  A geometry with bins so narrow that this eats the slop gets no tier 1 at all.
   const double slop_t = 1.8e-7 * ((1.0 + __builtin_fabs(f.tq0d)) / f.twd + 1.0), slop_p = 1.8e-7 * ((1.0 + __builtin_fabs(f.pq0d)) / f.pwd + 1.0);
   if (!(__builtin_fmax(slop_t, slop_p) <= TAB_SLOP_W)) f.dmax = 0.0f;
+  if (g.t_n >= (1 << 24) || g.p_n >= (1 << 24)) f.dmax = 0.0f;          // classify_fast forms the bin index with a 24-bit multiply
   // tier 1.5: one fp64 edge per bin boundary of the window behind the float32 tables, if the scratch holds them
   f.mid_ok = (f.dmax > 0.0f) && ((int64_t)f.tJ + f.pJ + 4 + (int64_t)g.t_n + g.p_n + 2 <= 2 * (int64_t)(TAB_T_MAX + TAB_P_MAX));
   f.pad1 = 0;
@@ -433,7 +434,9 @@ __device__ __forceinline__ void classify_fast(const FastCal &fc, const dfu3d_bin
     ok = ok & (itk < (uint32_t)g.t_n) & (ipk < (uint32_t)g.p_n);
     it[k] = (int)itk;                                                    // (meaningful only for a decided, binned pixel)
     ip[k] = (int)ipk;
-    res[k] = (dead[k] | th_out) ? NOBIN : (ok ? itk * (uint32_t)g.p_n + ipk : AMBIG);
+    // (a 24-bit multiply: v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate; make_fast_geom switches tier 1 off
+    // for a window of 2^24 or more bins along an axis)
+    res[k] = (dead[k] | th_out) ? NOBIN : (ok ? __umul24(itk, (uint32_t)g.p_n) + ipk : AMBIG);
   }
 }
 
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
     if (oldf != NOBIN) toggle_first_bit(bitmap_v, W, tiles_x, oldf);
   };
   const uint32_t pix00 = (uint32_t)(ty * (RPT * TILE_H) * W + tx * TILE_W);        // the tile's first pixel
-  auto global_pix = [&](uint32_t loc) { return pix00 + (loc >> 6) * (uint32_t)W + (loc & 63u); };
+  auto global_pix = [&](uint32_t loc) { return pix00 + __umul24(loc >> 6, (uint32_t)W) + (loc & 63u); };
   static_assert(TILE_W == 64, "tile-local pixel index");
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       continue;
 #endif
       if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {      // aggregate in the LDS window
-        const uint32_t w = lt * WIN_P + lp;
+        const uint32_t w = __umul24(lt, (uint32_t)WIN_P) + lp;     // (24-bit multiplies issue at four times the rate of v_mul_lo_u32)
         atomicAdd(&s_cnt[w], 1u);
         atomicMin(&s_first[w], loc0 + k);
         atomicMin(&s_kmin[w], ok);
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       const uint32_t loc = (uint32_t)((prow - ty * (RPT * TILE_H)) * TILE_W + (pcol - tx * TILE_W));
       const uint32_t lt = mo.it - (uint32_t)t0, lp = mo.ip - (uint32_t)p0;
       if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {
-        const uint32_t w = lt * WIN_P + lp;
+        const uint32_t w = __umul24(lt, (uint32_t)WIN_P) + lp;     // (24-bit multiplies issue at four times the rate of v_mul_lo_u32)
         atomicAdd(&s_cnt[w], 1u);
         atomicMin(&s_first[w], loc);
         atomicMin(&s_kmin[w], ok);
@@ -727,7 +730,9 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
 #ifdef DFU3D_DBG_P1_NO_FLUSH          /* timing experiment only: results are wrong */
     continue;
 #endif
-    const uint32_t b = (uint32_t)((t0 + w / WIN_P) * g.p_n + (p0 + w % WIN_P));
+    static_assert(WIN_T * WIN_P <= 768 && WIN_P == 48, "w / 48 as (w * 1366) >> 16 is exact below 768 * 48 / 18");
+    const uint32_t wq = __umul24((uint32_t)w, 1366u) >> 16, wr = (uint32_t)w - __umul24(wq, (uint32_t)WIN_P);   // w / 48, w % 48
+    const uint32_t b = __umul24((uint32_t)t0 + wq, (uint32_t)g.p_n) + ((uint32_t)p0 + wr);
     const int64_t e = tb0 + b;
     f_loc[i] = s_first[w];
     f_new[i] = global_pix(f_loc[i]);
