@@ -1242,8 +1242,11 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b) {
   return r;
 }
 __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t iz) {
-  uint32_t h = ix * 0x9E3779B1u ^ iy * 0x85EBCA77u ^ iz * 0xC2B2AE3Du;
+  // cell coordinates are below 2^12: 24-bit multiplies (three v_mul_lo_u32 per cell, eight cells per query, issue at a
+  // quarter of the rate)
+  uint32_t h = __umul24(ix, 0x9E3779u) ^ __umul24(iy, 0x85EBCBu) ^ __umul24(iz, 0xC2B2AFu);
   h ^= h >> 15;
+  h ^= h >> 7;
   return h;
 }
 
