@@ -93,15 +93,47 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
   return v;
 }
+// Minimum / maximum over the wave, the result in every lane.  Data-parallel-primitive moves inside the rows, two row
+// broadcasts, one read of lane 63: twelve register moves at the latency of a vector instruction.  (The xor butterfly
+// through ds_bpermute was twelve dependent LDS-latency operations per reduction, and the fit kernels do eight of them
+// per pair of headings.)  A minimum does not depend on the order it is formed in: same bits as before.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double min_f64_raw(double a, double b) {     // (no canonicalising copy of the operands)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double lane63_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, shfl_xor_d(v, m));
-  return v;
+  v = min_f64_raw(v, dpp_move_d<0xB1, 0xF>(v));      // quad_perm [1,0,3,2]
+  v = min_f64_raw(v, dpp_move_d<0x4E, 0xF>(v));      // quad_perm [2,3,0,1]
+  v = min_f64_raw(v, dpp_move_d<0x141, 0xF>(v));     // row_half_mirror
+  v = min_f64_raw(v, dpp_move_d<0x140, 0xF>(v));     // row_mirror: every lane of a row holds the row's minimum
+  v = min_f64_raw(v, dpp_move_d<0x142, 0xA>(v));     // row_bcast15 into rows 1 and 3
+  v = min_f64_raw(v, dpp_move_d<0x143, 0xC>(v));     // row_bcast31 into rows 2 and 3: lane 63 holds the wave's
+  return lane63_d(v);
 }
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_d(v, m));
-  return v;
+  v = max_f64_raw(v, dpp_move_d<0xB1, 0xF>(v));
+  v = max_f64_raw(v, dpp_move_d<0x4E, 0xF>(v));
+  v = max_f64_raw(v, dpp_move_d<0x141, 0xF>(v));
+  v = max_f64_raw(v, dpp_move_d<0x140, 0xF>(v));
+  v = max_f64_raw(v, dpp_move_d<0x142, 0xA>(v));
+  v = max_f64_raw(v, dpp_move_d<0x143, 0xC>(v));
+  return lane63_d(v);
 }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll

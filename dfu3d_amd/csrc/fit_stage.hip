@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(FT) void k_fit_medium(
 // per SIMD, 80 wave reductions + cross-wave sums and seven barriers per item.  A wave per heading reading the
 // members straight from global memory was tried as well: every XCD fetched every cluster, 5.4 GB per launch.)
 constexpr int BIGC_T = 512, BIGC_WAVES = BIGC_T / 64, BIGC_HPW = 2, BIGC_HB = BIGC_WAVES * BIGC_HPW;
-constexpr int BIGC_CH = 2048;
+constexpr int BIGC_CH = 4096;   // points staged per step: 64 KB of LDS, i.e. two workgroups per compute unit (four, which 64 registers would allow, measured 25 % slower)
 constexpr int BIGC_LONG = 16384, BIGC_MID = 6144;   // size classes of the scheduling rounds
 __global__ __launch_bounds__(BIGC_T) void k_fit_big_cost(const double *__restrict__ gsx,
                                                          const double *__restrict__ gsy, int n_theta,
