@@ -52,14 +52,43 @@ __device__ __forceinline__ int block_rank(bool flag, int *s_w, int &block_total)
   return off + r;
 }
 
-// wave inclusive scan of an int
+// Register moves between lanes without the LDS path: data-parallel-primitive modifiers.  A lane whose source lies
+// outside its row (or whose row the row mask leaves out) gets `old`.  (__shfl_up / __shfl_xor are ds_bpermute: an LDS
+// round trip each, and a scan or a reduction is six of them in a row.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+// wave inclusive scan of an int: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 of the row before into rows
+// 1 and 3, then lane 31 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_scan(int v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(v, d, 64);
-    if (lane_id() >= d) v += t;
-  }
+  v += dpp_move_i<0x111, 0xF>(0, v);               // row_shr:1
+  v += dpp_move_i<0x112, 0xF>(0, v);               // row_shr:2
+  v += dpp_move_i<0x114, 0xF>(0, v);               // row_shr:4
+  v += dpp_move_i<0x118, 0xF>(0, v);               // row_shr:8
+  v += dpp_move_i<0x142, 0xA>(0, v);               // row_bcast15
+  v += dpp_move_i<0x143, 0xC>(0, v);               // row_bcast31
   return v;
+}
+// the wave's sum / bitwise OR, in every lane (integers: the order does not matter)
+__device__ __forceinline__ int wave_sum_i_dpp(int v) {
+  v += dpp_move_i<0xB1, 0xF>(v, v);                // quad_perm [1,0,3,2]
+  v += dpp_move_i<0x4E, 0xF>(v, v);                // quad_perm [2,3,0,1]
+  v += dpp_move_i<0x141, 0xF>(v, v);               // row_half_mirror
+  v += dpp_move_i<0x140, 0xF>(v, v);               // row_mirror: every lane holds its row's sum
+  v += dpp_move_i<0x142, 0xA>(0, v);               // rows 1, 3 += row before
+  v += dpp_move_i<0x143, 0xC>(0, v);               // rows 2, 3 += rows 0 + 1: lane 63 holds the wave's
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_or_u32_dpp(uint32_t x) {
+  int v = (int)x;
+  v |= dpp_move_i<0xB1, 0xF>(v, v);
+  v |= dpp_move_i<0x4E, 0xF>(v, v);
+  v |= dpp_move_i<0x141, 0xF>(v, v);
+  v |= dpp_move_i<0x140, 0xF>(v, v);
+  v |= dpp_move_i<0x142, 0xA>(0, v);
+  v |= dpp_move_i<0x143, 0xC>(0, v);
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 
 // Block-wide exclusive scan of an int value.
@@ -144,11 +173,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   }
   return v;
 }
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i_dpp(v); }
 
 // ---- calibration arithmetic -------------------------------------------------
 // calibration_kitti.py:104-112, float32: sequential-k FMA chain (== sgemm).

@@ -50,11 +50,7 @@ constexpr int SEG_GX = 128;                         // workgroups per view at mo
 static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
 inline int seg_ranges(int cap_item) { return (cap_item + SEG_WI - 1) / SEG_WI; }
 
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x |= (uint32_t)__shfl_xor((int)x, m, 64);
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) { return wave_or_u32_dpp(x); }
 
 // lane j: how many of the wave's items (bit words b[k], one per lane and step) carry instance j
 __device__ __forceinline__ int wave_instance_counts(const uint32_t (&b)[SEG_STEPS], uint32_t (&wany)[SEG_STEPS]) {
@@ -230,8 +226,10 @@ __global__ __launch_bounds__(SEG_WPB * 64) void k_seg_write(
         const int j = __ffs((int)w) - 1;
         const bool has = (b[k] >> j) & 1u;
         const unsigned long long m = __ballot(has);
-        const long long start = __shfl(woff, j, 64);
-        const uint32_t swj = (uint32_t)__shfl((int)sw, j, 64);
+        // (j is the same in every lane: a read of lane j, not a shuffle through the LDS path)
+        const long long start = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(woff >> 32), j) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(woff & 0xFFFFFFFFll), j));
+        const uint32_t swj = (uint32_t)__builtin_amdgcn_readlane((int)sw, j);
         if (has) {
           const long long d = start + __popcll(m & ((1ull << lane) - 1ull));
           px[d] = x[k];
