@@ -80,6 +80,15 @@ __device__ __forceinline__ int wave_sum_i_dpp(int v) {
   v += dpp_move_i<0x143, 0xC>(0, v);               // rows 2, 3 += rows 0 + 1: lane 63 holds the wave's
   return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_min_i_dpp(int v) {
+  v = min(v, dpp_move_i<0xB1, 0xF>(v, v));
+  v = min(v, dpp_move_i<0x4E, 0xF>(v, v));
+  v = min(v, dpp_move_i<0x141, 0xF>(v, v));
+  v = min(v, dpp_move_i<0x140, 0xF>(v, v));
+  v = min(v, dpp_move_i<0x142, 0xA>(v, v));
+  v = min(v, dpp_move_i<0x143, 0xC>(v, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ uint32_t wave_or_u32_dpp(uint32_t x) {
   int v = (int)x;
   v |= dpp_move_i<0xB1, 0xF>(v, v);

@@ -15,6 +15,11 @@
 #include "common.hpp"
 
 namespace {
+// a register of lane l, l the same in every lane: v_readlane, not a shuffle through the LDS path (ds_bpermute)
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double rl_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 
 constexpr int CT = 512;            // threads per clustering workgroup
 constexpr int GRP = 32;            // points per summary / bounding-box group
@@ -236,7 +241,7 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
       const int pg = in ? par.load(jl) : -3;
       // cheap exit: every query of the wave that still needs this group sits in
       // one set and all 32 points already belong to it (own-chunk groups mostly)
-      const int r_first = __shfl(ri, __ffsll((unsigned long long)__ballot(need)) - 1, 64);
+      const int r_first = rl_i(ri, max(__ffsll((unsigned long long)__ballot(need)) - 1, 0));
       if (__all(!need || ri == r_first) && __all(!in || pg == r_first)) {
 #ifdef DFU3D_DBG_CLUSTER_TIMING
         dbg_cnt[6]++;
@@ -248,14 +253,14 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         if ((k & 7) == 7 && k != GRP - 1) {
           // every 8 points: once all queries that need this group have merged into
           // the set that owns all of its points, the rest of the group is moot
-          const int rf = __shfl(ri, __ffsll((unsigned long long)__ballot(need)) - 1, 64);
+          const int rf = rl_i(ri, max(__ffsll((unsigned long long)__ballot(need)) - 1, 0));
           if (__all(!need || ri == rf) && __all(!in || pg == rf)) break;
         }
 #ifdef DFU3D_DBG_CLUSTER_TIMING
         dbg_cnt[4]++;
 #endif
-        const int pj = __shfl(pg, k, 64);
-        const double xj = __shfl(xg, k, 64), yj = __shfl(yg, k, 64);
+        const int pj = rl_i(pg, k);
+        const double xj = rl_d(xg, k), yj = rl_d(yg, k);
         if (need && (jg + k < i) && pj != ri) {                 // (3) not in my set (yet)
           const double dx = xi - xj, dy = yi - yj;
           const double sq = dx * dx + dy * dy;
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
       while (todo) {
         const int src = __ffsll(todo) - 1;
         todo &= todo - 1ull;
-        const int cc = __shfl(c, src, 64), nn = __shfl(nb, src, 64);
+        const int cc = rl_i(c, src), nn = rl_i(nb, src);
         if (cell_find(s_par, cc) == cell_find(s_par, nn)) continue;   // merged meanwhile (uniform)
         const int a0 = cc ? s_end[cc - 1] : 0, a1 = s_end[cc];
         const int b0 = s_end[nn - 1], b1 = s_end[nn];
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
             while (am) {
               const int k = __ffsll((long long)am) - 1;
               am &= am - 1ull;
-              const double xa = __shfl(xal, k, 64), ya = __shfl(yal, k, 64);
+              const double xa = rl_d(xal, k), ya = rl_d(yal, k);
               const double dx = xa - xb, dy = ya - yb;
               const double sq = dx * dx + dy * dy;
               if (vb && sq <= S_HI) {
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
         unsigned long long rem = __ballot(key >= 0);
         while (rem) {
           const int src = __ffsll((long long)rem) - 1;
-          const int k = __shfl(key, src, 64);
+          const int k = rl_i(key, src);
           const unsigned long long m = __ballot(key == k);
           if (lane == src) s_cnt[wave][k] += __popcll(m);
           rem &= ~m;
@@ -1170,7 +1175,7 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
         unsigned long long rem = __ballot(key >= 0);
         while (rem) {
           const int src = __ffsll((long long)rem) - 1;
-          const int k = __shfl(key, src, 64);
+          const int k = rl_i(key, src);
           const unsigned long long m = __ballot(key == k);
           const int cur = s_cnt[wave][k];
           if (key == k) {

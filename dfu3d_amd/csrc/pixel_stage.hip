@@ -630,11 +630,8 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   P1_T(1);                                        // depth loads, classification, exact keys (thread 0's wave)
   // window origin: wave minimum first (all lanes), then one LDS atomic per wave -- 256 lanes on two
   // addresses serialise
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    tmin = min(tmin, __shfl_xor(tmin, m, 64));
-    pmin = min(pmin, __shfl_xor(pmin, m, 64));
-  }
+  tmin = wave_min_i_dpp(tmin);
+  pmin = wave_min_i_dpp(pmin);
   if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
