@@ -476,40 +476,41 @@ struct MidOut { uint32_t it, ip; double y, z; };    // window coordinates of the
 __device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Recip &rc, const dfu3d_bin_geom &g,
                                                   const FastGeom &fg, const float2 *__restrict__ tab, int W, int pix,
                                                   float d, bool &decided, MidOut *mo = nullptr) {
-  decided = true;
-  if (!(d >= (float)g.depth_min) || !(d > 0.0f)) return NOBIN;   // my_loader.py:507-509
+  // All the arithmetic first, then the two table cells together, then the two fp64 edges together: three dependent
+  // memory round trips instead of five (one wave per workgroup of k_bp_bin runs this while three wait).  Indices are
+  // clamped, so a pixel that turns out not to be binned at all reads harmlessly.
+  const bool dok = (d >= (float)g.depth_min) && (d > 0.0f);      // my_loader.py:507-509
   const int row = pix / W, col = pix - row * W;
   double x, y, z;
   pixel_to_lidar(c, rc, col, row, d, x, y, z);
-  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540
   double s = x * x;                                              // my_loader.py:167
   s = s + y * y;
   s = s + z * z;
   const double r = sqrt(s);
   const double qt = -(z / r);
-  if (qt < fg.q_tmin_d - 1e-12) return NOBIN;                    // theta <= theta_min for certain (:175)
-  decided = qt > fg.q_tmin_d + 1e-12;                            // (false for NaN)
   const double cr = floor((r - g.rmin_r) / g.vsize_r);
-  if (decided && !(cr >= 0.0 && cr < (double)g.grid_r)) return NOBIN;
-  // theta
-  const uint32_t jt = min((uint32_t)(int)__fmaf_rn((float)qt, fg.tinv, fg.tc1), (uint32_t)(fg.tJ + 1));
-  const float2 et = tab[jt];
-  const uint32_t i_t = (uint32_t)(__float_as_int(et.y) - g.t_lo);        // edge index inside the window: 0 .. t_n
-  decided = decided && (et.x == et.x) && (i_t <= (uint32_t)g.t_n);
-  const double dt = qt - edge_tab_t(tab, fg)[decided ? i_t : 0u];
-  decided = decided && (fabs(dt) > 1e-12);
-  const uint32_t it = i_t - (dt < 0.0 ? 1u : 0u);
-  // phi
   const double t = y / x;
   const float tf = (float)t;
   const float qpf = tf * __builtin_amdgcn_rcpf(1.0f + fabsf(tf));        // (NaN for an infinite quotient: no decision)
+  const uint32_t jt = min((uint32_t)(int)__fmaf_rn((float)qt, fg.tinv, fg.tc1), (uint32_t)(fg.tJ + 1));
   const uint32_t jp = min((uint32_t)(int)__fmaf_rn(qpf, fg.pinv, fg.pc1), (uint32_t)(fg.pJ + 1));
+  const float2 et = tab[jt];
   const float2 ep = tab[fg.tJ + 2 + jp];
+  const uint32_t i_t = (uint32_t)(__float_as_int(et.y) - g.t_lo);        // edge index inside the window: 0 .. t_n
   const uint32_t i_p = (uint32_t)(__float_as_int(ep.y) - g.p_lo);
-  decided = decided && (ep.x == ep.x) && (i_p <= (uint32_t)g.p_n);
-  const double dp = t - edge_tab_p(tab, fg, g)[decided ? i_p : 0u];
-  decided = decided && (fabs(dp) > 1e-12 * fma(t, t, 1.0));
-  const uint32_t ip = i_p - (dp < 0.0 ? 1u : 0u);
+  const double e_t = edge_tab_t(tab, fg)[min(i_t, (uint32_t)g.t_n)];
+  const double e_p = edge_tab_p(tab, fg, g)[min(i_p, (uint32_t)g.p_n)];
+  const double dt = qt - e_t, dp = t - e_p;
+  const uint32_t it = i_t - (dt < 0.0 ? 1u : 0u), ip = i_p - (dp < 0.0 ? 1u : 0u);
+  // the decisions, in the reference's order
+  decided = true;
+  if (!dok) return NOBIN;
+  if (!(z < g.z_max)) return NOBIN;                              // my_loader.py:540
+  if (qt < fg.q_tmin_d - 1e-12) return NOBIN;                    // theta <= theta_min for certain (:175)
+  decided = qt > fg.q_tmin_d + 1e-12;                            // (false for NaN)
+  if (decided && !(cr >= 0.0 && cr < (double)g.grid_r)) return NOBIN;
+  decided = decided && (et.x == et.x) && (i_t <= (uint32_t)g.t_n) && (fabs(dt) > 1e-12);
+  decided = decided && (ep.x == ep.x) && (i_p <= (uint32_t)g.p_n) && (fabs(dp) > 1e-12 * fma(t, t, 1.0));
   decided = decided && (it < (uint32_t)g.t_n) && (ip < (uint32_t)g.p_n);  // (a bin below / above the window: pixel_bin reports it)
   if (mo) { mo->it = it; mo->ip = ip; mo->y = y; mo->z = z; }
   return it * (uint32_t)g.p_n + ip;
