@@ -78,6 +78,9 @@ VARIANTS = {
     # packed min-(key|pixel) word with only 14 key bits: keys collide below the cut all the time, so the exact
     # repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never taken in the product build) does the work
     "keybits14": ["-DDFU3D_DBG_COMBO_KEYBITS=14"],
+    # no middle tier: what float32 leaves undecided goes to k_bp_bin_amb (pixels) and is parked for k_bp_vox_amb (first
+    # pixels of voxels) -- the paths the product build takes for a handful of pixels per launch
+    "no_mid": ["-DDFU3D_DBG_NO_MID"],
     # timing experiments (dev; wrong results): selected at load time with DFU3D_LIB_VARIANT=<name>
     "p1_noflush": ["-DDFU3D_DBG_P1_NO_FLUSH"],
     "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],

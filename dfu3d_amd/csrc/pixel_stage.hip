@@ -240,6 +240,9 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   // tier 1.5: one fp64 edge per bin boundary of the window behind the float32 tables, if the scratch holds them
   f.mid_ok = (f.dmax > 0.0f) && ((int64_t)f.tJ + f.pJ + 4 + (int64_t)g.t_n + g.p_n + 2 <= 2 * (int64_t)(TAB_T_MAX + TAB_P_MAX));
   f.pad1 = 0;
+#ifdef DFU3D_DBG_NO_MID              /* test build: every pixel / voxel tier 1 leaves undecided takes the full fp64 path */
+  f.mid_ok = 0;
+#endif
   f.pad0 = 0.0f;
   return f;
 }

@@ -676,6 +676,32 @@ def test_backproject_repair_path_with_colliding_keys(st, monkeypatch):
             assert np.array_equal(xyz[v, :len(pix)], pts), v
 
 
+def test_backproject_without_the_middle_tier_takes_the_full_fp64_paths(st, monkeypatch):
+    """Test build of the library without the middle tier of the bin classification: every pixel the float32 tier
+    leaves undecided is classified by k_bp_bin_amb, and every voxel whose first pixel is undecided is parked by
+    k_bp_vox and finished by k_bp_vox_amb -- in the product build those two kernels see a few pixels per launch, here
+    they see 0.7 % of them.  Same answer as the oracle's, bit for bit, and the same as the product build's."""
+    from dfu3d_amd import _lib, synth
+    s = synth.make_scene(35, H=180, W=320, M=4, cams=3, dense=True, k_min=10, k_max=14)
+    depth = s.depth.numpy().copy()
+    depth[0, 100:110, :] = 7.5
+    masks = s.masks.numpy()
+    ref = _bp_run(st, depth, s.calibs, masks, 100, 1000000, 2)
+    L = _lib.load_variant("no_mid")
+    monkeypatch.setattr(_lib, "_LIB", L)
+    for key_axis in (1, 2):
+        n_vox, vox_pix, bits, xyz, status = _bp_run(st, depth, s.calibs, masks, 100, 1000000, key_axis)
+        assert status == 0
+        for v in range(depth.shape[0]):
+            pix, pts, ob = _bp_oracle(depth[v], s.calibs[v], masks[v], 100, 1000000, key_axis)
+            assert n_vox[v] == len(pix)
+            assert np.array_equal(vox_pix[v, :len(pix)], pix), v
+            assert np.array_equal(bits[v, :len(pix)], ob), v
+            assert np.array_equal(xyz[v, :len(pix)], pts), v
+        if key_axis == 2:
+            assert np.array_equal(n_vox, ref[0]) and np.array_equal(vox_pix, ref[1]) and np.array_equal(xyz, ref[3])
+
+
 @pytest.mark.parametrize("max_points,max_voxels,key_axis", [(100, 1000000, 1), (100, 1000000, 2),
                                                             (3, 1000000, 1), (1, 1000000, 2),
                                                             (100, 500, 1), (2, 300, 1)])
