@@ -224,6 +224,7 @@ __device__ __forceinline__ int block_sum_i(int v, int *s_red) {
 }
 
 constexpr int RB = 8;   // RANSAC trials scored per sweep over the candidates
+constexpr int RS_LDS = 3072;   // candidates kept in LDS (48 KB); a view of the bench has ~2500
 
 __global__ __launch_bounds__(NT) void k_plane_ransac(
     const float4 *__restrict__ pts, const int *__restrict__ pt_off,
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
   __shared__ int s_redi[NW];
   __shared__ double s_model[RB][3];
   __shared__ int s_valid[RB], s_tot[RB], s_cnt[NW][RB];
+  __shared__ float4 s_pt[RS_LDS];
   const int v = blockIdx.x;
   const int p0 = pt_off[view_frame[v]];
   const int nf = n_fov[v];
@@ -261,14 +263,20 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
     n += tot;
   }
   __syncthreads();
+  // the candidates' coordinates in LDS (the first RS_LDS of them): every sweep below -- two medians of eight radix passes,
+  // thirteen batches of trials, the refit -- read a candidate through its index (two dependent global round trips);
+  // from LDS it is one
+  for (int i = threadIdx.x; i < min(n, RS_LDS); i += NT) s_pt[i] = pts[p0 + cidx[i]];
+  __syncthreads();
+  auto cand = [&](int i) -> float4 { return i < RS_LDS ? s_pt[i] : pts[p0 + cidx[i]]; };
   double *out = plane + (size_t)v * 4;
   if (n < 3) {
     if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 1e30; }
     return;
   }
-  auto zval = [&](int i) { return (double)pts[p0 + cidx[i]].z; };
+  auto zval = [&](int i) { return (double)cand(i).z; };
   const double med = block_median(n, zval, s_hist, s_sel);
-  auto dev = [&](int i) { return fabs((double)pts[p0 + cidx[i]].z - med); };
+  auto dev = [&](int i) { return fabs((double)cand(i).z - med); };
   const double thr = block_median(n, dev, s_hist, s_sel);
 
   // trials in batches of RB: thread t < RB draws the samples of trial t0+t and fits its
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
           if (!dup) idx[got++] = i;
         }
         if (got == 3) {
-          const float4 q0 = pts[p0 + cidx[idx[0]]], q1 = pts[p0 + cidx[idx[1]]], q2 = pts[p0 + cidx[idx[2]]];
+          const float4 q0 = cand(idx[0]), q1 = cand(idx[1]), q2 = cand(idx[2]);
           const double x0 = q0.x, y0 = q0.y, z0 = q0.z;
           const double dx1 = (double)q1.x - x0, dy1 = (double)q1.y - y0, dz1 = (double)q1.z - z0;
           const double dx2 = (double)q2.x - x0, dy2 = (double)q2.y - y0, dz2 = (double)q2.z - z0;
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
 #pragma unroll
     for (int k = 0; k < RB; k++) cnt[k] = 0;
     for (int i = threadIdx.x; i < n; i += NT) {
-      const float4 p = pts[p0 + cidx[i]];
+      const float4 p = cand(i);
       const double px_ = (double)p.x, py_ = (double)p.y, pz_ = (double)p.z;
 #pragma unroll
       for (int k = 0; k < RB; k++) {
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
   double sx = 0.0, sy = 0.0, sz = 0.0;
   int k = 0;
   for (int i = threadIdx.x; i < n; i += NT) {
-    const float4 p = pts[p0 + cidx[i]];
+    const float4 p = cand(i);
     const double res = fabs((double)p.z - ((ba * (double)p.x + bb * (double)p.y) + bc));
     if (res <= thr) { sx += p.x; sy += p.y; sz += p.z; k++; }
   }
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(NT) void k_plane_ransac(
   const double mx = sx / k, my = sy / k, mz = sz / k;
   double sxx = 0.0, sxy = 0.0, syy = 0.0, sxz = 0.0, syz = 0.0;
   for (int i = threadIdx.x; i < n; i += NT) {
-    const float4 p = pts[p0 + cidx[i]];
+    const float4 p = cand(i);
     const double res = fabs((double)p.z - ((ba * (double)p.x + bb * (double)p.y) + bc));
     if (res <= thr) {
       const double ux = (double)p.x - mx, uy = (double)p.y - my, uz = (double)p.z - mz;
