@@ -73,7 +73,8 @@ def build(force=False, verbose=False):
     return _compile(OUT, {"force": force, "flags": os.environ.get("DFU3D_EXTRA_HIPCC_FLAGS", "").split()}, verbose)
 
 
-# Variant builds for tests: the same sources with a debug switch, next to the product library.
+# Variant builds: the same sources with ONE switch of csrc/dbg.hpp, next to the product library.  All of them give the
+# product's results.  They are loaded only through _lib.load_variant() -- by tests/ and tools/, never by the package.
 VARIANTS = {
     # packed min-(key|pixel) word with only 14 key bits: keys collide below the cut all the time, so the exact
     # repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never taken in the product build) does the work
@@ -81,39 +82,8 @@ VARIANTS = {
     # no middle tier: what float32 leaves undecided goes to k_bp_bin_amb (pixels) and is parked for k_bp_vox_amb (first
     # pixels of voxels) -- the paths the product build takes for a handful of pixels per launch
     "no_mid": ["-DDFU3D_DBG_NO_MID"],
-    # timing experiments (dev; wrong results): selected at load time with DFU3D_LIB_VARIANT=<name>
-    "p1_noflush": ["-DDFU3D_DBG_P1_NO_FLUSH"],
-    "p1_nocommit": ["-DDFU3D_DBG_P1_NO_COMMIT"],
-    "grid_timing": ["-DDFU3D_DBG_GRID_TIMING"],
-    "grid_split": ["-DDFU3D_GRID_SPLIT_LAUNCH"],
-    # radius filter: cycles per phase of k_rf_stream / k_rf_pair / k_rf_resolve (tools/rf_timing.py)
-    "rf_timing": ["-DDFU3D_DBG_RF_TIMING"],
-    # radius filter, phase A: the streaming part alone / without its flag stores (wrong results: what is the ceiling?)
-    "rf_notail": ["-DDFU3D_DBG_RF_NOTAIL"],
-    "rf_notail_noflags": ["-DDFU3D_DBG_RF_NOTAIL", "-DDFU3D_DBG_RF_NOFLAGS"],
-    # radius filter, tuning builds (correct results): the pairing of listed points inside k_rf_stream instead of k_rf_pair,
-    # list neighbours lane^1 / lane^2 or across the whole wave, grids, occupancy of phase B, ranges in flight
-    "rf_fused": ["-DDFU3D_RF_FUSED"],
-    "rf_forward": ["-DDFU3D_RF_REVERSE=0"],
-    # ball query: two / four consecutive query tiles per workgroup (one table build for them when they share the instance)
-    "ball_tpw2": ["-DDFU3D_BALL_TPW=2"], "ball_tpw4": ["-DDFU3D_BALL_TPW=4"],
-    # ball query: one record per workgroup -- start, duration, the instance's sizes, longest chain walk (tools/ball_timing.py)
-    "ball_timing": ["-DDFU3D_DBG_BALL_TIMING"],
-    "rf_quad": ["-DDFU3D_RF_NBR=0"],
-    "rf_wave": ["-DDFU3D_RF_NBR=2"],
-    "rf_g2048": ["-DDFU3D_RF_GRID=2048"],
-    "rf_g4096": ["-DDFU3D_RF_GRID=4096"],
-    "rfb_occ8": ["-DDFU3D_RFB_OCC=8"],
-    "rfb_occ6": ["-DDFU3D_RFB_OCC=6"],
-    "rf_ul4": ["-DDFU3D_RF_UL=4"],
-    # k_bp_vox: which of its accesses cost what (wrong results; tools/vox_traffic.sh)
-    "vox_skip1": ["-DDFU3D_DBG_VOX_SKIP=1"], "vox_skip2": ["-DDFU3D_DBG_VOX_SKIP=2"],
-    "vox_skip8": ["-DDFU3D_DBG_VOX_SKIP=8"], "vox_skip11": ["-DDFU3D_DBG_VOX_SKIP=11"],
-    # k_bp_vox: two / one workgroup per compute unit instead of three (correct results)
-    "vox_2wg": ["-DDFU3D_VOX_LDS_PAD=40960"], "vox_1wg": ["-DDFU3D_VOX_LDS_PAD=65536"],
-    "vox_occ6": ["-DDFU3D_VOX_OCC=6"], "vox_occ8": ["-DDFU3D_VOX_OCC=8"],
-    # k_bp_bin: register budgets for 6 / 8 workgroups per compute unit (the short LDS list of undecided pixels makes room)
-    "p1_occ6": ["-DDFU3D_P1_OCC=6"], "p1_occ8": ["-DDFU3D_P1_OCC=8"],
+    # cycles between the DBG_T marks of a kernel, summed over its workgroups (tools/p1_timing.py)
+    "timing": ["-DDFU3D_DBG_TIMING"],
 }
 
 

@@ -149,10 +149,6 @@ def lib():
     # library is dlopen'ed so that both resolve the SAME libamdhip64 (otherwise torch's
     # streams and device pointers are foreign to our launches: hipErrorInvalid*).
     import torch  # noqa: F401
-    variant = os.environ.get("DFU3D_LIB_VARIANT")     # dev: a tuning build of the same sources (_build.VARIANTS)
-    if variant:
-        _LIB = load_variant(variant)
-        return _LIB
     path = _build.OUT
     try:
         _build.build()          # no-op when the library is newer than every source
@@ -177,7 +173,8 @@ def lib():
 
 
 def load_variant(name):
-    """A test build of the library (dfu3d_amd/_build.py: VARIANTS) with the product's signatures."""
+    """A test / timing build of the library (dfu3d_amd/_build.py: VARIANTS) with the product's signatures.  For tests/ and
+    tools/ only: lib() never returns one, whatever the environment says."""
     import torch  # noqa: F401
     path = _build.build_variant(name)        # no-op when newer than every source
     L = ctypes.CDLL(path)

@@ -55,6 +55,10 @@ __device__ __forceinline__ int block_rank(bool flag, int *s_w, int &block_total)
 // Register moves between lanes without the LDS path: data-parallel-primitive modifiers.  A lane whose source lies
 // outside its row (or whose row the row mask leaves out) gets `old`.  (__shfl_up / __shfl_xor are ds_bpermute: an LDS
 // round trip each, and a scan or a reduction is six of them in a row.)
+// PRECONDITION of every helper built on them (wave_incl_scan, wave_sum_i, wave_min_i_dpp, wave_or_u32_dpp, wave_min_d,
+// wave_max_d, and nbr_f / nbr_u of the radius filter): ALL 64 lanes of the wave are active at the call and blockDim.x is a
+// multiple of 64.  An inactive source lane leaves `old` in its reader, and if lane 63 is inactive the value read back
+// from it is stale for the whole wave -- call them from wave-uniform control flow only (every call site is).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_move_i(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);

@@ -128,11 +128,6 @@ __device__ __forceinline__ int uf_unite(const P &par, int a, int b) {
 //      or s > S_HI (sqrt(s) > every R); only the thin band in between evaluates
 //      the reference's sqrt expression (rectangle_fitting.py:167-170).
 // None of the prunes changes a decision, so the labels equal the reference's.
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-#define CT_STAMP(k) do { const long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
-#else
-#define CT_STAMP(k) do {} while (0)
-#endif
 
 template <class P, int NGRP>
 __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s_box,
@@ -141,11 +136,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
                                              int n, double R0, double Rd, const int *perm,
                                              int *tmp, int *glabel) {
   constexpr int NBLK = (NGRP + BLK - 1) / BLK;
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-  long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long dbg_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks, descended, boxtests(max lane), slow groups, slow iters, unites(lane0), early exits, -
-  long long dbg_t = clock64();
-#endif
   const int ngrp_all = min((n + GRP - 1) / GRP, NGRP);
   double r2max = 0.0;
   for (int i = threadIdx.x; i < n; i += CT) {
@@ -182,12 +172,10 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
   const double S_HI = Rmax * Rmax * (1.0 + 1e-9);      // s > S_HI  => sqrt(s) > every R_i
   const double S_LO = R0 * R0 * (1.0 - 1e-12);         // s <= S_LO => sqrt(s) <= R0 <= R_i
 
-  CT_STAMP(0);
   for (int c0 = 0; c0 < n; c0 += CT) {
     // flatten + summarise everything before this chunk
     for (int k = threadIdx.x; k < c0; k += CT) par.flatten(k, uf_find(par, k));
     __syncthreads();
-    CT_STAMP(1);
     const int ngrp = min(c0 / GRP, NGRP);
     for (int g = threadIdx.x; g < ngrp; g += CT) s_summ[g] = par.group_root(g);
     __syncthreads();
@@ -199,7 +187,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
       s_summ2[B] = (r >= 0 && !diff) ? r : -1;
     }
     __syncthreads();
-    CT_STAMP(2);
     const int nblk_sum = ngrp / BLK;
     const int i = c0 + threadIdx.x;
     const bool act = i < n;
@@ -232,9 +219,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         }
       }
       if (!__any(need)) return;                                 // wave-uniform
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-      dbg_cnt[3]++;
-#endif
       // the wave fetches the group's 32 points once (one coalesced load each)
       const int jl = jg + (lane & (GRP - 1));
       const bool in = jl < n;
@@ -243,9 +227,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
       // one set and all 32 points already belong to it (own-chunk groups mostly)
       const int r_first = rl_i(ri, max(__ffsll((unsigned long long)__ballot(need)) - 1, 0));
       if (__all(!need || ri == r_first) && __all(!in || pg == r_first)) {
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-        dbg_cnt[6]++;
-#endif
         return;
       }
       const double xg = in ? X[jl] : 0.0, yg = in ? Y[jl] : 0.0;
@@ -256,9 +237,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
           const int rf = rl_i(ri, max(__ffsll((unsigned long long)__ballot(need)) - 1, 0));
           if (__all(!need || ri == rf) && __all(!in || pg == rf)) break;
         }
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-        dbg_cnt[4]++;
-#endif
         const int pj = rl_i(pg, k);
         const double xj = rl_d(xg, k), yj = rl_d(yg, k);
         if (need && (jg + k < i) && pj != ri) {                 // (3) not in my set (yet)
@@ -271,18 +249,12 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
             const double d = sqrt(sq);                          // rectangle_fitting.py:169
             adj = (d <= Ri) || (d <= R0 + Rd * sqrt(xj * xj + yj * yj));
           }
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-          if (adj) dbg_cnt[5]++;
-#endif
           if (adj) ri = uf_unite(par, ri, jg + k);
         }
       }
     };
     for (int B = (gc + BLK - 1) / BLK - 1; B >= 0; B--) {
       const int g_lo = B * BLK, g_hi = min(g_lo + BLK, gc);
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-      dbg_cnt[0]++;
-#endif
       bool need2 = act;
       if (need2 && B < NBLK) {
         if (B < nblk_sum && s_summ2[B] == ri) need2 = false;    // (1) whole block is mine
@@ -294,9 +266,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         }
       }
       if (!__any(need2)) continue;                              // wave-uniform
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-      dbg_cnt[1]++;
-#endif
       if (g_lo >= NGRP) {                                       // beyond the summarised range
         for (int g = g_hi - 1; g >= g_lo; g--) visit_group(g, need2);
         continue;
@@ -309,9 +278,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
 #pragma unroll 8
         for (int q = 0; q < BLK; q++)
           mm |= (q < ng && s_summ[g_lo + q] != ri) ? (1u << q) : 0u;
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-        dbg_cnt[2] += __popc(mm);
-#endif
         while (mm) {
           const int q = __ffs((int)mm) - 1;
           mm &= mm - 1u;
@@ -330,14 +296,10 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
         visit_group(g_lo + q, need2 && ((cand >> q) & 1u));
       }
     }
-    CT_STAMP(3);
     __syncthreads();     // every point of the chunk has met the earlier points: own-chunk groups mostly exit early
-    CT_STAMP(4);
     for (int g = gc; g < gend; g++) visit_group(g, act);
-    CT_STAMP(5);
     __syncthreads();
   }
-  CT_STAMP(6);
   // Back to the reference's labelling: smallest ORIGINAL index of each cluster.
   for (int i = threadIdx.x; i < n; i += CT) {
     par.flatten(i, uf_find(par, i));
@@ -362,15 +324,6 @@ __device__ __forceinline__ void cluster_body(const P par, int *s_summ, float4 *s
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += CT)
     glabel[perm[i]] = __hip_atomic_load(&tmp[par.load(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef DFU3D_DBG_CLUSTER_TIMING
-  CT_STAMP(7);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 8; k++) {
-      ((long long *)(tmp))[(threadIdx.x >> 6) * 8 + k] = dbg_acc[k];
-      ((long long *)(tmp))[64 + (threadIdx.x >> 6) * 8 + k] = dbg_cnt[k];
-    }
-#endif
 }
 
 // Counting sort of one instance's points by spatial cell (row-major cells of
@@ -531,18 +484,6 @@ __device__ __forceinline__ void cell_unite(int *par, int a, int b) {
   }
 }
 
-#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of wave 0 per phase of k_range_cluster_grid, summed over workgroups */
-__device__ unsigned long long g_grid_dbg[16];
-__device__ unsigned long long g_grid_max[8];
-#define GT_START() long long gt_t = clock64(); const long long gt_t0 = gt_t
-#define GT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_grid_dbg[k], (unsigned long long)(t_ - gt_t)); atomicMax(&g_grid_max[k], ((unsigned long long)(t_ - gt_t) << 24) | (unsigned long long)min(n, 0xFFFFFF)); gt_t = t_; } } while (0)
-#define GT_COUNT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_dbg[k], (unsigned long long)(v)); } while (0)
-#else
-#define GT_START() do {} while (0)
-#define GT_STAMP(k) do {} while (0)
-#define GT_COUNT(k, v) do {} while (0)
-#endif
-
 // -1: instance not eligible for this variant (NC_MIN < ncell <= NC handled here)
 template <int NC, int NC_MIN, int TCT>
 __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
@@ -567,9 +508,7 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
   // leave at once instead of measuring the instance again
   int *mark = perm_all + 2 * pool_cap + base;
   if (NC_MIN > 0 && *mark) return;                     // the smaller variant did it
-  GT_START();
   const GridGeom<NC> G = grid_geometry<NC, TCT>(X, Y, n, R0, Rd, s_red);
-  GT_STAMP(0);
   if (threadIdx.x == 0 && (NC_MIN == 0 || G.ok)) *mark = G.ok ? 1 : 0;
   if (!G.ok) return;                                   // too wide: a larger variant / the point-level kernels
   const int ncell = G.ncell;
@@ -616,8 +555,6 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
     }
   }
   __syncthreads();
-  GT_STAMP(1);
-  GT_COUNT(8, 1); GT_COUNT(9, n); GT_COUNT(10, ncell);
   // ---- link neighbouring cells ----------------------------------------------
   const double S_HI = G.Rmax * G.Rmax * (1.0 + 1e-9);
   const double S_LO = R0 * R0 * (1.0 - 1e-12);
@@ -753,9 +690,6 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
       }
       // the wave serves its lanes' remaining open pairs one at a time, all 64 lanes on the point pairs
       unsigned long long todo = __ballot(need);
-#ifdef DFU3D_DBG_GRID_TIMING
-      if (lane == 0 && todo) atomicAdd(&g_grid_dbg[11], (unsigned long long)__popcll(todo));
-#endif
       while (todo) {
         const int src = __ffsll(todo) - 1;
         todo &= todo - 1ull;
@@ -803,7 +737,6 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
       }
     }
     __syncthreads();
-    GT_STAMP(2 + round);
   }
   // ---- labels: smallest original index of the component ---------------------
   for (int c = threadIdx.x; c < ncell; c += TCT) s_min[c] = 0x7FFFFFFF;        // (held the cell boxes until here)
@@ -834,14 +767,6 @@ __global__ __launch_bounds__(TCT) void k_range_cluster_grid(
     for (int u = 0; u < GU; u++)
       if (i0 + u * TCT < n) glabel[pm[u]] = s_min[cell_find(s_par, grid_cell(G, xs[u], ys[u]))];
   }
-  GT_STAMP(4);
-#ifdef DFU3D_DBG_GRID_TIMING
-  if (threadIdx.x == 0) {
-    const unsigned long long tot = (unsigned long long)(clock64() - gt_t0);
-    atomicMax(&g_grid_dbg[12], (tot << 24) | (unsigned long long)min(n, 0xFFFFFF));
-    atomicMax(&g_grid_dbg[13], ((unsigned long long)n << 32) | (tot & 0xFFFFFFFFull));
-  }
-#endif
 }
 
 __global__ __launch_bounds__(CT) void k_range_cluster_small(
@@ -1742,21 +1667,10 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
   // (an instance is walked by ONE workgroup, and the longest instance is the tail of the stage: 1024 threads)
-#ifdef DFU3D_GRID_SPLIT_LAUNCH   /* measured alternative: 512 threads for the short instances in a launch of their own */
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 512>), dim3(S), dim3(512), 0,
-                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si, (long long)pool_cap, 0, GRID_LONG_N);
-  DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(S), dim3(1024), 0,
-                     (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
-                     label, sx, sy, si, (long long)pool_cap, GRID_LONG_N, 0x7FFFFFFF);
-  DFU3D_LAUNCH_CHECK();
-#else
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
   DFU3D_LAUNCH_CHECK();
-#endif
   hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL, 1024>), dim3(S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
@@ -1774,24 +1688,6 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   return DFU3D_OK;
 }
 
-#ifdef DFU3D_DBG_GRID_TIMING
-extern "C" int dfu3d_debug_grid_timing(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_grid_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_grid_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-extern "C" int dfu3d_debug_grid_max(unsigned long long *out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_grid_max), sizeof(unsigned long long) * 8) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    unsigned long long z[8] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_grid_max), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
 
 extern "C" int64_t dfu3d_lshape_fit_ws_doubles(int64_t pool_cap, int32_t cap_rows) {
   if (pool_cap <= 0 || cap_rows <= 0) return DFU3D_EINVAL;

@@ -44,6 +44,7 @@
 //       check fails (two keys differ only below the cut: practically never) and bins
 //       that saw more than max_points pixels are queued for the exact repair.
 #include "common.hpp"
+#include "dbg.hpp"
 
 namespace {
 
@@ -74,9 +75,7 @@ static_assert(DFU3D_TABLE_ENTRY_BYTES == 28, "table entry");
 // order-preserving key cut to its top (64 - pix_bits) bits | pixel index
 __device__ __forceinline__ unsigned long long combo_word(unsigned long long okey, uint32_t pix,
                                                          int pix_bits) {
-#ifdef DFU3D_DBG_COMBO_KEYBITS      /* test builds: provoke the scan of k_bp_vox */
-  okey &= ~0ull << (64 - DFU3D_DBG_COMBO_KEYBITS);
-#endif
+  if (DBG_COMBO_KEYBITS < 64) okey &= ~0ull << (64 - DBG_COMBO_KEYBITS);      // (test builds: provoke the repair of k_bp_vox)
   return ((okey >> pix_bits) << pix_bits) | (unsigned long long)pix;
 }
 
@@ -240,9 +239,7 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   // tier 1.5: one fp64 edge per bin boundary of the window behind the float32 tables, if the scratch holds them
   f.mid_ok = (f.dmax > 0.0f) && ((int64_t)f.tJ + f.pJ + 4 + (int64_t)g.t_n + g.p_n + 2 <= 2 * (int64_t)(TAB_T_MAX + TAB_P_MAX));
   f.pad1 = 0;
-#ifdef DFU3D_DBG_NO_MID              /* test build: every pixel / voxel tier 1 leaves undecided takes the full fp64 path */
-  f.mid_ok = 0;
-#endif
+  if (DBG_NO_MID) f.mid_ok = 0;         // (test build: every pixel / voxel tier 1 leaves undecided takes the full fp64 path)
   f.pad0 = 0.0f;
   return f;
 }
@@ -526,22 +523,11 @@ __device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Reci
 // atomics per touched bin instead of one per pixel (6x fewer for dense depth).
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
-#ifdef DFU3D_DBG_GRID_TIMING      /* dev build: cycles of thread 0 per phase of k_bp_bin, summed over workgroups (tools/p1_timing.py) */
-__device__ unsigned long long g_p1_dbg[16];
-#define P1_T(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_p1_dbg[k], (unsigned long long)(t_ - p1_t)); p1_t = t_; } } while (0)
-#else
-#define P1_T(k) do {} while (0)
-#endif
-#ifndef DFU3D_P1_AMB
-#define DFU3D_P1_AMB 256
-#endif
-constexpr int P1_AMB = DFU3D_P1_AMB;               // undecided pixels a workgroup of k_bp_bin lists in LDS
-#ifndef DFU3D_P1_OCC
-#define DFU3D_P1_OCC 5
-#endif
+constexpr int P1_AMB = 256;                        // undecided pixels a workgroup of k_bp_bin lists in LDS
+constexpr int P1_OCC = 5;                          // workgroups per compute unit the register budget is cut for (6 / 8 spilled: 3.98 / 6.11 ms against 3.23)
 constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
                                                    // the window set-up, its flush and the reductions are paid once per 2048 pixels
-__global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
+__global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib,
     const FastCal *__restrict__ fastcal, const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
     int tiles_x, int tiles_y, int key_axis,
@@ -554,10 +540,8 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   __shared__ unsigned long long s_kmin[WIN_T * WIN_P], s_combo[WIN_T * WIN_P];
   __shared__ uint32_t s_cnt[WIN_T * WIN_P], s_first[WIN_T * WIN_P];
   __shared__ int s_namb, s_t0, s_p0;
-#ifdef DFU3D_DBG_GRID_TIMING
-  long long p1_t = clock64();
-  if (threadIdx.x == 0) atomicAdd(&g_p1_dbg[8], 1ull);
-#endif
+  DBG_T_START();
+  DBG_T_COUNT(8);
   const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
@@ -584,7 +568,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   static_assert(TILE_W == 64, "tile-local pixel index");
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
-  P1_T(0);                                        // set-up: records, window reset, barrier
+  DBG_T(0);                                        // set-up: records, window reset, barrier
   uint32_t bins[RPT][PPT];
   double keys[RPT][PPT];
   int its[RPT][PPT], ips[RPT][PPT];
@@ -631,7 +615,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       slot++;
     }
   }
-  P1_T(1);                                        // depth loads, classification, exact keys (thread 0's wave)
+  DBG_T(1);                                        // depth loads, classification, exact keys (thread 0's wave)
   // window origin: wave minimum first (all lanes), then one LDS atomic per wave -- 256 lanes on two
   // addresses serialise
   tmin = wave_min_i_dpp(tmin);
@@ -639,7 +623,7 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
   if (lane_id() == 0 && tmin != 0x7FFFFFFF) { atomicMin(&s_t0, tmin); atomicMin(&s_p0, pmin); }
   __syncthreads();
   const int t0 = s_t0, p0 = s_p0;
-  P1_T(2);                                        // origin reduction + barrier (= waiting for the slowest wave's classification)
+  DBG_T(2);                                        // origin reduction + barrier (= waiting for the slowest wave's classification)
   // every kept pixel goes to the LDS window on its own.  (Round 2 merged the runs of equal bins among a thread's four
   // consecutive pixels first: fewer LDS atomics, but the bookkeeping of the runs took more vector instructions than the
   // atomics it saved -- the kernel is bound by vector issue, not by the LDS.)
@@ -655,10 +639,6 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       const unsigned long long ok = ordered_key(keys[r][k]);
       const unsigned long long cm = combo_word(ok, base + k, pix_bits);
       const uint32_t lt = (uint32_t)(its[r][k] - t0), lp = (uint32_t)(ips[r][k] - p0);
-#ifdef DFU3D_DBG_P1_NO_COMMIT         /* timing experiment only: results are wrong */
-      if (lt == 12345u) s_cnt[0] = (uint32_t)cm;
-      continue;
-#endif
       if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {      // aggregate in the LDS window
         const uint32_t w = __umul24(lt, (uint32_t)WIN_P) + lp;     // (24-bit multiplies issue at four times the rate of v_mul_lo_u32)
         atomicAdd(&s_cnt[w], 1u);
@@ -714,9 +694,9 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       }
     }
   }
-  P1_T(3);                                        // LDS window atomics
+  DBG_T(3);                                        // LDS window atomics
   __syncthreads();
-  P1_T(4);                                        // barrier
+  DBG_T(4);                                        // barrier
   // flush the window: one set of global atomics per touched bin.  The atomic on `first` returns the value it replaced
   // (the bit-map update below needs it): all of a thread's atomics are issued before the first returned value is looked
   // at -- one memory round trip per workgroup instead of one per slot of the thread.
@@ -728,9 +708,6 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
     f_loc[i] = 0u; f_new[i] = NOBIN; f_old[i] = 0u;
     const uint32_t cw = (w < WIN_T * WIN_P) ? s_cnt[w] : 0u;
     if (cw == 0u) continue;
-#ifdef DFU3D_DBG_P1_NO_FLUSH          /* timing experiment only: results are wrong */
-    continue;
-#endif
     static_assert(WIN_T * WIN_P <= 768 && WIN_P == 48, "w / 48 as (w * 1366) >> 16 is exact below 768 * 48 / 18");
     const uint32_t wq = __umul24((uint32_t)w, 1366u) >> 16, wr = (uint32_t)w - __umul24(wq, (uint32_t)WIN_P);   // w / 48, w % 48
     const uint32_t b = __umul24((uint32_t)t0 + wq, (uint32_t)g.p_n) + ((uint32_t)p0 + wr);
@@ -745,9 +722,9 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
 #pragma unroll
   for (int i = 0; i < FL; i++)
     if (f_old[i] > f_new[i]) new_first(f_loc[i], f_old[i]);      // (f_new = NOBIN, the largest value, for an idle slot)
-  P1_T(5);                                        // flush loop (issue of the global atomics)
+  DBG_T(5);                                        // flush loop (issue of the global atomics)
   __syncthreads();
-  P1_T(6);                                        // barrier
+  DBG_T(6);                                        // barrier
   // the workgroup's own bits: contiguous 128-byte wave atomics, one per bit-map tile (XOR: other tiles may already
   // have toggled here)
   if (threadIdx.x < 32 * RPT && s_bits[threadIdx.x]) {
@@ -756,21 +733,11 @@ __global__ __launch_bounds__(PB, DFU3D_P1_OCC) void k_bp_bin(
       atomicXor(&bitmap_v[((size_t)(ty * RPT + sub) * tiles_x + tx) * 32 + (threadIdx.x & 31)], s_bits[threadIdx.x]);
   }
   const int na = min(s_namb, P1_AMB);
-  P1_T(7);                                        // bit-map flush
+  DBG_T(7);                                        // bit-map flush
   for (int i = threadIdx.x; i < na; i += PB)      // (what the middle tier left: in practice nothing)
     if (s_amb[i] != NOBIN) amb_list[(size_t)v * HW + atomicAdd(&n_amb[v], 1)] = s_amb[i];
 }
 
-#ifdef DFU3D_DBG_GRID_TIMING
-extern "C" int dfu3d_debug_p1_timing(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_p1_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_p1_dbg), z, sizeof(z)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
 
 // Tier 2: the undecided pixels, full fp64 classification (pixel_bin).
 __global__ __launch_bounds__(256) void k_bp_bin_amb(
@@ -878,39 +845,22 @@ __device__ __forceinline__ VoxCtx make_vox_ctx(const ViewCalib *calib, int v, vo
 
 // voxel k of view v lives in bin b: representative, outputs, table entry left clean (or queued for the repair)
 __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, int v, int k, uint32_t b,
-                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status, uint32_t f_dbg = 0u) {
+                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status) {
   const Table &T = X.T;
   const int64_t e = X.tb0 + b;
   // the three planes of the entry are requested together, and so are the two reads that hang on the representative
   // pixel (its depth and its mask word): four dependent round trips per voxel instead of six
-#ifndef DFU3D_DBG_VOX_SKIP
-#define DFU3D_DBG_VOX_SKIP 0       /* dev builds (wrong results): which accesses of P4 cost what -- 1: no table reads, 2: no reads at the
-                                      representative pixel, 8: no table reset (tools/vox_traffic.sh) */
-#endif
-#if DFU3D_DBG_VOX_SKIP & 1
-  const uint32_t cw = 1u;
-  unsigned long long e_combo = (unsigned long long)f_dbg, e_kmin = 0ull;
-#else
   const uint32_t cw = T.cnt[e];
-  unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
-#endif
+  const unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
   const uint32_t pix = (uint32_t)(e_combo & ((1ull << X.pix_bits) - 1ull));
   const int row = (int)pix / X.W, col = (int)pix - row * X.W;
-#if DFU3D_DBG_VOX_SKIP & 2
-  const float d_pix = 10.0f + (float)(pix & 1023u) * 0.01f;
-  const uint32_t m_bits = pix & 1u;
-#else
   const float d_pix = X.dv[pix];
   const uint32_t m_bits = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
-#endif
   double x, yy, z;
   pixel_to_lidar(X.c, X.rc, col, row, d_pix, x, yy, z);
   double key = (X.key_axis == 2) ? z : yy;
   key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
   // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
-#if DFU3D_DBG_VOX_SKIP & 1
-  e_kmin = ordered_key(key);
-#endif
   if (cw > (uint32_t)X.max_points || ordered_key(key) != e_kmin) {
     const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
     if (slot < X.cap_q) { q_bins[(size_t)v * X.cap_q + slot] = b; q_rank[(size_t)v * X.cap_q + slot] = k; }
@@ -926,12 +876,10 @@ __device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, i
     out.it_z[at] = z;
   }
   // leave the table clean for the next pass (rep is only ever written by the repair)
-#if !(DFU3D_DBG_VOX_SKIP & 8)
   T.kmin[e] = ~0ull;
   T.combo[e] = ~0ull;
   T.cnt[e] = 0u;
   T.first[e] = NOBIN;
-#endif
 }
 
 // ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
@@ -947,10 +895,7 @@ struct VoxPark {
   int *n;                                     // per view: parked voxels
   uint32_t *f, *k;                            // per view, HW slots each: first pixel, rank
 };
-#ifndef DFU3D_VOX_OCC
-#define DFU3D_VOX_OCC 1            /* waves per SIMD the register budget of P4 is cut for (1: whatever the code needs) */
-#endif
-__global__ __launch_bounds__(VXB, DFU3D_VOX_OCC) void k_bp_vox(
+__global__ __launch_bounds__(VXB) void k_bp_vox(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
     const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
@@ -1015,7 +960,7 @@ __global__ __launch_bounds__(VXB, DFU3D_VOX_OCC) void k_bp_vox(
       }
     }
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status, f);
+    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
   }
 }
 
@@ -1038,7 +983,7 @@ __global__ __launch_bounds__(256) void k_bp_vox_amb(
     double key_f;
     const uint32_t b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
     if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status, f);
+    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -1299,6 +1244,8 @@ __global__ void k_selftest_backproject(const ViewCalib *__restrict__ calib, cons
 
 }  // namespace
 
+DBG_T_READER(dfu3d_debug_timing_pixel)
+
 extern "C" int dfu3d_selftest_classify(const float *calib, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
                                        int32_t key_axis, int64_t n, uint64_t seed, double d_lo, double d_hi,
                                        void *scratch, uint64_t *out4, void *stream) {
@@ -1377,13 +1324,9 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
 static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
-#ifdef DFU3D_DBG_COMBO_KEYBITS
-  (void)HW; (void)max_points;
-  return cap_vox;                          // test builds provoke the repair for a large share of the bins
-#else
+  if (DBG_COMBO_KEYBITS < 64) return cap_vox;             // test builds provoke the repair for a large share of the bins
   const int64_t q = HW / (max_points + 1) + 1 + 4096;     // bins over the cap + room for key collisions
   return (int)(q < cap_vox ? q : cap_vox);
-#endif
 }
 
 extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
@@ -1469,10 +1412,10 @@ extern "C" int dfu3d_backproject_bin(
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-#ifndef DFU3D_VOX_LDS_PAD
-#define DFU3D_VOX_LDS_PAD 0        /* tuning builds: unused dynamic LDS, i.e. fewer workgroups of P4 per compute unit */
-#endif
-    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), DFU3D_VOX_LDS_PAD, st, depth, cal, fastcal, tab, *geom,
+    // the counter of parked voxels belongs to THIS phase: a caller that repeats it without DFU3D_BP_BIN must not meet
+    // the count of the pass before (k_bp_vox_amb would finish voxels whose entries are reset already)
+    if (hipMemsetAsync(park.n, 0, sizeof(int) * (size_t)V, st) != hipSuccess) return DFU3D_ELAUNCH;
+    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
                        fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
                        cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status, park);
     DFU3D_LAUNCH_CHECK();

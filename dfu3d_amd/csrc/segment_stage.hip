@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t shadow_word(int seg, double radius) {
 constexpr int SEG_WI = 256, SEG_STEPS = SEG_WI / 64;
 constexpr int SEG_WPB = 4;                          // waves (ranges) per workgroup
 constexpr int SEG_GX = 128;                         // workgroups per view at most (each loops over its ranges)
-static_assert(DFU3D_MAX_INST <= 32, "one lane per instance, instance bits in one 32-bit word");
+static_assert(DFU3D_MAX_INST == 32, "one lane per instance, instance bits in one 32-bit word; k_seg_scan: 32 x 32 threads");
 inline int seg_ranges(int cap_item) { return (cap_item + SEG_WI - 1) / SEG_WI; }
 
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) { return wave_or_u32_dpp(x); }
@@ -314,14 +314,8 @@ constexpr int RFB = 256;           // threads per phase-A workgroup
 constexpr int RF_IT = 8;           // 64-point chunks per wave
 constexpr int RF_WG = RFB * RF_IT; // pool positions per workgroup
 constexpr int RF_STRIDE = 8;       // nb_points > 1: lanes 0, 8, 16, ... of the chunk are broadcast
-#ifndef DFU3D_RF_OCC
-#define DFU3D_RF_OCC 8
-#endif
-constexpr int RF_OCC = DFU3D_RF_OCC;   // phase-A workgroups per compute unit the register allocation aims at
-#ifndef DFU3D_RF_GRID
-#define DFU3D_RF_GRID 8192
-#endif
-constexpr int RF_GRID = DFU3D_RF_GRID; // phase-A workgroups at most (2048 fit the chip at once)
+constexpr int RF_OCC = 8;          // phase-A workgroups per compute unit the register allocation aims at
+constexpr int RF_GRID = 8192;      // phase-A workgroups at most (2048 fit the chip at once; 2048 / 4096 measured no better)
 constexpr int RF_WLIST = 128;      // U slots of a range
 constexpr int RF_WIN = 16;         // the pairing looks at this many listed points before / behind a listed point
 constexpr int RF_PLDS = RF_WLIST + 2 * RF_WIN;
@@ -329,10 +323,7 @@ constexpr uint32_t RF_NOSEG = 0xFFFFu;
 constexpr int BOX_FLOATS = 16;     // per range: coherent min xyz, #listed | coherent max xyz, - | incoherent min xyz, - | incoherent max xyz, -
 constexpr int BOX_SHIFT = 9;       // a range = the 64 * RF_IT = 512 positions one wave of phase A walks
 constexpr float BOX_EMPTY = 3.0e38f;
-#ifndef DFU3D_RF_SC
-#define DFU3D_RF_SC 4
-#endif
-constexpr int RF_SC = DFU3D_RF_SC;     // chunks of a range / a short segment phase B has in flight
+constexpr int RF_SC = 4;           // chunks of a range / a short segment phase B has in flight
 constexpr int RF_DIRECT = 1024;    // phase B reads segments up to this size whole
 constexpr int RF_NEAR = 2;         // phase B looks at the U slots of its own range +- RF_NEAR first
 constexpr int RF_QSHARDS = 64;     // the queue of undecided points has 64 parts, each with its counter on a line of its own
@@ -385,22 +376,13 @@ __device__ __forceinline__ float wave_max63(float v) {
 
 // value of the lane before / behind (DPP row_shr:1 / row_shl:1: inside the rows of 16 lanes; the lane without such
 // a neighbour reads 0).  All 64 lanes must be active where this is called.
-#ifndef DFU3D_RF_NBR
-#define DFU3D_RF_NBR 1
-#endif
-#if DFU3D_RF_NBR == 0
-constexpr int RF_NB1 = 0xB1, RF_NB2 = 0x4E, RF_ND1 = 1, RF_ND2 = 2, RF_NXOR = 1;       // lane ^ 1, lane ^ 2 (quad permutes)
-#elif DFU3D_RF_NBR == 1
-constexpr int RF_NB1 = 0x111, RF_NB2 = 0x101, RF_ND1 = -1, RF_ND2 = 1, RF_NXOR = 0;    // row_shr:1, row_shl:1
-#else
-constexpr int RF_NB1 = 0x138, RF_NB2 = 0x130, RF_ND1 = -1, RF_ND2 = 1, RF_NXOR = 0;    // wave_shr:1, wave_shl:1
-#endif
+// (measured alternatives: quad permutes lane ^ 1 / lane ^ 2 -- same speed, 2.9 % of the bench pool listed instead of 2.5 %;
+// wave_shr:1 / wave_shl:1 across the rows -- the chunk loop 40 % longer)
+constexpr int RF_NB1 = 0x111, RF_NB2 = 0x101, RF_ND1 = -1, RF_ND2 = 1;    // row_shr:1, row_shl:1
 // the lane whose point lane `lane` tested as its neighbour number d (-1 where the permute reads nothing)
 __device__ __forceinline__ int rf_nbr_lane(int lane, int d) {
-  if (RF_NXOR) return lane ^ d;
   const int t = lane + d;
-  if (DFU3D_RF_NBR == 1) return ((t >> 4) == (lane >> 4)) ? t : -1;
-  return (t >= 0 && t < 64) ? t : -1;
+  return ((t >> 4) == (lane >> 4)) ? t : -1;
 }
 template <int CTRL>
 __device__ __forceinline__ float nbr_f(float v) {
@@ -452,21 +434,10 @@ __device__ __forceinline__ void rf_queue_push(const RfScratch &W, long long key,
   if (mine) W.queue[RF_QHDR + qs * W.qcap + g + __popcll(mask & ((1ull << lane) - 1ull))] = (int)gpos;
 }
 
-#ifdef DFU3D_DBG_RF_TIMING         /* dev build (tools/rf_timing.py): clock64 of lane 0 at the phase marks, one record per wave (plain stores) */
-constexpr int RF_DBG_WG = 32768, RF_DBG_F = 12;
-__device__ unsigned long long g_rf_recA[RF_DBG_WG * RF_DBG_F], g_rf_recP[RF_DBG_WG * RF_DBG_F], g_rf_recB[16384 * RF_DBG_F];
-#define RF_T(k) do { const long long t_ = clock64(); rf_rec[k] += (unsigned int)(t_ - rf_t); rf_t = t_; } while (0)
-#else
-#define RF_T(k) do {} while (0)
-#endif
 
 template <bool NB1>
 __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S, RfScratch W) {
-#ifdef DFU3D_RF_FUSED              /* tuning build: the pairing of the listed points at the end of the streaming wave (no k_rf_pair) */
-  __shared__ float4 s_e[RFB / 64][RF_PLDS];
-  __shared__ uint32_t s_p[RFB / 64][RF_WLIST];
-#endif
   long long n_used = n_max;
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
   const int lane = lane_id();
@@ -475,26 +446,17 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
   // (DFU3D_RF_REVERSE, default): k_seg_write has just written the shadow front to back, so the memory-side cache
   // holds its tail; a walk from the front misses, and what it brings in pushes out exactly the lines it would have
   // hit next (44 -> 52 us when the writer became a sequential pass); from the end the most recent lines are read first
-#ifndef DFU3D_RF_REVERSE
-#define DFU3D_RF_REVERSE 1
-#endif
   const long long n_tiles = (n_used + RF_WG - 1) / RF_WG;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long wg0 = (DFU3D_RF_REVERSE ? n_tiles - 1 - tile : tile) * RF_WG;
+    const long long wg0 = (n_tiles - 1 - tile) * RF_WG;
     const long long w0 = wg0 + (long long)wave * (64 * RF_IT);
     if (w0 >= n_used) continue;
-#ifdef DFU3D_DBG_RF_TIMING
-    unsigned int rf_rec[5] = {0};
-    long long rf_t = clock64();
-    const unsigned long long rf_r0 = wall_clock64();
-#endif
     // (positions at or beyond n_used are read all the same -- the scratch allocation extends megabytes beyond the
     // shadow proper -- and marked "no segment" afterwards: eight loads, no branch between them)
     float4 p[RF_IT];
 #pragma unroll
     for (int it = 0; it < RF_IT; it++) p[it] = pq[w0 + it * 64 + lane];
     const int lim = (int)min(n_used - w0, (long long)(64 * RF_IT));     // (scalar)
-    RF_T(0);
     const long long rg = w0 >> BOX_SHIFT;
     float4 *my_ent = W.uent + rg * RF_WLIST;
     uint32_t *my_pos = W.upos + rg * RF_WLIST;
@@ -533,9 +495,7 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
       }
       // decided here: inactive segments (r == 0: no filter; r < 0 / NaN: drop all) and the coherent points that
       // are not listed; a listed point gets its flag in phase A' (or B)
-#ifndef DFU3D_DBG_RF_NOFLAGS
       if (valid && !listed) W.flags[i] = active ? 1 : ((r == 0.0f) ? 1 : 0);
-#endif
       lx = min_raw(lx, coh ? x : BOX_EMPTY); ly = min_raw(ly, coh ? y : BOX_EMPTY); lz = min_raw(lz, coh ? z : BOX_EMPTY);
       hx = max_raw(hx, coh ? x : -BOX_EMPTY); hy = max_raw(hy, coh ? y : -BOX_EMPTY); hz = max_raw(hz, coh ? z : -BOX_EMPTY);
       const unsigned long long m = __ballot(listed);
@@ -545,10 +505,6 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
           if (slot < RF_WLIST) {
             my_ent[slot] = make_float4(x, y, z, __uint_as_float(wb));
             my_pos[slot] = (uint32_t)i | (coh ? 0u : RF_INCOH);
-#ifdef DFU3D_RF_FUSED
-            s_e[wave][RF_WIN + slot] = make_float4(x, y, z, __uint_as_float(wb));
-            s_p[wave][slot] = (uint32_t)i | (coh ? 0u : RF_INCOH);
-#endif
           } else {                     // slots full (a pathological range): the segment's overflow list and the queue
             const uint32_t seg = wb >> 16;
             if (!coh) {
@@ -564,7 +520,6 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
         run += __popcll(m);
       }
     }
-    RF_T(1);
     lx = wave_min63(lx); ly = wave_min63(ly); lz = wave_min63(lz);
     hx = wave_max63(hx); hy = wave_max63(hy); hz = wave_max63(hz);
     if (lane == 63) {
@@ -572,77 +527,6 @@ __global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
       o[0] = make_float4(lx, ly, lz, __int_as_float(min(run, RF_WLIST)));
       o[1] = make_float4(hx, hy, hz, 0.0f);
     }
-#ifdef DFU3D_RF_FUSED
-    {
-      // the listed points of this range against the RF_WIN listed points before / behind them (k_rf_pair's loop,
-      // without the neighbours' ranges), the box around the incoherent ones, flags, queue
-      const int n_own = min(run, RF_WLIST);
-      float4 *rec = (float4 *)(W.rrec + (size_t)rg * BOX_FLOATS);
-      __builtin_amdgcn_wave_barrier();
-      const bool v0 = lane < n_own, v1 = lane + 64 < n_own;
-      const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 q0 = v0 ? s_e[wave][RF_WIN + lane] : none;
-      const uint32_t p0 = v0 ? s_p[wave][lane] : 0u;
-      float4 q1 = none;
-      uint32_t p1 = 0u;
-      if (n_own > 64) {                              // uniform
-        if (v1) { q1 = s_e[wave][RF_WIN + 64 + lane]; p1 = s_p[wave][64 + lane]; }
-      }
-      {
-        const bool i0 = (p0 & RF_INCOH) != 0u, i1 = (p1 & RF_INCOH) != 0u;
-        float ux = min_raw(i0 ? q0.x : BOX_EMPTY, i1 ? q1.x : BOX_EMPTY), uy = min_raw(i0 ? q0.y : BOX_EMPTY, i1 ? q1.y : BOX_EMPTY),
-              uz = min_raw(i0 ? q0.z : BOX_EMPTY, i1 ? q1.z : BOX_EMPTY);
-        float vx = max_raw(i0 ? q0.x : -BOX_EMPTY, i1 ? q1.x : -BOX_EMPTY), vy = max_raw(i0 ? q0.y : -BOX_EMPTY, i1 ? q1.y : -BOX_EMPTY),
-              vz = max_raw(i0 ? q0.z : -BOX_EMPTY, i1 ? q1.z : -BOX_EMPTY);
-        if (n_own > 0) {                             // uniform
-          ux = wave_min63(ux); uy = wave_min63(uy); uz = wave_min63(uz);
-          vx = wave_max63(vx); vy = wave_max63(vy); vz = wave_max63(vz);
-        }
-        if (lane == 63) {
-          rec[2] = make_float4(ux, uy, uz, 0.0f);
-          rec[3] = make_float4(vx, vy, vz, 0.0f);
-        }
-      }
-      const int lo = RF_WIN, hi = RF_WIN + n_own;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        if (n_own <= h * 64) break;                  // uniform
-        const bool v = h ? v1 : v0;
-        const float4 q = h ? q1 : q0;
-        const uint32_t wa = __float_as_uint(q.w);
-        const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
-        const int ci = RF_WIN + h * 64 + lane;
-        int cnt = 0;
-#pragma unroll 1
-        for (int d0 = -RF_WIN; d0 <= RF_WIN; d0 += 4) {
-          float4 o[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) o[u] = s_e[wave][min(max(ci + d0 + u, 0), RF_PLDS - 1)];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int k = ci + d0 + u;
-            const float dx = q.x - o[u].x, dy = q.y - o[u].y, dz = q.z - o[u].z;
-            cnt += ((d0 + u <= RF_WIN) & (k >= lo) & (k < hi) & (__float_as_uint(o[u].w) == wa) & (dx * dx + dy * dy + dz * dz < thr2)) ? 1 : 0;
-          }
-          if (__ballot(v && cnt <= nb) == 0ull) break;
-        }
-        const bool pend = v && cnt <= nb;
-        const uint32_t gpos = (h ? p1 : p0) & ~RF_INCOH;
-        if (v) W.flags[gpos] = pend ? 0 : 1;
-        const unsigned long long mp = __ballot(pend);
-        if (mp) rf_queue_push(W, rg, mp, pend, gpos);
-      }
-      __builtin_amdgcn_wave_barrier();               // the next tile of this wave rewrites the list
-    }
-#endif
-#ifdef DFU3D_DBG_RF_TIMING
-    RF_T(2);
-    if (lane == 0 && rg < RF_DBG_WG) {
-      unsigned long long *o_ = g_rf_recA + (size_t)rg * RF_DBG_F;
-      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
-      o_[5] = 1; o_[6] = (unsigned long long)run; o_[8] = rf_r0; o_[9] = wall_clock64();
-    }
-#endif
   }
 }
 
@@ -661,10 +545,6 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float4 *my_e = s_e[wv];
   for (long long rg = (long long)blockIdx.x * 4 + wv; rg < n_rg; rg += (long long)gridDim.x * 4) {
-#ifdef DFU3D_DBG_RF_TIMING
-    unsigned int rf_rec[5] = {0};
-    long long rf_t = clock64();
-#endif
     // lane l < 3: the number of listed points of range rg - 1 + l (0 outside the used ranges)
     int nl = 0;
     {
@@ -695,7 +575,6 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
     // lanes 0 .. t_prev-1: the tail of the range before; lanes 32 .. 32+t_next-1: the head of the range behind
     if (lane < t_prev) eh = W.uent[(rg - 1) * RF_WLIST + n_prev - t_prev + lane];
     else if (lane >= 32 && lane - 32 < t_next) eh = W.uent[(rg + 1) * RF_WLIST + lane - 32];
-    RF_T(0);
     // LDS, list order: [RF_WIN - t_prev, RF_WIN) tail | [RF_WIN, RF_WIN + n_own) own | [.., + t_next) head
     __builtin_amdgcn_wave_barrier();
     if (v0) my_e[RF_WIN + lane] = q0;
@@ -745,14 +624,6 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
       const unsigned long long mp = __ballot(pend);
       if (mp) rf_queue_push(W, rg, mp, pend, gpos);
     }
-#ifdef DFU3D_DBG_RF_TIMING
-    RF_T(1);
-    if (lane == 0 && rg < RF_DBG_WG) {
-      unsigned long long *o_ = g_rf_recP + (size_t)rg * RF_DBG_F;
-      for (int k = 0; k < 5; k++) o_[k] = rf_rec[k];
-      o_[5] = 1; o_[6] = (unsigned long long)n_own; o_[7] = (unsigned long long)(hi - lo);
-    }
-#endif
   }
 }
 
@@ -856,10 +727,7 @@ __device__ __forceinline__ int rf_scan_range(const RfQuery &Q, long long rg, con
 }
 // the INCOHERENT listed points of up to RF_UL ranges (taken from the ballot mask mu; lane k holds range r0 + k and its
 // number of listed points nl) within the radius of the query.  Whole wave, uniform.
-#ifndef DFU3D_RF_UL
-#define DFU3D_RF_UL 4
-#endif
-constexpr int RF_UL = DFU3D_RF_UL;     // ranges / overflow-list loads in flight per lane
+constexpr int RF_UL = 4;           // ranges / overflow-list loads in flight per lane
 __device__ __forceinline__ int rf_count_slots(const RfQuery &Q, const RfScratch &W, unsigned long long &mu, long long r0, int nl,
                                               const double *px, const double *py, const double *pz) {
   const int lane = lane_id();
@@ -906,10 +774,8 @@ __device__ __forceinline__ int rf_count_slots(const RfQuery &Q, const RfScratch 
 }
 
 // Phase B: one wave per queued point, counting from scratch.
-#ifndef DFU3D_RFB_OCC
-#define DFU3D_RFB_OCC 5
-#endif
-__global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
+// (register budgets for 6 / 8 waves per SIMD spilled and were slower: 55 / 69 us against 37)
+__global__ __launch_bounds__(256, 5) void k_rf_resolve(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, const double *__restrict__ radius,
@@ -924,18 +790,12 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
   const int nq = __builtin_amdgcn_readlane(q_incl, 63);
   int *lq_tab = W.work + RF_WORK_HDR + 65536, *items = lq_tab + 4 * RF_LQ_CAP;
   for (int e = wave; e < nq; e += nwaves) {
-#ifdef DFU3D_DBG_RF_TIMING
-    unsigned int rf_rec[5] = {0};
-    long long rf_t = clock64();
-    int dbg_cand = 0;
-#endif
     const int part = __popcll(__ballot(q_incl <= e));
     const int before = part ? __builtin_amdgcn_readlane(q_incl, part - 1) : 0;
     RfQuery Q;
     if (!rf_load_query(Q, W.queue[RF_QHDR + part * W.qcap + (e - before)], n_max, pq, px, py, pz, seg_base, seg_cnt, radius, S)) continue;
     const int n = (int)(Q.end - Q.base);
     int cnt = 0, n_items = 0, lq = -1;
-    RF_T(0);
     if (n <= RF_DIRECT) {
       // a short segment (the LiDAR lists): every point of it, straight from the shadow
       const long long c_lo = Q.base >> 6, c_hi = (Q.end - 1) >> 6;
@@ -950,7 +810,6 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
           cnt += __popcll(__ballot(hit));
         }
       }
-      RF_T(1);
     } else {
       const long long r_lo = Q.base >> BOX_SHIFT, r_hi = (Q.end - 1) >> BOX_SHIFT, r_q = Q.i >> BOX_SHIFT;
       // (1) the listed points next door first: most queued points have their neighbours a few hundred positions away
@@ -962,10 +821,6 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
         unsigned long long mu = __ballot(nl > 0);
         while (mu && cnt <= nb) cnt += rf_count_slots(Q, W, mu, n_lo, nl, px, py, pz);
       }
-      RF_T(1);
-#ifdef DFU3D_DBG_RF_TIMING
-      rf_rec[3] = (cnt > nb) ? 1u : 0u;              // the ranges next door were enough
-#endif
       int n_inline = 0;
       for (long long r0 = r_lo; r0 <= r_hi && cnt <= nb; r0 += 64) {
         const long long rg = r0 + lane;
@@ -989,9 +844,6 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
           const int k = __ffsll((long long)m) - 1;
           m &= m - 1ull;
           n_inline++;
-#ifdef DFU3D_DBG_RF_TIMING
-          dbg_cand++;
-#endif
           cnt += rf_scan_range(Q, r0 + k, pq, n_used, px, py, pz);
         }
         if (m && cnt <= nb) {                          // the rest of this batch: work items
@@ -1010,10 +862,13 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
               items[2 * t + 1] = (int)rg;
             }
             n_items += c;
-#ifdef DFU3D_DBG_RF_TIMING
-            dbg_cand += c;
-#endif
           } else {                                     // tables full (never seen): read the ranges here after all
+            // the slots this wave was given and does not fill must not be read as items: k_rf_ranges takes
+            // min(work[16], RF_ITEM_CAP) slots, and what an earlier pass left in them would be counted for a live query
+            if (lq < RF_LQ_CAP && ((m >> lane) & 1ull)) {
+              const int t = ib + __popcll(m & ((1ull << lane) - 1ull));
+              if (t < RF_ITEM_CAP) items[2 * t] = -1;
+            }
             while (m && cnt <= nb) {
               const int k = __ffsll((long long)m) - 1;
               m &= m - 1ull;
@@ -1051,16 +906,6 @@ __global__ __launch_bounds__(256, DFU3D_RFB_OCC) void k_rf_resolve(
         W.flags[Q.i] = (cnt > nb) ? 1 : 0;
       }
     }
-#ifdef DFU3D_DBG_RF_TIMING
-    RF_T(2);
-    if (lane == 0 && wave < 16384) {
-      unsigned long long *o_ = g_rf_recB + (size_t)wave * RF_DBG_F;
-      for (int k = 0; k < 3; k++) o_[k] += rf_rec[k];
-      o_[3] += 1; o_[4] += (n <= RF_DIRECT) ? 1 : 0; o_[5] += (unsigned long long)dbg_cand;
-      o_[6] += (unsigned long long)((n + 511) / 512); o_[7] += (cnt > nb) ? 1 : 0; o_[8] += (unsigned long long)n;
-      o_[9] += rf_rec[3];
-    }
-#endif
   }
 }
 
@@ -1094,23 +939,6 @@ __global__ __launch_bounds__(256) void k_rf_ranges(
   }
 }
 
-#ifdef DFU3D_DBG_RF_TIMING
-extern "C" int dfu3d_debug_rf_timing(unsigned long long *out_a, unsigned long long *out_p, unsigned long long *out_b, int reset) {
-  if (out_a && hipMemcpyFromSymbol(out_a, HIP_SYMBOL(g_rf_recA), sizeof(g_rf_recA)) != hipSuccess) return DFU3D_ELAUNCH;
-  if (out_p && hipMemcpyFromSymbol(out_p, HIP_SYMBOL(g_rf_recP), sizeof(g_rf_recP)) != hipSuccess) return DFU3D_ELAUNCH;
-  if (out_b && hipMemcpyFromSymbol(out_b, HIP_SYMBOL(g_rf_recB), sizeof(g_rf_recB)) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    void *pa = nullptr, *pp = nullptr, *pb = nullptr;
-    if (hipGetSymbolAddress(&pa, HIP_SYMBOL(g_rf_recA)) != hipSuccess || hipGetSymbolAddress(&pp, HIP_SYMBOL(g_rf_recP)) != hipSuccess ||
-        hipGetSymbolAddress(&pb, HIP_SYMBOL(g_rf_recB)) != hipSuccess)
-      return DFU3D_ELAUNCH;
-    if (hipMemset(pa, 0, sizeof(g_rf_recA)) != hipSuccess || hipMemset(pp, 0, sizeof(g_rf_recP)) != hipSuccess ||
-        hipMemset(pb, 0, sizeof(g_rf_recB)) != hipSuccess)
-      return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
 
 // standalone use of the filter (no k_seg_write in front): float32 shadow of the given segments
 __global__ __launch_bounds__(QT) void k_shadow_build(
@@ -1248,10 +1076,7 @@ __device__ __forceinline__ uint32_t bh_hash(uint32_t ix, uint32_t iy, uint32_t i
   return h;
 }
 
-#ifdef DFU3D_DBG_BALL_TIMING       /* dev build (tools/ball_timing.py): one record per workgroup with a tile, plain stores */
-constexpr int BALL_REC = 1 << 17;
-__device__ unsigned long long g_ball_rec[2][BALL_REC][4];      // [build][tile]: start | cycles, na | nq | walked chain nodes (max over lanes)
-#endif
+constexpr int BALL_TPW = 1;        // consecutive query tiles per workgroup (2 / 4 measured slower: the kernels' durations follow their longest workgroups)
 template <int BT, int BH_MAX, int BH_HEADS>
 __global__ __launch_bounds__(BT) void k_ball_flags(
     const double *__restrict__ px, const double *__restrict__ py,
@@ -1262,20 +1087,10 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
   __shared__ unsigned long long s_node[BH_MAX];
   __shared__ uint32_t s_head[BH_HEADS];
   __shared__ int s_pending;
-#ifndef DFU3D_BALL_TPW
-#define DFU3D_BALL_TPW 1           /* consecutive query tiles per workgroup (tuning builds: 2, 4) */
-#endif
   const int ntile = tile_off[S];
-  int t = blockIdx.x * DFU3D_BALL_TPW;
+  int t = blockIdx.x * BALL_TPW;
   if (t >= ntile) return;
-#ifdef DFU3D_DBG_BALL_TIMING
-  const long long bt0 = wall_clock64();
-  long long bt1 = bt0, bt2 = bt0, bt3 = bt0;     // segment facts and query point loaded | table built | queries done
-  __shared__ unsigned int s_dbg_walk;
-  if (threadIdx.x == 0) s_dbg_walk = 0u;
-  unsigned int dbg_walk = 0u;
-#endif
-  const int t_end = min(t + DFU3D_BALL_TPW, ntile);
+  const int t_end = min(t + BALL_TPW, ntile);
   int s = find_segment(tile_off, S, t);
   const double inv = 16.0 / (C * (1.0 + 1e-5));  // quantisation: 16 units per C
   const double Cq = C * (1.0 + 1e-6);
@@ -1298,9 +1113,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     }
     double x = 0.0, y = 0.0, z = 0.0;
     if (valid) { x = px[bq + q]; y = py[bq + q]; z = pz[bq + q]; }
-#ifdef DFU3D_DBG_BALL_TIMING
-    if (__ballot(x != 12345.678)) bt1 = wall_clock64();      // (after the loads have arrived)
-#endif
     if (na <= BH_MAX && hashed_s != s) {         // (re)build the table -- uniform per workgroup
       int slots = 256;
       while (slots < 2 * na) slots <<= 1;
@@ -1326,9 +1138,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
       __syncthreads();
       hash_ok = (s_pending == 0);
       hashed_s = s;
-#ifdef DFU3D_DBG_BALL_TIMING
-      bt2 = wall_clock64();
-#endif
     }
     bool found = false;
     if (na <= BH_MAX && hash_ok) {
@@ -1363,9 +1172,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                            ez_ = min(sz_ ? sz_ - 1u : 0u, 31u);
             if (!qin || __umul24(ex_, ex_) + __umul24(ey_, ey_) + __umul24(ez_, ez_) <= 257u) {
               const int j = (int)node - 1;
-#ifdef DFU3D_DBG_BALL_TIMING
-              dbg_walk += 1u << 12;                          // exact tests in the upper bits
-#endif
               const double ex = x - px[ba + j], ey = y - py[ba + j], ez = z - pz[ba + j];
               double d = ex * ex;
               d += ey * ey;
@@ -1379,9 +1185,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
               test_node(node, wv);
               if (found) return;
               node = (uint32_t)(wv >> 51);
-#ifdef DFU3D_DBG_BALL_TIMING
-              dbg_walk++;
-#endif
               if (!node) return;
               wv = s_node[node - 1u];
             }
@@ -1414,9 +1217,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                   if (nd[c4]) {
                     test_node(nd[c4], wv[c4]);
                     nd[c4] = (uint32_t)(wv[c4] >> 51);
-#ifdef DFU3D_DBG_BALL_TIMING
-                    dbg_walk++;
-#endif
                   }
                 if (found) break;
 #pragma unroll
@@ -1432,9 +1232,6 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
         }
         flags[bq + q] = found ? 1 : 0;
       }
-#ifdef DFU3D_DBG_BALL_TIMING
-      bt3 = wall_clock64();
-#endif
       continue;
     }
     // brute force over LDS tiles (more LiDAR points than the table holds, or a huge extent)
@@ -1466,29 +1263,8 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     }
     if (valid) flags[bq + q] = found ? 1 : 0;
   }
-#ifdef DFU3D_DBG_BALL_TIMING
-  atomicMax(&s_dbg_walk, (dbg_walk >> 12) << 12 | min(dbg_walk & 0xFFFu, 0xFFFu));   // (ordered by exact tests first)
-  __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.x < BALL_REC) {
-    const int s_ = find_segment(tile_off, S, blockIdx.x * DFU3D_BALL_TPW);
-    const int b_ = BT == BT_BIG ? 1 : 0;
-    g_ball_rec[b_][blockIdx.x][0] = ((unsigned long long)(bt0 & 0xFFFFFFFFll) << 32) | (unsigned long long)((wall_clock64() - bt0) & 0xFFFFFFFFll);
-    g_ball_rec[b_][blockIdx.x][2] = ((unsigned long long)((bt1 - bt0) & 0xFFFFFll) << 40) | ((unsigned long long)((bt2 - bt1) & 0xFFFFFll) << 20) | (unsigned long long)((bt3 - bt2) & 0xFFFFFll);
-    g_ball_rec[b_][blockIdx.x][1] = ((unsigned long long)(unsigned)cnt_a[s_] << 40) | ((unsigned long long)(unsigned)(cnt_b[s_] & 0xFFFFF) << 20) | (unsigned long long)(s_dbg_walk & 0xFFFFF);
-  }
-#endif
 }
 
-#ifdef DFU3D_DBG_BALL_TIMING
-extern "C" int dfu3d_debug_ball_timing(unsigned long long *out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ball_rec), sizeof(g_ball_rec)) != hipSuccess) return DFU3D_ELAUNCH;
-  if (reset) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ball_rec)) != hipSuccess || hipMemset(p, 0, sizeof(g_ball_rec)) != hipSuccess) return DFU3D_ELAUNCH;
-  }
-  return DFU3D_OK;
-}
-#endif
 
 // ---------------------------------------------------------------- compaction
 // In-order compaction of segment s by flags.  dst = src (in place) or, when
@@ -1744,12 +1520,10 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
       hipLaunchKernelGGL(k_rf_stream<false>, grid, dim3(RFB), 0, st, pq, (const long long *)n_used, (long long)pool_cap,
                          nb_points, S, W);
     DFU3D_LAUNCH_CHECK();
-#ifndef DFU3D_RF_FUSED
     const long long g_pair = ((long long)n_ranges + 3) / 4;                     // a wave per range
     hipLaunchKernelGGL(k_rf_pair, dim3((unsigned)(g_pair < 4096 ? g_pair : 4096)), dim3(256), 0, st, (const long long *)n_used,
                        (long long)pool_cap, nb_points, W);
     DFU3D_LAUNCH_CHECK();
-#endif
   }
   if (phases & DFU3D_RF_RESOLVE) {
     hipLaunchKernelGGL(k_rf_resolve, dim3(8192), dim3(256), 0, st, px, py, pz, pq, (const long long *)n_used,
@@ -1824,12 +1598,12 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_tile_scan_class, dim3(1), dim3(1024), 0, st, S, cnt_b, cnt_a, BH_MAX_SMALL, 0x7FFFFFFF, tile_big, BT_BIG);
   DFU3D_LAUNCH_CHECK();
-  const int g_small = (int)(((pool_cap + BT_SMALL - 1) / BT_SMALL + S + DFU3D_BALL_TPW - 1) / DFU3D_BALL_TPW);
+  const int g_small = (int)(((pool_cap + BT_SMALL - 1) / BT_SMALL + S + BALL_TPW - 1) / BALL_TPW);
   hipLaunchKernelGGL((k_ball_flags<BT_SMALL, BH_MAX_SMALL, BH_HEADS_SMALL>), dim3(g_small), dim3(BT_SMALL), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_small, flags, masked);
   DFU3D_LAUNCH_CHECK();
-  const int g_big = (int)(((pool_cap + BT_BIG - 1) / BT_BIG + S + DFU3D_BALL_TPW - 1) / DFU3D_BALL_TPW);
+  const int g_big = (int)(((pool_cap + BT_BIG - 1) / BT_BIG + S + BALL_TPW - 1) / BALL_TPW);
   hipLaunchKernelGGL((k_ball_flags<BT_BIG, BH_MAX_BIG, BH_HEADS_BIG>), dim3(g_big), dim3(BT_BIG), 0, st, px, py, pz,
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_big, flags, masked);

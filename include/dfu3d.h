@@ -187,7 +187,13 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
                           void *stream);
 /* `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
  * production; single phases let a caller bracket one kernel group with HIP events
- * on its stream).  The phases of one pass must be issued in this order. */
+ * on its stream).  The phases of one pass must be issued in this order, each once:
+ * BIN starts a pass (it zeroes the per-view counters and the first-pixel bit map and
+ * fills the table); AMB / MARK / VOX consume what BIN left and VOX resets every table
+ * entry it finishes, so a phase repeated without BIN in front of it finds nothing to do
+ * -- it must not be relied on to reproduce outputs.  Scratch aliasing: the lists of
+ * voxels VOX parks for its fp64 kernel live in `pix_bin`, which AMB reads and REPAIR
+ * rewrites; their per-view counter is zeroed by BIN and again at the start of VOX. */
 #define DFU3D_BP_BIN 1     /* k_bp_bin: back-project, bin, table atomics, touched-bin list          */
 #define DFU3D_BP_AMB 2     /* k_bp_bin_amb: the pixels float32 could not classify, in fp64           */
 #define DFU3D_BP_MARK 4    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix     */
