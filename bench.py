@@ -317,9 +317,6 @@ def main():
                          "dfu3d_pseudo_boxes; same kernels, same results)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2)")
-    ap.add_argument("--view-group", type=int, default=0,
-                    help="views per cache-resident group of the back-projection (dfu3d_backproject_bin: view_group); 0 = a "
-                         "chunk's views at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=16,
                     help="host processes of the 16-process CPU figure (0 = skip; forked before the GPU is initialised)")
@@ -393,7 +390,7 @@ def main():
     def make_engine(lanes, vpc):
         return PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=vpc, dense=dense, cap_vox=1 << 18,
                                pool_per_view=1 << 17, device=dev, lanes=lanes, graphs=args.graphs,
-                               chain=not args.no_chain, view_group=args.view_group)
+                               chain=not args.no_chain)
 
     eng = make_engine(args.lanes, views)
 
@@ -480,7 +477,6 @@ def main():
                                       "one bit-packed %d-byte word per pixel" % mask_word if mask_word else "uint8 planes",
                                       args.boxes[0], args.boxes[1]),
                        "frames_per_gpu_per_step": frames, "views_per_launch_chunk": views, "streams": args.lanes,
-                       "backprojection_view_group": args.view_group,
                        "boxes_per_step_all_ranks": n_boxes, "parallelism": "frames sharded x%d" % world},
             "hbm_copy_GBs_measured": round(copy_rate, 1),
         }
@@ -492,16 +488,13 @@ def main():
             alg = algorithmic_bytes(c1, V1, MAX_INST, mask_word)
             table = []
             for name, (ms, n) in sorted(kern.items(), key=lambda kv: -kv[1][0]):
-                # a stage that runs view group by view group has several launches per pass: bytes and duration are
-                # both per launch (their quotient is the same as per pass)
-                avg, per_pass = ms / n, n / tsteps
+                avg = ms / n
                 row = {"stage": name, "kernels": STAGE_KERNELS.get(name, [name]), "total_ms": round(ms, 3),
-                       "launches": n, "launches_per_pass": round(per_pass, 2), "avg_ms": round(avg, 4),
-                       "ms_per_pass": round(ms / tsteps, 4)}
+                       "launches": n, "avg_ms": round(avg, 4)}
                 if alg.get(name):
-                    row["alg_bytes_per_launch"] = int(alg[name] / per_pass)
-                    row["achieved_GBs"] = round(alg[name] / (ms / tsteps * 1e-3) / 1e9, 2)
-                    row["frac_of_peak"] = round(alg[name] / (ms / tsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    row["alg_bytes_per_launch"] = int(alg[name])
+                    row["achieved_GBs"] = round(alg[name] / (avg * 1e-3) / 1e9, 2)
+                    row["frac_of_peak"] = round(alg[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 table.append(row)
             out["kernels"] = table
             out["kernel_timing"] = {"how": "HIP events on the launch stream around every stage, %d passes after the timed "
@@ -523,7 +516,7 @@ def main():
                                              "(profiles/rNN_kernel_stats_bench_single_stream.csv)" % V1}
             rf = [r for r in table if r["stage"] in RF_STAGE]
             if rf:
-                ms_stage = sum(r["ms_per_pass"] for r in rf)
+                ms_stage = sum(r["avg_ms"] for r in rf)
                 gbs = alg["rf_stage"] / (ms_stage * 1e-3) / 1e9
                 fl = next((r for r in rf if r["stage"] == "rf_flags"), None)
                 traffic, tsrc = pmc_traffic([k for r in rf for k in r["kernels"]])
@@ -533,8 +526,8 @@ def main():
                               "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / copy_rate, 5),
                               "traffic": traffic},
                     "phase_A_stream_and_pair": None if fl is None else {
-                        "avg_ms": fl["ms_per_pass"], "achieved": round(alg["rf_stage"] / (fl["ms_per_pass"] * 1e-3) / 1e9, 2),
-                        "frac": round(alg["rf_stage"] / (fl["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                        "avg_ms": fl["avg_ms"], "achieved": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9, 2),
+                        "frac": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "points_per_launch": int(c1["pool_points"]),
                     "undecided_after_phase_A": int(c1.get("rf_undecided", 0))}
         if cpu_scenes is not None and world == 1:

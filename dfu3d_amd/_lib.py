@@ -46,7 +46,7 @@ class ChainCfg(ctypes.Structure):
         ("V", c_i32), ("H", c_i32), ("W", c_i32), ("max_inst", c_i32), ("cap_n", c_i32), ("cap_vox", c_i32),
         ("cap_rows", c_i32),
         ("dense", c_i32), ("apply_fov", c_i32), ("fov_h", c_i32), ("fov_w", c_i32), ("stat_filter", c_i32),
-        ("bounds_h", c_i32), ("bounds_w", c_i32), ("mask_format", c_i32), ("bp_view_group", c_i32),
+        ("bounds_h", c_i32), ("bounds_w", c_i32), ("mask_format", c_i32), ("reserved0", c_i32),
         ("pool_cap", c_i64),
         ("plane_max_hs", c_f64), ("plane_range", c_f64), ("plane_offset", c_f64),
         ("ransac_trials", c_i32), ("nb_points", c_i32),
@@ -81,7 +81,7 @@ SIGNATURES = {
                                                 ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32,
                                       ctypes.POINTER(BinGeom), c_i32, _P, _P, _P, c_i32, _P,
-                                      _P, _P, _P, _P, _P, _P, c_i32, c_i32, c_i32, _P]),
+                                      _P, _P, _P, _P, _P, _P, c_i32, _P]),
     "dfu3d_segments_build": (c_i32, [_P, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, _P, c_i32,
                                      c_i32, c_i32, c_i64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),

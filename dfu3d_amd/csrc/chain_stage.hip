@@ -228,7 +228,7 @@ extern "C" int dfu3d_pseudo_boxes(
   if (cfg->dense) {
     CHAIN_TRY(dfu3d_backproject_bin(depth, calib, masks, cfg->mask_format, n_inst, V, M, cfg->H, cfg->W, &cfg->geom, 1, w.table,
                                     w.pix_bin, w.blk_cnt, cfg->cap_vox, w.n_vox, w.vox_pix, w.b_bits, w.b_x,
-                                    w.b_y, w.b_z, status, DFU3D_BP_ALL, cfg->bp_view_group, 0, stream));
+                                    w.b_y, w.b_z, status, DFU3D_BP_ALL, stream));
   } else {
     if (hipMemsetAsync(w.n_vox, 0, sizeof(int32_t) * V, st) != hipSuccess) return DFU3D_ELAUNCH;
   }

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
     const FastCal *__restrict__ fastcal, const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
     int tiles_x, int tiles_y, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
-    int pix_bits, uint32_t *__restrict__ bitmap, int BW, int v0) {
+    int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
   __shared__ uint32_t s_bits[32 * RPT];           // this workgroup's piece of the first-pixel bit map (RPT bit-map tiles)
   // the workgroup's undecided pixels: a short list (0.7 % of the pixels are undecided: 14 of a tile's 2048; a list for
   // all 2048 took 8 KB of the workgroup's LDS); what does not fit goes to the global list one pixel at a time
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
   __shared__ int s_namb, s_t0, s_p0;
   DBG_T_START();
   DBG_T_COUNT(8);
-  const int v = v0 + blockIdx.y;
+  const int v = blockIdx.y;
   const int HW = H * W;
   const ViewCalib c = calib[v];
   const FastCal fc = fastcal[v];
@@ -744,8 +744,8 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
     int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, const int *__restrict__ n_amb,
     const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits,
-    uint32_t *__restrict__ bitmap, int BW, int tiles_x, int v0) {
-  const int v = v0 + blockIdx.y;
+    uint32_t *__restrict__ bitmap, int BW, int tiles_x) {
+  const int v = blockIdx.y;
   const int na = n_amb[v];
   const ViewCalib c = calib[v];
   const Recip rc = make_recip(c);
@@ -761,40 +761,41 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
 
-// ---- P3: exclusive popcount prefix of the bit map in raster order --------------------------------
-// item j = y * tiles_x + tx: the 64 pixels of image row y inside tile column tx (two words of the tile-major map).
-// A workgroup scans SCB consecutive items of a view and leaves the prefix INSIDE its block in wpre and the block's total
-// in bsum; the blocks' own prefix (at most 256 numbers per view) is formed by every workgroup of k_bp_vox for itself.
-// (Until round 4 one workgroup per view walked all items, 22 dependent steps for 1600 x 900 -- 39 us for 384 views at once,
-// but the same 39 us for a group of 16 views: the pass runs view group by view group now.)
+// ---- P3: exclusive popcount prefix of the bit map in raster order (one workgroup per view) ------
+// item j = y * tiles_x + tx: the 64 pixels of image row y inside tile column tx (two words of the tile-major map)
 constexpr int SCB = 1024;
-constexpr int SCB_SHIFT = 10;
-constexpr int SC_MAXB = 256;                  // blocks per view at most (k_bp_vox scans them with its 256 threads)
 __device__ __forceinline__ unsigned long long row_piece(const uint32_t *bitmap_v, int tiles_x, int y, int tx) {
   return *(const unsigned long long *)(bitmap_v + ((size_t)(y >> 4) * tiles_x + tx) * 32 + (y & 15) * 2);
 }
-__global__ __launch_bounds__(SCB) void k_bp_scan(int v0, int BW, int NJ, int NBS, int tiles_x, const uint32_t *__restrict__ bitmap,
-                                                 uint32_t *__restrict__ wpre, int *__restrict__ bsum) {
+__global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, const uint32_t *__restrict__ bitmap,
+                                                 uint32_t *__restrict__ wpre, int *__restrict__ n_vox, int cap_vox,
+                                                 uint32_t *__restrict__ status) {
   __shared__ int s_w[SCB / 64];
-  const int v = v0 + blockIdx.y;
+  const int v = blockIdx.x;
   const uint32_t *bv = bitmap + (size_t)v * BW;
-  const int j = blockIdx.x * SCB + threadIdx.x;
-  int c = 0;
-  if (j < NJ) {
-    const int y = j / tiles_x, tx = j - y * tiles_x;
-    c = __popcll(row_piece(bv, tiles_x, y, tx));
+  int running = 0;
+  for (int j0 = 0; j0 < NJ; j0 += SCB) {
+    const int j = j0 + threadIdx.x;
+    int c = 0;
+    if (j < NJ) {
+      const int y = j / tiles_x, tx = j - y * tiles_x;
+      c = __popcll(row_piece(bv, tiles_x, y, tx));
+    }
+    int tot;
+    const int ex = block_excl_scan<SCB / 64>(c, s_w, tot);
+    if (j < NJ) wpre[(size_t)v * NJ + j] = (uint32_t)(running + ex);
+    running += tot;
   }
-  int tot;
-  const int ex = block_excl_scan<SCB / 64>(c, s_w, tot);
-  if (j < NJ) wpre[(size_t)v * NJ + j] = (uint32_t)ex;
-  if (threadIdx.x == 0) bsum[(size_t)v * NBS + blockIdx.x] = tot;
+  if (threadIdx.x == 0) {
+    n_vox[v] = running;                                   // voxels = first pixels (clamped by k_bp_finalize)
+    if (running > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
+  }
 }
 
 // the bit map and its prefix: the rank of a first pixel = the voxel's place in first-seen order
 struct RankMap {
   const uint32_t *bitmap, *wpre;
-  const int *bsum;
-  int BW, NJ, NBS, tiles_x, W;
+  int BW, NJ, tiles_x, W;
 };
 struct VoxOut {
   uint32_t *vox_pix, *it_bits;
@@ -899,13 +900,11 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
     const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
-    uint32_t *__restrict__ status, VoxPark park, int v0, int *__restrict__ n_vox) {
+    uint32_t *__restrict__ status, VoxPark park) {
   __shared__ uint32_t s_vox[VX_PIECES * 64];
   __shared__ int s_wp[VX_PIECES];             // rank of the first voxel of each of the tile's row pieces
   __shared__ int s_w[VXB / 64];
-  __shared__ int s_bp[SC_MAXB];               // voxels of the view before each block of the scan
-  static_assert(SC_MAXB == VXB, "one thread per block of the scan");
-  const int v = v0 + blockIdx.y;
+  const int v = blockIdx.y;
   // A workgroup takes a 64-pixel-wide, VX_PIECES-row-high tile of the image, not a run of VX_PIECES row pieces of one
   // row: the bins of a table line (8 consecutive phi bins) have their first pixels on two or three neighbouring
   // rows, and with row strips those rows belonged to workgroups on different XCDs, each of which fetched (and
@@ -919,25 +918,14 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
   const int y = ty * VX_PIECES + lrow;
   uint32_t m16 = 0u;
   uint32_t ord = 0u;
-  const int bs = ((int)threadIdx.x < R.NBS) ? R.bsum[(size_t)v * R.NBS + threadIdx.x] : 0;
-  unsigned long long word = 0ull;
-  int wp_in = 0;                              // prefix of the row piece inside its block of the scan
-  const int jrow = y * R.tiles_x + tx;
   if (y < H) {
-    word = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
+    const unsigned long long word = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
     m16 = (uint32_t)(word >> (16 * quarter)) & 0xFFFFu;
     ord = (uint32_t)__popcll(word & ((1ull << (16 * quarter)) - 1ull));
-    if (quarter == 0 && word) wp_in = (int)R.wpre[(size_t)v * R.NJ + jrow];
+    if (quarter == 0) s_wp[lrow] = word ? (int)R.wpre[(size_t)v * R.NJ + (size_t)y * R.tiles_x + tx] : 0;
   }
   int tot;
-  s_bp[threadIdx.x] = block_excl_scan<VXB / 64>(bs, s_w, tot);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    n_vox[v] = tot;                           // voxels = first pixels (clamped by k_bp_finalize)
-    if (tot > cap_vox) atomicOr(status, DFU3D_ST_VOX_OVERFLOW);
-  }
-  __syncthreads();
-  if (y < H && quarter == 0) s_wp[lrow] = word ? wp_in + s_bp[jrow >> SCB_SHIFT] : 0;
-  int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);      // (its barriers publish s_wp as well)
+  int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);
   if (tot == 0) return;
   while (m16) {
     const int bpos = __ffs((int)m16) - 1;
@@ -982,8 +970,8 @@ __global__ __launch_bounds__(256) void k_bp_vox_amb(
     const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
     int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, VoxOut out, int key_axis,
     int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
-    uint32_t *__restrict__ status, VoxPark park, int v0) {
-  const int v = v0 + blockIdx.y;                  // ONE workgroup per view (gridDim.x == 1): it owns the view's counter
+    uint32_t *__restrict__ status, VoxPark park) {
+  const int v = blockIdx.y;                       // ONE workgroup per view (gridDim.x == 1): it owns the view's counter
   const int n = park.n[v];
   if (n == 0) return;
   const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
@@ -1334,9 +1322,9 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 
 // Scratch carve-up.
 // blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], n_park[V], bitmap[V*BW] -- everything up to here is
-//   zeroed at the start of a pass --, wpre[V*NJ], bsum[V*NBS], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
+//   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
 //   calibration constants (80 B per view) and the edge tables of tier 1 (8 B x (TAB_T_MAX + TAB_P_MAX + 4) at most; the carve-up keeps round 2's 16 B)
-//   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, NBS = blocks of the scan per view, cap_q: queue_cap)
+//   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
 static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
@@ -1351,10 +1339,10 @@ extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t
   if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1) return DFU3D_EINVAL;
   const int64_t HW = (int64_t)H * W;
   const int64_t tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-  const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x, NBS = (NJ + SCB - 1) / SCB;
+  const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW;
-  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + V * NBS + 3 * V * cap_q + 20 * (int64_t)V + 16 +
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 20 * (int64_t)V + 16 +
                               4 * (int64_t)(TAB_T_MAX + TAB_P_MAX) + 16;
   return 0;
 }
@@ -1364,7 +1352,7 @@ extern "C" int dfu3d_backproject_bin(
     int32_t V, int32_t max_inst, int32_t H, int32_t W, const dfu3d_bin_geom *geom,
     int32_t key_axis, void *table, uint32_t *pix_bin, int32_t *blk_cnt, int32_t cap_vox,
     int32_t *n_vox, uint32_t *vox_pix, uint32_t *it_bits, double *it_x, double *it_y,
-    double *it_z, uint32_t *status, int32_t phases, int32_t view_group, int32_t view0, void *stream) {
+    double *it_z, uint32_t *status, int32_t phases, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
   if (!depth || !calib || !geom || !table || !pix_bin || !blk_cnt || !n_vox || !vox_pix ||
       !it_bits || !it_x || !it_y || !it_z || !status)
@@ -1379,11 +1367,9 @@ extern "C" int dfu3d_backproject_bin(
   if (W % 4) return DFU3D_EINVAL;                    // float4 row loads
   if (geom->max_points_per_voxel < 1) return DFU3D_EINVAL;
   if (((uintptr_t)blk_cnt & 7u) != 0) return DFU3D_EINVAL;   // 64-bit counters in front
-  if (view_group < 0 || view0 < 0 || view0 >= V) return DFU3D_EINVAL;
   const int HW = (int)HW64;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-  const int BW = tiles_x * tiles_y * 32, NJ = H * tiles_x, NBS = (NJ + SCB - 1) / SCB;
-  if (NBS > SC_MAXB) return DFU3D_ERANGE;            // H * ceil(W / 64) <= 262144 row pieces
+  const int BW = tiles_x * tiles_y * 32, NJ = H * tiles_x;
   const int cap_q = queue_cap(HW64, geom->max_points_per_voxel, cap_vox);
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
@@ -1393,8 +1379,7 @@ extern "C" int dfu3d_backproject_bin(
   int *q_cursor = n_q + V;
   uint32_t *bitmap = (uint32_t *)(q_cursor + 2 * (size_t)V);
   uint32_t *wpre = bitmap + (size_t)V * BW;
-  int *bsum = (int *)(wpre + (size_t)V * NJ);
-  int *q_cnt = bsum + (size_t)V * NBS;
+  int *q_cnt = (int *)(wpre + (size_t)V * NJ);
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int *q_rank = (int *)(q_bins + (size_t)V * cap_q);
   FastCal *fastcal = (FastCal *)(((uintptr_t)(q_rank + (size_t)V * cap_q) + 15) & ~(uintptr_t)15);   // 80 B per view
@@ -1405,56 +1390,40 @@ extern "C" int dfu3d_backproject_bin(
   uint32_t *q_list = pix_bin + (size_t)V * HW;       // undecided pixels first, repair lists later
   const ViewCalib *cal = (const ViewCalib *)calib;
   const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
-  const RankMap R = {bitmap, wpre, bsum, BW, NJ, NBS, tiles_x, W};
+  const RankMap R = {bitmap, wpre, BW, NJ, tiles_x, W};
   // voxels parked by k_bp_vox: the counter is the fourth per-view word of the header, the lists sit where the bin ids
   // and pixel lists of the repair go (written after P4, read before it only by k_bp_bin_amb: free in between)
   const VoxPark park = {q_cursor + V, pix_bin, q_list};
 
-  // View groups.  The four main phases of a group run back to back (binning -> undecided pixels -> scan -> voxels), so
-  // that the voxel pass finds what the binning pass has just touched -- the group's table lines, its depth maps, its bit
-  // map -- in the memory-side cache (256 MiB; a view touches ~10 MB of table lines and 5.8 MB of depth) instead of
-  // re-reading it from HBM after the atomics of all the other views have pushed it out.  A call with all four main phases
-  // loops over the groups itself; a call with fewer of them (a caller bracketing single kernels) acts on the group that
-  // starts at view0.  The set-up (counters, bit map, per-view constants, edge tables) and the repair cover all V views.
-  const int MAIN = DFU3D_BP_BIN | DFU3D_BP_AMB | DFU3D_BP_MARK | DFU3D_BP_VOX;
-  const bool looped = (phases & MAIN) == MAIN;
-  const int G = (view_group > 0 && view_group < V) ? view_group : V;
-  const int g_first = looped ? 0 : view0, g_end = looped ? V : std::min(view0 + G, V);
-
-  if ((phases & DFU3D_BP_BIN) && g_first == 0) {      // start of a pass
+  if (phases & DFU3D_BP_BIN) {
     if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_tables, dim3((tables_threads(fg, *geom) + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);
     DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
+                       fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
+                       bitmap, BW);
+    DFU3D_LAUNCH_CHECK();
   }
-  for (int v0 = g_first; v0 < g_end; v0 += G) {
-    const int gv = std::min(G, g_end - v0);
-    if (phases & DFU3D_BP_BIN) {
-      hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), gv), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
-                         fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
-                         bitmap, BW, v0);
-      DFU3D_LAUNCH_CHECK();
-    }
-    if (phases & DFU3D_BP_AMB) {
-      hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, gv), dim3(256), 0, st, depth, cal, *geom, W, HW,
-                         key_axis, E_view, table, E_total, n_amb, q_list, status, pix_bits, bitmap, BW, tiles_x, v0);
-      DFU3D_LAUNCH_CHECK();
-    }
-    if (phases & DFU3D_BP_MARK) {
-      hipLaunchKernelGGL(k_bp_scan, dim3(NBS, gv), dim3(SCB), 0, st, v0, BW, NJ, NBS, tiles_x, bitmap, wpre, bsum);
-      DFU3D_LAUNCH_CHECK();
-    }
-    if (phases & DFU3D_BP_VOX) {
-      hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), gv), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
-                         fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
-                         cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status, park, v0, n_vox);
-      DFU3D_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_bp_vox_amb, dim3(1, gv), dim3(256), 0, st, depth, cal, *geom, masks, mask_format, n_inst, max_inst,
-                         W, HW, E_view, table, E_total, cap_vox, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status,
-                         park, v0);
-      DFU3D_LAUNCH_CHECK();
-    }
+  if (phases & DFU3D_BP_AMB) {
+    hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
+                       key_axis, E_view, table, E_total, n_amb, q_list, status, pix_bits, bitmap, BW, tiles_x);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_MARK) {
+    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, cap_vox, status);
+    DFU3D_LAUNCH_CHECK();
+  }
+  if (phases & DFU3D_BP_VOX) {
+    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
+                       fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
+                       cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status, park);
+    DFU3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bp_vox_amb, dim3(1, V), dim3(256), 0, st, depth, cal, *geom, masks, mask_format, n_inst, max_inst,
+                       W, HW, E_view, table, E_total, cap_vox, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status,
+                       park);
+    DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {
     // exact repair of the queued bins (more than max_points pixels, or a key collision below the cut of the

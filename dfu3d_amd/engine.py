@@ -66,7 +66,7 @@ class PseudoBoxEngine:
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
                  device="cuda:0", apply_fov: bool = True, lanes: int = 1, graphs: bool = False,
-                 chain: bool = False, view_group: int = 0):
+                 chain: bool = False):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         # H, W: the canvas of the masks and the depth maps.  The in-bounds test of my_loader.py:526 is
@@ -97,8 +97,6 @@ class PseudoBoxEngine:
         # points over a single workspace -- what a non-Python host would bind.  Per-kernel timing needs the
         # stage-by-stage path, so `timing` overrides it.
         self.chain = bool(chain)
-        # views per cache-resident group of the back-projection (dfu3d_backproject_bin: view_group); 0 = the chunk at once
-        self.view_group = int(view_group)
         self.graphs = bool(graphs)
         self._graph_key = None
         self._graph_state = None
@@ -178,7 +176,6 @@ class PseudoBoxEngine:
                 c.dtheta, c.car_aspect_max, c.stat_std_ratio = self.dtheta, p.car_aspect_max, p.stat_std_ratio
                 if self.dense:
                     c.geom = L.geom
-                c.bp_view_group = self.view_group
                 lib = st._lib.lib()
                 nbytes = int(lib.dfu3d_chain_workspace_bytes(c))
                 if nbytes <= 0:
@@ -316,18 +313,13 @@ class PseudoBoxEngine:
         self._count("fov_points", self.n_fov)
         self._count("label_rows", self.K)
         if self.dense and b.depth is not None:
-            bp_args = (b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
-                       self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
-                       self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y, self.b_z, status)
-            G = self.view_group if 0 < self.view_group < V else V
-            if not self.timing:
-                st.backproject_bin(*bp_args, phases=st.BP_ALL, mask_format=b.mask_format, view_group=G)
-            else:       # the same launches, every kernel of every view group bracketed on its own
-                for g0 in range(0, V, G):
-                    for tag, bit in (("bin", st.BP_BIN), ("amb", st.BP_AMB), ("mark", st.BP_MARK), ("vox", st.BP_VOX)):
-                        self._run("bp_" + tag, st.backproject_bin, *bp_args, phases=bit, mask_format=b.mask_format,
-                                  view_group=G, view0=g0)
-                self._run("bp_repair", st.backproject_bin, *bp_args, phases=st.BP_REPAIR, mask_format=b.mask_format)
+            self._phased("bp_", st.backproject_bin,
+                         (("bin", st.BP_BIN), ("amb", st.BP_AMB), ("mark", st.BP_MARK), ("vox", st.BP_VOX),
+                          ("repair", st.BP_REPAIR)),
+                         b.depth[v0:v1], calib, masks, n_inst, V, M, H, W, self.geom,
+                         self.E, 1, self.table, self.pix_bin, self.blk_cnt, self.cap_vox,
+                         self.n_vox, self.vox_pix, self.b_bits, self.b_x, self.b_y,
+                         self.b_z, status, mask_format=b.mask_format)
             self._count("voxels", self.n_vox)
             self._count("amb_pixels", self.blk_cnt[:V])
         else:

@@ -196,9 +196,7 @@ def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, mask
 
 def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_entries,
                     key_axis, table, pix_bin, blk_cnt, cap_vox, n_vox, vox_pix, it_bits, it_x,
-                    it_y, it_z, status, phases=BP_ALL, mask_format=MASK_BYTES, view_group=0, view0=0):
-    """view_group: views per cache-resident group of the four main phases (0: all at once); view0: the group a call
-    with fewer than the four main phases acts on (include/dfu3d.h)."""
+                    it_y, it_z, status, phases=BP_ALL, mask_format=MASK_BYTES):
     pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel)
     if table.data_ptr() % 8 or blk_cnt.data_ptr() % 8:
         raise Dfu3dError("table / blk_cnt: must be 8-byte aligned")
@@ -221,7 +219,7 @@ def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_
         _chk(it_x, "it_x", torch.float64, numel=V * cap_vox),
         _chk(it_y, "it_y", torch.float64, numel=V * cap_vox),
         _chk(it_z, "it_z", torch.float64, numel=V * cap_vox),
-        _chk(status, "status", torch.int32, min_numel=1), int(phases), int(view_group), int(view0), _stream())
+        _chk(status, "status", torch.int32, min_numel=1), int(phases), _stream())
     _lib.check(rc, "dfu3d_backproject_bin")
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 150          /* 0.1.5: view groups of dfu3d_backproject_bin (view_group, view0; dfu3d_chain_cfg.bp_view_group); 141: 128-byte scratch of dfu3d_selftest_backproject */
+#define DFU3D_VERSION 141          /* 0.1.4.1: 128-byte scratch of dfu3d_selftest_backproject; 140 = 0.1.4: radius-filter scratch sizes */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -184,16 +184,8 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
                           int32_t cap_vox, int32_t *n_vox, uint32_t *vox_pix,
                           uint32_t *it_bits, double *it_x, double *it_y,
                           double *it_z, uint32_t *status, int32_t phases,
-                          int32_t view_group, int32_t view0, void *stream);
-/* `view_group` = G > 0: the four main phases (BIN, AMB, MARK, VOX) run group by group of G
- * consecutive views, so that the voxel pass finds the table lines, depth maps and bit map its
- * group's binning pass has just touched in the 256 MiB memory-side cache; 0 (or >= V): all
- * views at once.  Results do not depend on it.  A call whose `phases` hold all four main
- * phases loops over the groups itself (view0 is ignored); a call with fewer of them acts on
- * the ONE group [view0, view0 + G) -- a caller that brackets single kernels issues the phases
- * group by group, BIN of the group at view0 = 0 first (it starts the pass).  REPAIR always
- * covers all V views and comes last.  Limit: H * ceil(W / 64) <= 262144 (DFU3D_ERANGE).
- * `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
+                          void *stream);
+/* `phases` selects which kernels of the stage a call enqueues (DFU3D_BP_ALL in
  * production; single phases let a caller bracket one kernel group with HIP events
  * on its stream).  The phases of one pass must be issued in this order, each once:
  * BIN starts a pass (it zeroes the per-view counters and the first-pixel bit map and
@@ -201,7 +193,7 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
  * entry it finishes, so a phase repeated without BIN in front of it finds nothing to do
  * -- it must not be relied on to reproduce outputs.  Scratch aliasing: the lists of
  * voxels VOX parks for its fp64 kernel live in `pix_bin`, which AMB reads and REPAIR
- * rewrites; their per-view counter is zeroed by BIN and again by VOX when it has consumed them. */
+ * rewrites; their per-view counter is zeroed by BIN and again by VOX once it has consumed them. */
 #define DFU3D_BP_BIN 1     /* k_bp_bin: back-project, bin, table atomics, touched-bin list          */
 #define DFU3D_BP_AMB 2     /* k_bp_bin_amb: the pixels float32 could not classify, in fp64           */
 #define DFU3D_BP_MARK 4    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix     */
@@ -484,7 +476,7 @@ typedef struct dfu3d_chain_cfg {
   int32_t V, H, W, max_inst, cap_n, cap_vox, cap_rows;
   int32_t dense, apply_fov, fov_h, fov_w, stat_filter;
   int32_t bounds_h, bounds_w;       /* my_loader.py:526 (<= H, W)           */
-  int32_t mask_format, bp_view_group;   /* DFU3D_MASK_BYTES or 1 / 2 / 4 | view_group of dfu3d_backproject_bin (0: all views at once) */
+  int32_t mask_format, reserved0;   /* DFU3D_MASK_BYTES or 1 / 2 / 4        */
   int64_t pool_cap;
   double plane_max_hs, plane_range, plane_offset;
   int32_t ransac_trials, nb_points;
