@@ -43,12 +43,12 @@ STAGE_KERNELS = {
     "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
                                           "k_bp_finalize"],
     "segments_build": ["k_seg_count", "k_seg_scan", "k_seg_alloc", "k_seg_write"],
-    "rf_flags": ["k_rf_stream", "k_rf_pair"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"], "rf_compact": ["k_seg_compact_short"],
+    "rf_flags": ["k_rf_stream"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"],
     "ballquery_fuse": ["k_tile_scan_class", "k_ball_flags", "k_seg_compact"],
     "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],
     "lshape_fit": ["k_fit_gather", "k_fit_tiny", "k_fit_medium", "k_fit_big_cost", "k_fit_big_box"],
 }
-RF_STAGE = ("rf_flags", "rf_resolve", "rf_compact")
+RF_STAGE = ("rf_flags", "rf_resolve")     # (the compaction of both lists is the fuse's: one launch for both filters)
 
 
 def algorithmic_bytes(c, views, max_inst, mask_word):

@@ -96,6 +96,8 @@ SIGNATURES = {
                                      _P]),
     "dfu3d_ballquery_fuse_masked": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,
                                      _P]),
+    "dfu3d_ballquery_fuse_joint": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,
+                                     _P]),
     "dfu3d_range_cluster": (c_i32, [_P, _P, _P, _P, c_i32, c_f64, c_f64, _P, _P, _P, _P, c_i64,
                                     _P]),
     "dfu3d_points_in_boxes_mask": (c_i32, [_P, c_i32, c_i32, _P, c_i32, _P, _P]),

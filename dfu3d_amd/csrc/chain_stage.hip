@@ -240,15 +240,12 @@ extern "C" int dfu3d_pseudo_boxes(
                                  w.chunk_cnt, stream));
   // a10 (+a11) + a12
   if (joint) {
-    // the shadow and the joint segment table come from the segment build; the LiDAR lists are compacted in
-    // place, the pseudo lists keep their flags for the masked fuse (one compaction for both filters)
+    // the shadow and the joint segment table come from the segment build; both lists keep their flags for the
+    // joint fuse (one compaction launch for both lists and both filters)
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_ab, w.cnt_ab, w.rad_ab, cfg->nb_points, 2 * S,
                                   cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
                                   DFU3D_RF_FLAGS | DFU3D_RF_RESOLVE, stream));
-    CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,
-                                  cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
-                                  DFU3D_RF_COMPACT | DFU3D_RF_SHORT_LISTS, stream));
-    CHAIN_TRY(dfu3d_ballquery_fuse_masked(w.px, w.py, w.pz, w.base_a, w.cnt_a, w.base_b, w.cnt_b, cfg->fuse_C,
+    CHAIN_TRY(dfu3d_ballquery_fuse_joint(w.px, w.py, w.pz, w.base_a, w.cnt_a, w.base_b, w.cnt_b, cfg->fuse_C,
                                           S, cfg->pool_cap, w.tile_off, w.flags, stream));
   } else {
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_a, w.cnt_a, inst_r_lidar, cfg->nb_points, S,

@@ -27,9 +27,11 @@ constexpr bool DBG_NO_MID = false;
 #ifdef DFU3D_DBG_TIMING
 constexpr int DBG_T_SLOTS = 32;
 static __device__ unsigned long long g_dbg_cycles[DBG_T_SLOTS];
-#define DBG_T_START() long long dbg_t_ = clock64()
+#define DBG_T_START() long long dbg_t_ = clock64(); const long long dbg_t0_ = dbg_t_; (void)dbg_t0_
 #define DBG_T(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_dbg_cycles[k], (unsigned long long)(t_ - dbg_t_)); dbg_t_ = t_; } } while (0)
 #define DBG_T_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_dbg_cycles[k], 1ull); } while (0)
+#define DBG_T_ADD(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_dbg_cycles[k], (unsigned long long)(v)); } while (0)
+#define DBG_T_MAX(k, v) do { if (threadIdx.x == 0) atomicMax(&g_dbg_cycles[k], (unsigned long long)(v)); } while (0)
 // at file scope, outside any namespace: int name(unsigned long long out[DBG_T_SLOTS], int reset)
 #define DBG_T_READER(name)                                                                                              \
   extern "C" int name(unsigned long long *out, int reset) {                                                            \
@@ -45,5 +47,7 @@ static __device__ unsigned long long g_dbg_cycles[DBG_T_SLOTS];
 #define DBG_T_START() do {} while (0)
 #define DBG_T(k) do {} while (0)
 #define DBG_T_COUNT(k) do {} while (0)
+#define DBG_T_ADD(k, v) do {} while (0)
+#define DBG_T_MAX(k, v) do {} while (0)
 #define DBG_T_READER(name)
 #endif

@@ -299,6 +299,8 @@ __device__ __forceinline__ int find_segment(const int *tile_off, int S, int t) {
 // comes within the radius (such a range is re-read and the coherence of its points re-derived with phase A's own
 // function, so every point of the segment is counted exactly once: through U slots or through its range).  The
 // first two such ranges are read by the wave itself, further ones become work items of k_rf_ranges.
+// The lists are NOT compacted here in the engine's path: the flags go to dfu3d_ballquery_fuse_joint, whose compaction
+// launch serves both lists and both filters.
 // History, all measured on the bench pool (11.5 M points; tools/rf_timing.py, tools/rf_variants.py):
 //  * round 2: phase B walked candidate ranges one after the other: 0.23 ms for 0.14 % of the points (a box that a
 //    pair of neighbouring outliers has blown up is a candidate for every query of its segment: one query had 71);
@@ -955,67 +957,6 @@ __global__ __launch_bounds__(QT) void k_shadow_build(
   }
 }
 
-// in-place ordered compaction of SHORT lists (the per-instance LiDAR lists): one workgroup per segment, 2048
-// positions per step; lane l of wave w looks after positions u * 256 + w * 64 + l (u < 8), so consecutive lanes read
-// consecutive positions and -- the ranks coming from ballots and ONE exchange of the 32 per-wave counts -- write
-// consecutive destinations; flags and coordinates are requested together (no load waits for another).
-// History: one wave per segment walking 64 (later 512) positions at a time was a chain of dependent round trips for
-// the longest list (0.03 / 0.02 ms for 0.36 M points); a thread per 8 CONSECUTIVE positions made every store
-// instruction of a wave touch 64 different 64-byte segments (the stores were half of the kernel's 26 us).
-// A destination never lies ahead of a source of the same or a later step, and every source of a step is in registers
-// before the barrier, i.e. before the first store of the step.
-constexpr int CS_T = 256, CS_E = 8;
-__global__ __launch_bounds__(CS_T) void k_seg_compact_short(
-    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-    const long long *__restrict__ seg_base, int *__restrict__ seg_cnt, const uint8_t *__restrict__ flags, int S) {
-  __shared__ int s_c[CS_E][CS_T / 64];
-  const int s = blockIdx.x;
-  const int n = seg_cnt[s];
-  if (n == 0) return;
-  const long long base = seg_base[s];
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  int running = 0;
-  for (int t0 = 0; t0 < n; t0 += CS_T * CS_E) {
-    bool f[CS_E];
-    double x[CS_E], y[CS_E], z[CS_E];
-#pragma unroll
-    for (int u = 0; u < CS_E; u++) {
-      const int i = t0 + u * CS_T + (int)threadIdx.x;
-      const bool in = i < n;
-      f[u] = in && flags[base + i];
-      x[u] = in ? px[base + i] : 0.0;
-      y[u] = in ? py[base + i] : 0.0;
-      z[u] = in ? pz[base + i] : 0.0;
-    }
-    unsigned long long m[CS_E];
-#pragma unroll
-    for (int u = 0; u < CS_E; u++) {
-      m[u] = __ballot(f[u]);
-      if (lane == 0) s_c[u][wave] = __popcll(m[u]);
-    }
-    __syncthreads();
-    int before = 0, tot = 0;                       // kept points of the step before (u, wave) in position order | in the step
-#pragma unroll
-    for (int u = 0; u < CS_E; u++) {
-      int mine = before;
-#pragma unroll
-      for (int w = 0; w < CS_T / 64; w++) {
-        const int c = s_c[u][w];
-        mine += (w < wave) ? c : 0;
-        tot += c;
-      }
-      if (f[u]) {
-        const long long d = base + running + mine + __popcll(m[u] & ((1ull << lane) - 1ull));
-        px[d] = x[u]; py[d] = y[u]; pz[d] = z[u];
-      }
-      before = tot;
-    }
-    running += tot;
-    __syncthreads();                               // s_c is rewritten by the next step
-  }
-  if (threadIdx.x == 0) seg_cnt[s] = running;
-}
-
 // ---------------------------------------------------------------- a12 ball query
 // exists-within-C with a spatial hash.  Coordinates are quantised to units of
 // u = C(1+1e-5)/16 (17 bits per axis, +-409 m for C = 0.1); a cell is 32 units
@@ -1086,7 +1027,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     uint8_t *__restrict__ flags, int masked) {
   __shared__ unsigned long long s_node[BH_MAX];
   __shared__ uint32_t s_head[BH_HEADS];
-  __shared__ int s_pending;
+  __shared__ int s_pending, s_nkept;
   const int ntile = tile_off[S];
   int t = blockIdx.x * BALL_TPW;
   if (t >= ntile) return;
@@ -1107,6 +1048,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     // masked: flags hold the keep mask of a preceding filter that was not compacted;
     // a dropped point is not a query and stays dropped
     const bool valid = (q < nq) && (!masked || flags[bq + q]);
+    const bool amask = masked == 2;      // the LiDAR list is not compacted either: flags[ba + i] says who is left of it
     if (na == 0) {                       // my_loader.py:602: fuse skipped
       if (valid) flags[bq + q] = 1;
       continue;
@@ -1119,10 +1061,13 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
       mask = (uint32_t)slots - 1u;
       __syncthreads();                           // queries of the previous tile are done
       for (int i = threadIdx.x; i < slots; i += BT) s_head[i] = 0u;
-      if (threadIdx.x == 0) s_pending = 0;
+      if (threadIdx.x == 0) { s_pending = 0; s_nkept = 0; }
       __syncthreads();
       bool too_wide = false;
+      int mine_kept = 0;
       for (int i = threadIdx.x; i < na; i += BT) {
+        if (amask && !flags[ba + i]) continue;
+        mine_kept++;
         const double fx = floor(px[ba + i] * inv) + OFF, fy = floor(py[ba + i] * inv) + OFF,
                      fz = floor(pz[ba + i] * inv) + OFF;
         if (!(fx >= 64.0 && fy >= 64.0 && fz >= 64.0 && fx < 131000.0 && fy < 131000.0 && fz < 131000.0)) {
@@ -1135,12 +1080,14 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                     ((unsigned long long)iz << 34) | ((unsigned long long)prev << 51);
       }
       if (too_wide) s_pending = 1;
+      if (mine_kept) atomicAdd(&s_nkept, mine_kept);
       __syncthreads();
       hash_ok = (s_pending == 0);
       hashed_s = s;
     }
     bool found = false;
     if (na <= BH_MAX && hash_ok) {
+      if (s_nkept == 0) continue;        // the filter left no LiDAR point: fuse skipped (my_loader.py:602), the flags stand
       if (valid) {
         // quantised range [q - C', q + C'] on each axis (NaN / far-away queries fail the range test)
         const double lx = floor((x - Cq) * inv) + OFF, hx = floor((x + Cq) * inv) + OFF;
@@ -1238,16 +1185,23 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
     hashed_s = -1;                               // the tiles below overwrite the table
     constexpr int PTB = BH_MAX / 3;              // points per tile: x | y | z in the nodes' LDS
     double *sx = (double *)s_node, *sy = sx + PTB, *sz = sy + PTB;
+    int any_kept = 0;                            // (uniform after each barrier) LiDAR points the filter left, so far
     for (int j0 = 0; j0 < na; j0 += PTB) {
       const int m = min(PTB, na - j0);
       __syncthreads();
-      if (threadIdx.x == 0) s_pending = 0;
+      if (threadIdx.x == 0) { s_pending = 0; s_nkept = 0; }
+      __syncthreads();
+      int mine_kept = 0;
       for (int i = threadIdx.x; i < m; i += BT) {
-        sx[i] = px[ba + j0 + i];
+        const bool there = !amask || flags[ba + j0 + i];
+        mine_kept += there ? 1 : 0;
+        sx[i] = there ? px[ba + j0 + i] : (double)INFINITY;      // (a point the filter dropped is within C of nothing)
         sy[i] = py[ba + j0 + i];
         sz[i] = pz[ba + j0 + i];
       }
+      if (mine_kept) atomicAdd(&s_nkept, mine_kept);
       __syncthreads();
+      any_kept += s_nkept;
       if (valid && !found) {
         for (int j = 0; j < m; j++) {
           const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
@@ -1259,9 +1213,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
         if (!found) s_pending = 1;
       }
       __syncthreads();
-      if (!s_pending) break;
+      if (!s_pending && any_kept) break;         // (with nothing kept so far the rest of the list decides whether there is a fuse)
     }
-    if (valid) flags[bq + q] = found ? 1 : 0;
+    if (valid && any_kept) flags[bq + q] = found ? 1 : 0;      // (no LiDAR point left: fuse skipped, the flags stand)
   }
 }
 
@@ -1272,20 +1226,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
 // (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
 constexpr int CPT = 1024;   // threads per compaction workgroup
 constexpr int CPE = 2;      // consecutive elements per thread (4 needed 76 VGPRs: one 1024-thread workgroup per CU)
-__global__ __launch_bounds__(CPT) void k_seg_compact(
-    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-    long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
-    const uint8_t *__restrict__ flags, const long long *__restrict__ dst_after_base,
-    const int *__restrict__ dst_after_cnt) {
-  __shared__ int s_w[CPT / 64];
-  const int s = blockIdx.x;
-  const int n = seg_cnt[s];
-  const long long src = seg_base[s];
-  const long long dst = dst_after_base ? dst_after_base[s] + dst_after_cnt[s] : src;
-  if (n == 0) {
-    if (dst_after_base && threadIdx.x == 0) seg_base[s] = dst;
-    return;
-  }
+// n positions from src to dst (dst <= src) by flags, in order; returns the number kept (the same in every thread)
+__device__ __forceinline__ int compact_list(double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+                                            const uint8_t *__restrict__ flags, long long src, long long dst, int n, int *s_w) {
   int running = 0;
   for (int t0 = 0; t0 < n; t0 += CPT * CPE) {
     const int i0 = t0 + threadIdx.x * CPE;
@@ -1312,6 +1255,34 @@ __global__ __launch_bounds__(CPT) void k_seg_compact(
     }
     running += tot;
   }
+  return running;
+}
+// In-order compaction of segment s by flags.  dst = src (in place) or, when
+// dst_after_base != nullptr, directly behind another segment
+// (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.  compact_front: that other segment carries flags
+// as well (a joint filter pass without compaction) and is compacted in place first -- it is the short one, the
+// per-instance LiDAR list --, its count updated.
+__global__ __launch_bounds__(CPT) void k_seg_compact(
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+    long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
+    const uint8_t *__restrict__ flags, const long long *__restrict__ dst_after_base,
+    int *__restrict__ dst_after_cnt, int compact_front) {
+  __shared__ int s_w[CPT / 64];
+  const int s = blockIdx.x;
+  const int n = seg_cnt[s];
+  const long long src = seg_base[s];
+  int front = dst_after_base ? dst_after_cnt[s] : 0;
+  if (compact_front && dst_after_base && front > 0) {
+    const int kept = compact_list(px, py, pz, flags, dst_after_base[s], dst_after_base[s], front, s_w);
+    if (threadIdx.x == 0) dst_after_cnt[s] = kept;
+    front = kept;
+  }
+  const long long dst = dst_after_base ? dst_after_base[s] + front : src;
+  if (n == 0) {
+    if (dst_after_base && threadIdx.x == 0) seg_base[s] = dst;
+    return;
+  }
+  const int running = compact_list(px, py, pz, flags, src, dst, n, s_w);
   if (threadIdx.x == 0) {
     seg_cnt[s] = running;
     if (dst_after_base) seg_base[s] = dst;
@@ -1534,14 +1505,9 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {
-    if (phases & DFU3D_RF_SHORT_LISTS) {
-      hipLaunchKernelGGL(k_seg_compact_short, dim3(S), dim3(CS_T), 0, st, px, py, pz,
-                         (const long long *)seg_base, seg_cnt, flags, S);
-    } else {
-      hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
-                         (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
-                         (const int *)nullptr);
-    }
+    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
+                       (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
+                       (int *)nullptr, 0);
     DFU3D_LAUNCH_CHECK();
   }
   return DFU3D_OK;
@@ -1570,13 +1536,13 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
                      (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
-                     (const int *)nullptr);
+                     (int *)nullptr, 0);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
 
 static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t *base_a,
-                                    const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
+                                    int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
                                     double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
                                     uint8_t *flags, int masked, void *stream) {
   DFU3D_CLEAR_STALE_ERROR();
@@ -1609,7 +1575,7 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
                      tile_big, flags, masked);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz, (long long *)base_b,
-                     cnt_b, flags, (const long long *)base_a, cnt_a);
+                     cnt_b, flags, (const long long *)base_a, cnt_a, masked == 2 ? 1 : 0);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
@@ -1618,7 +1584,7 @@ extern "C" int dfu3d_ballquery_fuse(double *px, double *py, double *pz, const in
                                     const int32_t *cnt_a, int64_t *base_b, int32_t *cnt_b,
                                     double C, int32_t S, int64_t pool_cap, int32_t *tile_off,
                                     uint8_t *flags, void *stream) {
-  return ballquery_fuse_impl(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
+  return ballquery_fuse_impl(px, py, pz, base_a, (int32_t *)cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
                              flags, 0, stream);
 }
 
@@ -1627,6 +1593,15 @@ extern "C" int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
                                            int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
                                            int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
                                            void *stream) {
-  return ballquery_fuse_impl(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
+  return ballquery_fuse_impl(px, py, pz, base_a, (int32_t *)cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
                              flags, 1, stream);
+}
+
+extern "C" int dfu3d_ballquery_fuse_joint(double *px, double *py, double *pz,
+                                          const int64_t *base_a, int32_t *cnt_a,
+                                          int64_t *base_b, int32_t *cnt_b, double C, int32_t S,
+                                          int64_t pool_cap, int32_t *tile_off, uint8_t *flags,
+                                          void *stream) {
+  return ballquery_fuse_impl(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off,
+                             flags, 2, stream);
 }

@@ -340,15 +340,12 @@ class PseudoBoxEngine:
         self._count("pool_points", self.pool_cursor)
         if fused:
             # ONE pass over the LiDAR and the pseudo lists of all instances (2S segments) on the float32
-            # shadow written by the segment build; the LiDAR lists are compacted in place, the pseudo lists
-            # keep their flags -- the fuse below compacts them once for both filters
+            # shadow written by the segment build; both keep their flags -- the fuse below reads them and
+            # compacts the lists once for both filters
             self._phased("rf_", st.radius_filter, (("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE)),
                          self.px, self.py, self.pz, self.base_ab, self.cnt_ab, self.rad_ab, p.nb_points, 2 * S,
                          self.pool_cap, self.tile_off, self.flags, self.queue, shadow=self.shadow,
                          n_used=self.pool_cursor)
-            self._run("rf_compact", st.radius_filter, self.px, self.py, self.pz, self.base_a, self.cnt_a,
-                      rl, p.nb_points, S, self.pool_cap, self.tile_off, self.flags, self.queue,
-                      phases=st.RF_COMPACT | st.RF_SHORT_LISTS, shadow=self.shadow, n_used=self.pool_cursor)
         else:           # the (dormant) statistical filter sits in between and needs the filtered lists
             rf_ph = (("shadow", st.RF_SHADOW), ("flags", st.RF_FLAGS), ("resolve", st.RF_RESOLVE),
                      ("compact", st.RF_COMPACT))
@@ -366,7 +363,8 @@ class PseudoBoxEngine:
         self._count("ball_points", self.cnt_a)
         self._count("ball_points", self.cnt_b)
         R("ballquery_fuse", st.ballquery_fuse, self.px, self.py, self.pz, self.base_a, self.cnt_a, self.base_b,
-                          self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags, masked=fused)
+                          self.cnt_b, p.fuse_C, S, self.pool_cap, self.tile_off, self.flags,
+                          masked="joint" if fused else False)
         torch.add(self.cnt_a, self.cnt_b, out=self.cnt_all)     # cat(lidar, pseudo)
         self._count("instance_points", self.cnt_all)
         R("range_cluster", st.range_cluster, self.px, self.py, self.base_a, self.cnt_all, S, p.R0,

@@ -20,7 +20,7 @@ MAX_INST = 32
 
 BP_BIN, BP_AMB, BP_MARK, BP_VOX, BP_REPAIR, BP_ALL = 1, 2, 4, 8, 16, 31
 MASK_BYTES = 0
-RF_SHADOW, RF_FLAGS, RF_RESOLVE, RF_COMPACT, RF_ALL, RF_SHORT_LISTS = 1, 2, 4, 8, 15, 16
+RF_SHADOW, RF_FLAGS, RF_RESOLVE, RF_COMPACT, RF_ALL = 1, 2, 4, 8, 15
 
 ST_POOL_OVERFLOW = 1
 ST_VOX_OVERFLOW = 2
@@ -302,8 +302,10 @@ def stat_filter(px, py, pz, seg_base, seg_cnt, enable, nb_neighbors, std_ratio, 
 
 
 def ballquery_fuse(px, py, pz, base_a, cnt_a, base_b, cnt_b, C, S, pool_cap, tile_off, flags, masked=False):
-    """masked=True: `flags` holds the keep mask of a radius_filter call made without RF_COMPACT."""
-    fn = _lib.lib().dfu3d_ballquery_fuse_masked if masked else _lib.lib().dfu3d_ballquery_fuse
+    """masked=True: `flags` holds the keep mask of a radius_filter call over the B lists made without RF_COMPACT;
+    masked="joint": of a joint call over the A and B lists (cnt_a is updated: A is compacted here too)."""
+    L = _lib.lib()
+    fn = L.dfu3d_ballquery_fuse_joint if masked == "joint" else (L.dfu3d_ballquery_fuse_masked if masked else L.dfu3d_ballquery_fuse)
     rc = fn(
         _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
         _chk(pz, "pz", torch.float64, numel=pool_cap),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 141          /* 0.1.4.1: 128-byte scratch of dfu3d_selftest_backproject; 140 = 0.1.4: radius-filter scratch sizes */
+#define DFU3D_VERSION 150          /* 0.1.5: dfu3d_ballquery_fuse_joint, no DFU3D_RF_SHORT_LISTS; 141: 128-byte scratch of dfu3d_selftest_backproject */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -253,11 +253,10 @@ int dfu3d_radius_filter(double *px, double *py, double *pz,
 int64_t dfu3d_rf_shadow_bytes(int64_t pool_cap);
 int64_t dfu3d_rf_queue_ints(int64_t pool_cap);
 #define DFU3D_RF_SHADOW 1   /* shadow of the given segments (not needed behind dfu3d_segments_build(..., shadow)) */
-#define DFU3D_RF_FLAGS 2    /* k_rf_stream: list neighbours / own wave / own workgroup, float32             */
+#define DFU3D_RF_FLAGS 2    /* k_rf_stream: list neighbours, then the point's whole 512-slot range, float32 */
 #define DFU3D_RF_RESOLVE 4  /* k_rf_resolve: the undecided against their whole segment                       */
 #define DFU3D_RF_COMPACT 8  /* ordered in-place compaction of the given segments                            */
 #define DFU3D_RF_ALL 15
-#define DFU3D_RF_SHORT_LISTS 16 /* hint for COMPACT: one wave per segment (the per-instance LiDAR lists)    */
 
 /* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
  * keep i iff 0 < mean_knn_dist_i < mu + std_ratio * sigma (self included in
@@ -291,6 +290,17 @@ int dfu3d_ballquery_fuse_masked(double *px, double *py, double *pz,
                                 int64_t *base_b, int32_t *cnt_b, double C,
                                 int32_t S, int64_t pool_cap, int32_t *tile_off,
                                 uint8_t *flags, void *stream);
+/* Same, behind a JOINT filter pass: flags holds the keep mask of segment A as well
+ * (dfu3d_radius_filter over the 2S lists A | B of dfu3d_segments_build's joint table with
+ * phases = DFU3D_RF_FLAGS | DFU3D_RF_RESOLVE).  Points of A the filter dropped are not
+ * candidates; if it left none the fuse is skipped as for an empty A (my_loader.py:602).
+ * A is compacted in place, cnt_a[s] updated, and the survivors of B follow it: one
+ * compaction launch for both lists and both filters. */
+int dfu3d_ballquery_fuse_joint(double *px, double *py, double *pz,
+                               const int64_t *base_a, int32_t *cnt_a,
+                               int64_t *base_b, int32_t *cnt_b, double C,
+                               int32_t S, int64_t pool_cap, int32_t *tile_off,
+                               uint8_t *flags, void *stream);
 
 /* ---- f-2: points in boxes / ground-truth database --------------------------
  * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-171 points_in_boxes_cpu;

@@ -19,7 +19,7 @@ def test_library_exports_every_header_symbol():
 
 def test_version_and_strerror():
     L = _lib.lib()
-    assert L.dfu3d_version() == 141 == _lib.header_version()
+    assert L.dfu3d_version() == 150 == _lib.header_version()
     assert L.dfu3d_strerror(0) == b"ok"
     assert b"invalid" in L.dfu3d_strerror(-1)
 

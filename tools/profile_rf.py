@@ -1,7 +1,7 @@
 """Dev tool (GPU): the radius-filter stage on the state the engine hands it (joint LiDAR + pseudo lists of `frames` bench
 frames): time per kernel (HIP events on the launch stream, best / median of `reps`), queue length after phase A, length of
 the U lists, achieved GB/s of the stage at 21 B/point, and a check of the keep mask against a brute-force float64 count on
-a sample of segments.
+a sample of segments (every segment of one frame: tests/test_gpu_radius_filter.py).
 
     python tools/profile_rf.py [frames=64] [reps=20]
 """
@@ -38,7 +38,6 @@ eng.run(b)
 torch.cuda.synchronize()
 st.radius_filter = orig
 joint = snaps[0]                    # FLAGS | RESOLVE over the 2S joint lists
-short = snaps[2] if len(snaps) > 2 else snaps[-1]     # COMPACT | SHORT_LISTS over the S LiDAR lists
 n_pts = int(joint["cnt"].sum())
 S2 = joint["S"]
 
@@ -64,28 +63,10 @@ t_flags = timed(lambda: call(joint, st.RF_FLAGS))
 nq = int(eng.queue[0:1024:16].sum())
 t_res = timed(lambda: call(joint, st.RF_RESOLVE))
 flags = eng.flags.clone()
-cnt_save = short["cnt"].clone()
-pool_save = [short[k].clone() for k in ("px", "py", "pz")]
-
-
-def compact():
-    call(short, st.RF_COMPACT | st.RF_SHORT_LISTS)
-
-
-ts = []
-for _ in range(reps):
-    short["cnt"].copy_(cnt_save)
-    for k, t in zip(("px", "py", "pz"), pool_save):
-        short[k].copy_(t)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); compact(); e1.record(); e1.synchronize()
-    ts.append(e0.elapsed_time(e1) * 1e3)
-t_cmp = (min(ts), float(np.median(ts)))
-stage = t_flags[0] + t_res[0] + t_cmp[0]
+stage = t_flags[0] + t_res[0]
 print("points %d  segments %d  queued %d (%.3f%%)" % (n_pts, S2, nq, 100.0 * nq / max(n_pts, 1)))
-print("phase A %.1f / %.1f us   phase B %.1f / %.1f us   short compaction %.1f / %.1f us   (best / median, events include ~2 us launch)"
-      % (t_flags + t_res + t_cmp))
+print("phase A %.1f / %.1f us   phase B %.1f / %.1f us   (best / median, events include ~2 us launch; the lists are compacted by the fuse)"
+      % (t_flags + t_res))
 print("stage (best) %.1f us = %.0f GB/s at 21 B/point = %.3f of 8 TB/s; phase A alone %.0f GB/s" %
       (stage, 21.0 * n_pts / stage / 1e3, 21.0 * n_pts / stage / 1e3 / 8000.0, 21.0 * n_pts / t_flags[0] / 1e3))
 # U slots: the count sits next to each range's first box
