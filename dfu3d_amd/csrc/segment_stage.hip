@@ -1066,10 +1066,11 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
       bool too_wide = false;
       int mine_kept = 0;
       for (int i = threadIdx.x; i < na; i += BT) {
+        // (coordinates and flag are requested together: the table build is a dependent prologue of the workgroup)
+        const double ax = px[ba + i], ay = py[ba + i], az = pz[ba + i];
         if (amask && !flags[ba + i]) continue;
         mine_kept++;
-        const double fx = floor(px[ba + i] * inv) + OFF, fy = floor(py[ba + i] * inv) + OFF,
-                     fz = floor(pz[ba + i] * inv) + OFF;
+        const double fx = floor(ax * inv) + OFF, fy = floor(ay * inv) + OFF, fz = floor(az * inv) + OFF;
         if (!(fx >= 64.0 && fy >= 64.0 && fz >= 64.0 && fx < 131000.0 && fy < 131000.0 && fz < 131000.0)) {
           too_wide = true;
           continue;
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
                     ((unsigned long long)iz << 34) | ((unsigned long long)prev << 51);
       }
       if (too_wide) s_pending = 1;
-      if (mine_kept) atomicAdd(&s_nkept, mine_kept);
+      if (mine_kept) s_nkept = 1;                   // (plain store, every writer the same value: atomics on one LDS word serialise lane by lane)
       __syncthreads();
       hash_ok = (s_pending == 0);
       hashed_s = s;
@@ -1199,9 +1200,9 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
         sy[i] = py[ba + j0 + i];
         sz[i] = pz[ba + j0 + i];
       }
-      if (mine_kept) atomicAdd(&s_nkept, mine_kept);
+      if (mine_kept) s_nkept = 1;                   // (plain store, every writer the same value: atomics on one LDS word serialise lane by lane)
       __syncthreads();
-      any_kept += s_nkept;
+      any_kept |= s_nkept;
       if (valid && !found) {
         for (int j = 0; j < m; j++) {
           const double dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
@@ -1226,42 +1227,13 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
 // (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
 constexpr int CPT = 1024;   // threads per compaction workgroup
 constexpr int CPE = 2;      // consecutive elements per thread (4 needed 76 VGPRs: one 1024-thread workgroup per CU)
-// n positions from src to dst (dst <= src) by flags, in order; returns the number kept (the same in every thread)
-__device__ __forceinline__ int compact_list(double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-                                            const uint8_t *__restrict__ flags, long long src, long long dst, int n, int *s_w) {
-  int running = 0;
-  for (int t0 = 0; t0 < n; t0 += CPT * CPE) {
-    const int i0 = t0 + threadIdx.x * CPE;
-    bool f[CPE];
-    double x[CPE], y[CPE], z[CPE];
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < CPE; k++) {
-      const int i = i0 + k;
-      f[k] = (i < n) && flags[src + i];
-      x[k] = y[k] = z[k] = 0.0;
-      if (f[k]) { x[k] = px[src + i]; y[k] = py[src + i]; z[k] = pz[src + i]; }
-      mine += f[k] ? 1 : 0;
-    }
-    int tot;
-    int r = block_excl_scan<CPT / 64>(mine, s_w, tot);   // barriers: loads above complete first
-#pragma unroll
-    for (int k = 0; k < CPE; k++) {
-      if (f[k]) {
-        const long long d = dst + running + r;            // d <= src + i: never ahead of the reads
-        px[d] = x[k]; py[d] = y[k]; pz[d] = z[k];
-        r++;
-      }
-    }
-    running += tot;
-  }
-  return running;
-}
-// In-order compaction of segment s by flags.  dst = src (in place) or, when
-// dst_after_base != nullptr, directly behind another segment
-// (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.  compact_front: that other segment carries flags
-// as well (a joint filter pass without compaction) and is compacted in place first -- it is the short one, the
-// per-instance LiDAR list --, its count updated.
+// In-order compaction of segment s by flags.  dst = src (in place) or, when dst_after_base != nullptr, directly behind
+// another segment (dst_after_base[s] + dst_after_cnt[s]); seg_base[s] is updated then.
+// compact_front: that other segment carries flags as well (a joint filter pass without compaction).  The two lists are
+// then ONE list to this kernel -- positions [0, front) the other segment (the short one: the per-instance LiDAR list),
+// [front, front + n) this one -- compacted towards dst_after_base[s]: the survivors of the second list land directly behind
+// the survivors of the first, no step and no barrier more than for the second list alone; both counts are updated.
+// Needs base + front <= seg_base (the second list lies behind the first), so that a destination is never ahead of a source.
 __global__ __launch_bounds__(CPT) void k_seg_compact(
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
     long long *__restrict__ seg_base, int *__restrict__ seg_cnt,
@@ -1271,21 +1243,47 @@ __global__ __launch_bounds__(CPT) void k_seg_compact(
   const int s = blockIdx.x;
   const int n = seg_cnt[s];
   const long long src = seg_base[s];
-  int front = dst_after_base ? dst_after_cnt[s] : 0;
-  if (compact_front && dst_after_base && front > 0) {
-    const int kept = compact_list(px, py, pz, flags, dst_after_base[s], dst_after_base[s], front, s_w);
-    if (threadIdx.x == 0) dst_after_cnt[s] = kept;
-    front = kept;
-  }
-  const long long dst = dst_after_base ? dst_after_base[s] + front : src;
-  if (n == 0) {
+  const int front_all = dst_after_base ? dst_after_cnt[s] : 0;
+  const int front = (compact_front && dst_after_base) ? front_all : 0;     // positions of the front list that are compacted here
+  const long long src_f = dst_after_base ? dst_after_base[s] : 0;
+  const long long dst = dst_after_base ? src_f + (front_all - front) : src;
+  const int n_all = front + n;
+  if (n_all == 0) {
     if (dst_after_base && threadIdx.x == 0) seg_base[s] = dst;
     return;
   }
-  const int running = compact_list(px, py, pz, flags, src, dst, n, s_w);
+  int running = 0, kept_front = 0;
+  for (int t0 = 0; t0 < n_all; t0 += CPT * CPE) {
+    const int i0 = t0 + threadIdx.x * CPE;
+    bool f[CPE];
+    double x[CPE], y[CPE], z[CPE];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < CPE; k++) {
+      const int i = i0 + k;
+      const long long g = (i < front) ? src_f + i : src + (i - front);
+      f[k] = (i < n_all) && flags[g];
+      x[k] = y[k] = z[k] = 0.0;
+      if (f[k]) { x[k] = px[g]; y[k] = py[g]; z[k] = pz[g]; }
+      mine += f[k] ? ((i < front) ? 0x10001 : 1) : 0;     // kept | kept of the front list, in one scan
+    }
+    int tot;
+    int r = block_excl_scan<CPT / 64>(mine, s_w, tot) & 0xFFFF;   // barriers: loads above complete first  (a step holds 2048 positions)
+#pragma unroll
+    for (int k = 0; k < CPE; k++) {
+      if (f[k]) {
+        const long long d = dst + running + r;            // d <= source position: never ahead of the reads
+        px[d] = x[k]; py[d] = y[k]; pz[d] = z[k];
+        r++;
+      }
+    }
+    running += tot & 0xFFFF;
+    kept_front += tot >> 16;
+  }
   if (threadIdx.x == 0) {
-    seg_cnt[s] = running;
-    if (dst_after_base) seg_base[s] = dst;
+    seg_cnt[s] = running - kept_front;
+    if (dst_after_base) seg_base[s] = dst + kept_front;
+    if (front) dst_after_cnt[s] = kept_front;
   }
 }
 
