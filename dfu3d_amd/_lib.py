@@ -47,6 +47,7 @@ class ChainCfg(ctypes.Structure):
         ("cap_rows", c_i32),
         ("dense", c_i32), ("apply_fov", c_i32), ("fov_h", c_i32), ("fov_w", c_i32), ("stat_filter", c_i32),
         ("bounds_h", c_i32), ("bounds_w", c_i32), ("mask_format", c_i32), ("reserved0", c_i32),
+        ("stat_voxel", c_f64),
         ("pool_cap", c_i64),
         ("plane_max_hs", c_f64), ("plane_range", c_f64), ("plane_offset", c_f64),
         ("ransac_trials", c_i32), ("nb_points", c_i32),
@@ -92,6 +93,8 @@ SIGNATURES = {
                                     c_i32, _P]),
     "dfu3d_stat_filter": (c_i32, [_P, _P, _P, _P, _P, _P, c_i32, c_f64, c_i32, c_i64, _P, _P,
                                   _P, _P, _P]),
+    "dfu3d_voxel_down_sample_scratch_bytes": (c_i64, [c_i64]),
+    "dfu3d_voxel_down_sample": (c_i32, [_P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P, _P]),
     "dfu3d_ballquery_fuse": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,
                                      _P]),
     "dfu3d_ballquery_fuse_masked": (c_i32, [_P, _P, _P, _P, _P, _P, _P, c_f64, c_i32, c_i64, _P, _P,

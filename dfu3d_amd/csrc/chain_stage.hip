@@ -25,6 +25,7 @@ struct ChainWs {
   int64_t *base_a, *base_b, *base_ab;
   int32_t *cnt_a, *cnt_b, *cnt_all, *cnt_ab, *tile_off, *queue, *stat_enable;
   double *rad_ab, *mean_d;
+  void *vd_scratch;
   void *shadow;
   int32_t *chunk_cnt;
   int64_t *pool_cursor;
@@ -73,6 +74,7 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
   t.chunk_cnt = (int32_t *)take(4 * dfu3d_segments_scratch_words(c->V, c->cap_n, c->cap_vox));
   t.rad_ab = (double *)take(8 * 2 * S);
   t.mean_d = c->stat_filter ? (double *)take(8 * P) : nullptr;
+  t.vd_scratch = c->stat_filter ? (void *)take(dfu3d_voxel_down_sample_scratch_bytes(P)) : nullptr;
   t.pool_cursor = (int64_t *)take(8);
   if (w) *w = t;
   return off;
@@ -83,7 +85,8 @@ bool cfg_ok(const dfu3d_chain_cfg *c) {
          c->cap_n > 0 && c->cap_vox > 0 && c->cap_rows > 0 && c->pool_cap > 0 && c->n_theta > 0 &&
          c->bounds_h > 0 && c->bounds_w > 0 && c->bounds_h <= c->H && c->bounds_w <= c->W &&
          mask_format_ok(c->mask_format, c->max_inst) &&
-         (!c->dense || (c->geom.t_n > 0 && c->geom.p_n > 0));
+         (!c->dense || (c->geom.t_n > 0 && c->geom.p_n > 0)) &&
+         (!c->stat_filter || (c->stat_voxel > 0.0 && c->stat_nb_neighbors >= 1));
 }
 
 // apply_fov == 0: the caller's points are already the FOV points (vis_utils.py:152-154 done upstream)
@@ -138,6 +141,8 @@ extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
       return P > 0 ? up(DFU3D_SHADOW_BYTES(P)) + up(4 * (2 * S + 1)) + up(P) + up(4 * DFU3D_RF_QUEUE_INTS(P)) : DFU3D_EINVAL;
     case DFU3D_STAGE_STAT_FILTER:                        /* tile_off, flags, mean_d */
       return P > 0 ? up(4 * (S + 1)) + up(P) + up(8 * P) : DFU3D_EINVAL;
+    case DFU3D_STAGE_VOXEL_DOWN_SAMPLE:                  /* scratch */
+      return P > 0 ? up(dfu3d_voxel_down_sample_scratch_bytes(P)) : DFU3D_EINVAL;
     case DFU3D_STAGE_BALLQUERY_FUSE:                     /* tile_off, flags */
       return P > 0 ? up(4 * (2 * S + 2)) + up(P) : DFU3D_EINVAL;
     case DFU3D_STAGE_RANGE_CLUSTER:                      /* sx, sy, si */
@@ -254,6 +259,8 @@ extern "C" int dfu3d_pseudo_boxes(
     CHAIN_TRY(dfu3d_radius_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, inst_r_pseudo, cfg->nb_points, S,
                                   cfg->pool_cap, w.pool_cursor, w.shadow, w.tile_off, w.flags, w.queue,
                                   DFU3D_RF_ALL, stream));
+    CHAIN_TRY(dfu3d_voxel_down_sample(w.px, w.py, w.pz, w.base_b, w.cnt_b, w.stat_enable, cfg->stat_voxel, S,
+                                      cfg->pool_cap, w.vd_scratch, status, stream));
     CHAIN_TRY(dfu3d_stat_filter(w.px, w.py, w.pz, w.base_b, w.cnt_b, w.stat_enable, cfg->stat_nb_neighbors,
                                 cfg->stat_std_ratio, S, cfg->pool_cap, w.tile_off, w.flags, w.mean_d, nullptr,
                                 stream));

@@ -1287,19 +1287,153 @@ __global__ __launch_bounds__(CPT) void k_seg_compact(
   }
 }
 
-// ---------------------------------------------------------------- a11 statistical
+// ---------------------------------------------------------------- a11 voxel down-sample + statistical
+// Open3D PointCloud::VoxelDownSample(voxel_size) (my_loader0.py:734; the leaf is not in the reference tree -- restated
+// from Open3D's published source, `oracle/penet_oracle.py: voxel_down_sample` is the checker): with
+//   voxel_min_bound = min over the points - voxel_size / 2,   index = (int)floor((p - voxel_min_bound) / voxel_size)
+// every voxel's points are summed IN INPUT ORDER and the sum is divided by their number.  Open3D emits the centroids in
+// the iteration order of an std::unordered_map, which is unspecified; this library DEFINES the order as first-seen:
+// voxels come out in the order of their first point in the input list.
+// One workgroup per segment.  A hash table over the voxel index (open addressing in global scratch, 2n .. 4n slots)
+// gives every voxel the list position of its first point; the sums live at that position.  The points are walked in
+// chunks of 1024 in list order: inside a chunk the first point of every voxel (no earlier point of the chunk in the same
+// slot) takes the voxel's running sum, adds the chunk's points of that voxel in list order and puts it back -- so every
+// sum is formed in exactly the reference's order, whatever the scheduling.  Quadratic in the chunk (LDS reads), linear
+// in the segment; the stage is off by default and is built for exactness, not for speed.
+constexpr int VD_T = 1024;
+constexpr unsigned long long VD_EMPTY = ~0ull;
+struct VdScratch {
+  unsigned long long *hkey;          // 4 * pool_cap: segment s owns [4 * base, 4 * base + H), H = power of two in [2n, 4n)
+  int *hfirst;                       // 4 * pool_cap: list position of the slot's first point
+  double *ax, *ay, *az;              // pool_cap: running sums of the voxel whose first point sits at this pool position
+  int *acnt, *vfirst;                // pool_cap: its number of points | for every point: the first point of its voxel
+};
+__host__ __device__ inline VdScratch vd_scratch(void *scratch, int64_t P) {
+  VdScratch W;
+  W.hkey = (unsigned long long *)scratch;
+  W.ax = (double *)(W.hkey + 4 * P);
+  W.ay = W.ax + P;
+  W.az = W.ay + P;
+  W.hfirst = (int *)(W.az + P);
+  W.acnt = W.hfirst + 4 * P;
+  W.vfirst = W.acnt + P;
+  return W;
+}
+// L2-served loads of what other threads of the workgroup stored or updated with atomics (the vector L1 is not coherent)
+__device__ __forceinline__ int ld_agent_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent_d(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__global__ __launch_bounds__(VD_T) void k_voxel_down(
+    double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+    const long long *__restrict__ seg_base, int *__restrict__ seg_cnt, const int *__restrict__ enable,
+    double voxel, VdScratch W, uint32_t *__restrict__ status) {
+  __shared__ int s_slot[VD_T];
+  __shared__ double s_x[VD_T], s_y[VD_T], s_z[VD_T];
+  __shared__ double s_red[3][VD_T / 64];
+  __shared__ int s_w[VD_T / 64];
+  const int s = blockIdx.x;
+  if (!enable[s]) return;
+  const int n = seg_cnt[s];
+  if (n <= 0) return;
+  const long long base = seg_base[s];
+  int H = 2;
+  while (H < 2 * n) H <<= 1;
+  unsigned long long *hk = W.hkey + 4 * base;
+  int *hf = W.hfirst + 4 * base;
+  for (int i = threadIdx.x; i < H; i += VD_T) { hk[i] = VD_EMPTY; hf[i] = 0x7FFFFFFF; }
+  double mx = INFINITY, my = INFINITY, mz = INFINITY;
+  for (int i = threadIdx.x; i < n; i += VD_T) {
+    W.ax[base + i] = 0.0; W.ay[base + i] = 0.0; W.az[base + i] = 0.0; W.acnt[base + i] = 0;
+    mx = fmin(mx, px[base + i]); my = fmin(my, py[base + i]); mz = fmin(mz, pz[base + i]);
+  }
+  mx = wave_min_d(mx); my = wave_min_d(my); mz = wave_min_d(mz);
+  if (lane_id() == 0) { s_red[0][threadIdx.x >> 6] = mx; s_red[1][threadIdx.x >> 6] = my; s_red[2][threadIdx.x >> 6] = mz; }
+  __threadfence();
+  __syncthreads();
+  for (int w = 0; w < VD_T / 64; w++) { mx = fmin(mx, s_red[0][w]); my = fmin(my, s_red[1][w]); mz = fmin(mz, s_red[2][w]); }
+  const double bx = mx - voxel * 0.5, by = my - voxel * 0.5, bz = mz - voxel * 0.5;     // voxel_min_bound
+  bool range_err = false;
+  for (int c0 = 0; c0 < n; c0 += VD_T) {
+    const int i = c0 + (int)threadIdx.x;
+    const bool valid = i < n;
+    const int cn = min(VD_T, n - c0);
+    int h = -1;
+    if (valid) {
+      const double x = px[base + i], y = py[base + i], z = pz[base + i];
+      s_x[threadIdx.x] = x; s_y[threadIdx.x] = y; s_z[threadIdx.x] = z;
+      const double fx = floor((x - bx) / voxel), fy = floor((y - by) / voxel), fz = floor((z - bz) / voxel);
+      // (indices are >= 0 by construction; Open3D refuses a cloud wider than voxel_size * INT_MAX, this table one wider
+      // than 2^21 voxels along an axis: 100 km at 0.05 m)
+      if (!(fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < 2097152.0 && fy < 2097152.0 && fz < 2097152.0)) range_err = true;
+      const unsigned long long key = (unsigned long long)(long long)fmin(fmax(fx, 0.0), 2097151.0) |
+                                     ((unsigned long long)(long long)fmin(fmax(fy, 0.0), 2097151.0) << 21) |
+                                     ((unsigned long long)(long long)fmin(fmax(fz, 0.0), 2097151.0) << 42);
+      h = (int)(mix64(key) & (unsigned long long)(H - 1));
+      while (true) {
+        const unsigned long long old = atomicCAS(&hk[h], VD_EMPTY, key);
+        if (old == VD_EMPTY || old == key) break;
+        h = (h + 1) & (H - 1);
+      }
+      atomicMin(&hf[h], i);
+    }
+    s_slot[threadIdx.x] = h;
+    __threadfence();
+    __syncthreads();
+    if (valid) {
+      const int f = ld_agent_i(&hf[h]);               // final: every later point has a larger position
+      W.vfirst[base + i] = f;
+      bool leader = true;                              // no earlier point of the chunk in the same voxel
+      for (int j = (int)threadIdx.x - 1; j >= 0 && leader; j--) leader = s_slot[j] != h;
+      if (leader) {
+        double sx = ld_agent_d(&W.ax[base + f]), sy = ld_agent_d(&W.ay[base + f]), sz = ld_agent_d(&W.az[base + f]);
+        int c = ld_agent_i(&W.acnt[base + f]);
+        for (int j = threadIdx.x; j < cn; j++)
+          if (s_slot[j] == h) { sx += s_x[j]; sy += s_y[j]; sz += s_z[j]; c++; }     // AccumulatedPoint::AddPoint, in list order
+        W.ax[base + f] = sx; W.ay[base + f] = sy; W.az[base + f] = sz; W.acnt[base + f] = c;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (range_err) atomicOr(status, DFU3D_ST_VOXEL_RANGE);
+  // centroids in first-seen order, written over the list (every source is in the sums by now)
+  int running = 0;
+  for (int c0 = 0; c0 < n; c0 += VD_T) {
+    const int i = c0 + (int)threadIdx.x;
+    const bool first = (i < n) && (W.vfirst[base + i] == i);
+    int tot;
+    const int rank = running + block_excl_scan<VD_T / 64>(first ? 1 : 0, s_w, tot);
+    if (first) {
+      const double c = (double)ld_agent_i(&W.acnt[base + i]);
+      px[base + rank] = ld_agent_d(&W.ax[base + i]) / c;          // AccumulatedPoint::GetAveragePoint
+      py[base + rank] = ld_agent_d(&W.ay[base + i]) / c;
+      pz[base + rank] = ld_agent_d(&W.az[base + i]) / c;
+    }
+    running += tot;
+  }
+  if (threadIdx.x == 0) seg_cnt[s] = running;
+}
+
+// Open3D remove_statistical_outlier, first half: mean distance to the knn nearest points (the point itself included).
+// The candidate list of a query -- its knn smallest squared distances so far, ascending -- lives in LDS, query-minor
+// (best[k][query]: consecutive lanes, consecutive words), and its largest entry in a register: a point farther than
+// that is rejected without touching the list.  (Until round 4 the list was a private array of 64 doubles: 528 bytes of
+// scratch per thread.)
 constexpr int KMAX = 64;
-__global__ __launch_bounds__(QT) void k_knn_mean(
+constexpr int KQ = 128;     // queries per workgroup
+__global__ __launch_bounds__(KQ) void k_knn_mean(
     const double *__restrict__ px, const double *__restrict__ py,
     const double *__restrict__ pz, const long long *__restrict__ seg_base,
     const int *__restrict__ seg_cnt, const int *__restrict__ enable, int knn, int S,
     const int *__restrict__ tile_off, double *__restrict__ mean_d) {
   __shared__ double sx[PT], sy[PT], sz[PT];
+  extern __shared__ double s_best[];            // knn x KQ
   const int t = blockIdx.x;
   if (t >= tile_off[S]) return;
   const int s = find_segment(tile_off, S, t);
   if (!enable[s]) return;
-  const int q0 = (t - tile_off[s]) * QT;
+  const int q0 = (t - tile_off[s]) * KQ;
   const int n = seg_cnt[s];
   const long long base = seg_base[s];
   const int q = q0 + threadIdx.x;
@@ -1307,12 +1441,13 @@ __global__ __launch_bounds__(QT) void k_knn_mean(
   double x = 0.0, y = 0.0, z = 0.0;
   if (valid) { x = px[base + q]; y = py[base + q]; z = pz[base + q]; }
   const int kk = min(knn, n);
-  double best[KMAX];                 // ascending squared distances
+  double *best = s_best + threadIdx.x;          // best[p * KQ]: ascending squared distances
   int nbest = 0;
+  double worst = INFINITY;                      // best[kk - 1] once the list is full
   for (int j0 = 0; j0 < n; j0 += PT) {
     const int m = min(PT, n - j0);
     __syncthreads();
-    for (int i = threadIdx.x; i < m; i += QT) {
+    for (int i = threadIdx.x; i < m; i += KQ) {
       sx[i] = px[base + j0 + i];
       sy[i] = py[base + j0 + i];
       sz[i] = pz[base + j0 + i];
@@ -1324,18 +1459,19 @@ __global__ __launch_bounds__(QT) void k_knn_mean(
         double d = dx * dx;
         d += dy * dy;
         d += dz * dz;
-        if (nbest < kk || d < best[nbest - 1]) {
+        if (nbest < kk || d < worst) {
           int p = (nbest < kk) ? nbest : kk - 1;
-          while (p > 0 && best[p - 1] > d) { best[p] = best[p - 1]; p--; }
-          best[p] = d;
+          while (p > 0 && best[(p - 1) * KQ] > d) { best[p * KQ] = best[(p - 1) * KQ]; p--; }
+          best[p * KQ] = d;
           if (nbest < kk) nbest++;
+          if (nbest == kk) worst = best[(kk - 1) * KQ];
         }
       }
     }
   }
   if (valid) {
     double sum = 0.0;
-    for (int i = 0; i < nbest; i++) sum += sqrt(best[i]);
+    for (int i = 0; i < nbest; i++) sum += sqrt(best[i * KQ]);
     mean_d[base + q] = nbest > 0 ? sum / (double)nbest : -1.0;
   }
 }
@@ -1511,6 +1647,25 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   return DFU3D_OK;
 }
 
+extern "C" int64_t dfu3d_voxel_down_sample_scratch_bytes(int64_t pool_cap) {
+  return pool_cap > 0 ? 80 * pool_cap : DFU3D_EINVAL;      // 4 P keys (8 B) + 3 P sums (8 B) + 4 P + P + P ints
+}
+
+extern "C" int dfu3d_voxel_down_sample(double *px, double *py, double *pz, const int64_t *seg_base,
+                                       int32_t *seg_cnt, const int32_t *enable, double voxel_size,
+                                       int32_t S, int64_t pool_cap, void *scratch, uint32_t *status,
+                                       void *stream) {
+  DFU3D_CLEAR_STALE_ERROR();
+  if (!px || !py || !pz || !seg_base || !seg_cnt || !enable || !scratch || !status) return DFU3D_EINVAL;
+  if (S <= 0 || pool_cap <= 0 || !(voxel_size > 0.0) || !(voxel_size < 1e300)) return DFU3D_EINVAL;   // (Open3D: voxel_size <= 0 is an error)
+  if (pool_cap >= (1ll << 29)) return DFU3D_ERANGE;            // hash regions are addressed with 32-bit positions
+  if ((uintptr_t)scratch & 7u) return DFU3D_EINVAL;
+  hipLaunchKernelGGL(k_voxel_down, dim3(S), dim3(VD_T), 0, (hipStream_t)stream, px, py, pz, (const long long *)seg_base,
+                     seg_cnt, enable, voxel_size, vd_scratch(scratch, pool_cap), status);
+  DFU3D_LAUNCH_CHECK();
+  return DFU3D_OK;
+}
+
 extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64_t *seg_base,
                                  int32_t *seg_cnt, const int32_t *enable, int32_t nb_neighbors,
                                  double std_ratio, int32_t S, int64_t pool_cap,
@@ -1523,10 +1678,12 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   if (S <= 0 || pool_cap <= 0 || nb_neighbors < 1) return DFU3D_EINVAL;
   if (nb_neighbors > KMAX) return DFU3D_ERANGE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, QT);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, KQ);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_knn_mean, dim3(tile_grid(pool_cap, S)), dim3(QT), 0, st, px, py, pz,
-                     (const long long *)seg_base, seg_cnt, enable, nb_neighbors, S, tile_off,
+  if (hipFuncSetAttribute((const void *)k_knn_mean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * KMAX * KQ)) != hipSuccess)
+    return DFU3D_ELAUNCH;
+  hipLaunchKernelGGL(k_knn_mean, dim3((unsigned)((pool_cap + KQ - 1) / KQ + S)), dim3(KQ), sizeof(double) * (size_t)nb_neighbors * KQ, st,
+                     px, py, pz, (const long long *)seg_base, seg_cnt, enable, nb_neighbors, S, tile_off,
                      mean_d);
   DFU3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_stat_flags, dim3(S), dim3(256), 0, st, (const long long *)seg_base,

@@ -146,6 +146,8 @@ class PseudoBoxEngine:
             L.fit_ws = f64(int(st._lib.lib().dfu3d_lshape_fit_ws_doubles(pc, self.cap_rows)))
             L.flags = torch.empty(pc, dtype=torch.uint8, device=d)
             L.mean_d = f64(pc) if self.p.stat_filter else None
+            L.vd_scratch = (torch.empty(st.voxel_down_sample_scratch_bytes(pc), dtype=torch.uint8, device=d)
+                            if self.p.stat_filter else None)
             L.base_a = torch.empty(S, dtype=torch.int64, device=d)
             L.base_b = torch.empty(S, dtype=torch.int64, device=d)
             L.cnt_a, L.cnt_b, L.cnt_all = i32(S), i32(S), i32(S)
@@ -174,6 +176,7 @@ class PseudoBoxEngine:
                 c.fuse_C, c.R0, c.Rd = p.fuse_C, p.R0, p.Rd
                 c.n_theta, c.stat_nb_neighbors = int(self.n_theta), int(p.stat_nb_neighbors)
                 c.dtheta, c.car_aspect_max, c.stat_std_ratio = self.dtheta, p.car_aspect_max, p.stat_std_ratio
+                c.stat_voxel = p.stat_voxel
                 if self.dense:
                     c.geom = L.geom
                 lib = st._lib.lib()
@@ -355,7 +358,9 @@ class PseudoBoxEngine:
             self._phased("rf_", st.radius_filter, rf_ph, self.px, self.py, self.pz, self.base_b,
                          self.cnt_b, rp, p.nb_points, S, self.pool_cap, self.tile_off, self.flags,
                          self.queue, shadow=self.shadow, n_used=self.pool_cursor)
-        if p.stat_filter:
+        if p.stat_filter:       # the reference's dormant pair (my_loader0.py:734-735): centroids per 0.05 m voxel, then the k-NN rule
+            R("voxel_down_sample", st.voxel_down_sample, self.px, self.py, self.pz, self.base_b, self.cnt_b,
+              self.stat_enable, p.stat_voxel, S, self.pool_cap, self.vd_scratch, status)
             R("stat_filter", st.stat_filter, self.px, self.py, self.pz, self.base_b, self.cnt_b, self.stat_enable,
                            p.stat_nb_neighbors, p.stat_std_ratio, S, self.pool_cap,
                            self.tile_off, self.flags, self.mean_d)

@@ -40,6 +40,7 @@ class Params:
     dtheta_deg: float = 1.0             # rectangle_fitting.py:35
     car_aspect_max: float = 5.0         # :651
     stat_filter: bool = False           # dormant: my_loader0.py:734-735
+    stat_voxel: float = 0.05            # voxel_down_sample in front of it (my_loader0.py:734)
     stat_nb_neighbors: int = 30
     stat_std_ratio: float = 0.3
     ransac_trials: int = 100            # sklearn RANSACRegressor default max_trials

@@ -27,12 +27,14 @@ ST_VOX_OVERFLOW = 2
 ST_ROW_OVERFLOW = 4
 ST_BIN_RANGE = 8
 ST_VOX_PTS_OVERFLOW = 16
+ST_VOXEL_RANGE = 32
 STATUS_TEXT = {
     ST_POOL_OVERFLOW: "instance point pool too small (raise pool_cap)",
     ST_VOX_OVERFLOW: "more voxels than cap_vox in a view (raise cap_vox; bin table must be re-initialised)",
     ST_ROW_OVERFLOW: "more box rows than cap_rows",
     ST_BIN_RANGE: "a spherical bin fell outside the bin table",
     ST_VOX_PTS_OVERFLOW: "overflow-bin pixel list too small",
+    ST_VOXEL_RANGE: "voxel_down_sample: a segment is wider than 2^21 voxels along an axis",
 }
 
 
@@ -285,6 +287,22 @@ def radius_filter(px, py, pz, seg_base, seg_cnt, radius, nb_points, S, pool_cap,
         _chk(flags, "flags", torch.uint8, numel=pool_cap),
         _chk(queue, "queue", torch.int32, min_numel=rf_queue_ints(pool_cap)), int(phases), _stream())
     _lib.check(rc, "dfu3d_radius_filter")
+
+
+def voxel_down_sample_scratch_bytes(pool_cap):
+    return int(_lib.lib().dfu3d_voxel_down_sample_scratch_bytes(int(pool_cap)))
+
+
+def voxel_down_sample(px, py, pz, seg_base, seg_cnt, enable, voxel_size, S, pool_cap, scratch, status):
+    """Open3D voxel_down_sample per enabled segment, in place, centroids in first-seen voxel order (include/dfu3d.h)."""
+    rc = _lib.lib().dfu3d_voxel_down_sample(
+        _chk(px, "px", torch.float64, numel=pool_cap), _chk(py, "py", torch.float64, numel=pool_cap),
+        _chk(pz, "pz", torch.float64, numel=pool_cap), _chk(seg_base, "seg_base", torch.int64, numel=S),
+        _chk(seg_cnt, "seg_cnt", torch.int32, numel=S), _chk(enable, "enable", torch.int32, numel=S),
+        float(voxel_size), S, pool_cap,
+        _chk(scratch, "scratch", torch.uint8, min_numel=voxel_down_sample_scratch_bytes(pool_cap)),
+        _chk(status, "status", torch.int32, min_numel=1), _stream())
+    _lib.check(rc, "dfu3d_voxel_down_sample")
 
 
 def stat_filter(px, py, pz, seg_base, seg_cnt, enable, nb_neighbors, std_ratio, S, pool_cap,

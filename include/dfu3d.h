@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DFU3D_VERSION 150          /* 0.1.5: dfu3d_ballquery_fuse_joint, no DFU3D_RF_SHORT_LISTS; 141: 128-byte scratch of dfu3d_selftest_backproject */
+#define DFU3D_VERSION 150          /* 0.1.5: dfu3d_ballquery_fuse_joint, dfu3d_voxel_down_sample (+ dfu3d_chain_cfg.stat_voxel), no DFU3D_RF_SHORT_LISTS; 141: 128-byte scratch of dfu3d_selftest_backproject */
 #define DFU3D_CALIB_FLOATS 48
 #define DFU3D_ROW_DOUBLES 24       /* see dfu3d_lshape_fit */
 #define DFU3D_TABLE_ENTRY_BYTES 28 /* see dfu3d_backproject_bin */
@@ -54,6 +54,7 @@ extern "C" {
 #define DFU3D_ST_ROW_OVERFLOW 4u    /* more box rows than cap_rows              */
 #define DFU3D_ST_BIN_RANGE 8u       /* a spherical bin fell outside the table   */
 #define DFU3D_ST_VOX_PTS_OVERFLOW 16u /* overflow-bin list too small            */
+#define DFU3D_ST_VOXEL_RANGE 32u    /* dfu3d_voxel_down_sample: a segment wider than 2^21 voxels along an axis */
 
 int dfu3d_version(void);
 const char *dfu3d_strerror(int code);
@@ -84,6 +85,7 @@ typedef struct dfu3d_sizes {
 #define DFU3D_STAGE_RANGE_CLUSTER 8
 #define DFU3D_STAGE_LSHAPE_FIT 9
 #define DFU3D_STAGE_PSEUDO_BOXES 10
+#define DFU3D_STAGE_VOXEL_DOWN_SAMPLE 11
 int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *sizes);
 
 /* Geometry of the spherical-bin table used by dfu3d_backproject_bin.  Filled by
@@ -257,6 +259,24 @@ int64_t dfu3d_rf_queue_ints(int64_t pool_cap);
 #define DFU3D_RF_RESOLVE 4  /* k_rf_resolve: the undecided against their whole segment                       */
 #define DFU3D_RF_COMPACT 8  /* ordered in-place compaction of the given segments                            */
 #define DFU3D_RF_ALL 15
+
+/* ---- a11: Open3D voxel_down_sample(voxel_size) (my_loader0.py:734; dormant) ----
+ * The first half of the reference's (commented) pair `voxel_down_sample(0.05)` ->
+ * `remove_statistical_outlier(30, 0.3)`.  Every enabled segment is replaced IN PLACE by the
+ * centroids of its occupied voxels: voxel_min_bound = min over the segment - voxel_size / 2,
+ * voxel index = floor((p - voxel_min_bound) / voxel_size), centroid = sum of the voxel's
+ * points in list order / their number (Open3D's AccumulatedPoint).  Open3D emits them in
+ * the iteration order of an unordered_map (unspecified); this library DEFINES the order:
+ * first-seen -- a voxel's place is that of its first point in the list.  seg_cnt[s] becomes
+ * the number of voxels.  A segment wider than 2^21 voxels along an axis raises
+ * DFU3D_ST_VOXEL_RANGE.  Scratch: dfu3d_voxel_down_sample_scratch_bytes(pool_cap) bytes,
+ * 8-byte aligned (hash table 4 x pool_cap slots, running sums, first-point positions). */
+int64_t dfu3d_voxel_down_sample_scratch_bytes(int64_t pool_cap);
+int dfu3d_voxel_down_sample(double *px, double *py, double *pz,
+                            const int64_t *seg_base, int32_t *seg_cnt,
+                            const int32_t *enable, double voxel_size, int32_t S,
+                            int64_t pool_cap, void *scratch, uint32_t *status,
+                            void *stream);
 
 /* ---- a11: Open3D remove_statistical_outlier (my_loader0.py:735; dormant) ---
  * keep i iff 0 < mean_knn_dist_i < mu + std_ratio * sigma (self included in
@@ -487,6 +507,7 @@ typedef struct dfu3d_chain_cfg {
   int32_t dense, apply_fov, fov_h, fov_w, stat_filter;
   int32_t bounds_h, bounds_w;       /* my_loader.py:526 (<= H, W)           */
   int32_t mask_format, reserved0;   /* DFU3D_MASK_BYTES or 1 / 2 / 4        */
+  double stat_voxel;                /* voxel size of the down-sample in front of the statistical filter (my_loader0.py:734: 0.05) */
   int64_t pool_cap;
   double plane_max_hs, plane_range, plane_offset;
   int32_t ransac_trials, nb_points;

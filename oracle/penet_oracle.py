@@ -85,6 +85,7 @@ class Params:
     car_aspect_max: float = 5.0         # my_loader.py:651
     # dormant global statistical filter (my_loader0.py:734-735); off = shipped
     stat_filter: bool = False
+    stat_voxel: float = 0.05            # my_loader0.py:734 voxel_down_sample(voxel_size=0.05)
     stat_nb_neighbors: int = 30
     stat_std_ratio: float = 0.3
     # seeded RANSAC (H1)
@@ -421,6 +422,35 @@ def radius_outlier(pts, nb_points, radius):
     return np.nonzero(keep)[0]
 
 
+def voxel_down_sample(pts, voxel_size):
+    """Open3D PointCloud::VoxelDownSample(voxel_size) (my_loader0.py:734, commented; the leaf is absent from the reference
+    tree and from this image -- restated from Open3D's published source, geometry/PointCloud.cpp, PARITY UNPINNED):
+        voxel_min_bound = GetMinBound() - voxel_size * 0.5
+        voxel_index     = int(floor((p - voxel_min_bound) / voxel_size))          per axis
+        voxelindex_to_accpoint[voxel_index].AddPoint(p)   for the points in input order (point_ += p; num_of_points_++)
+        output          = point_ / double(num_of_points_)                         per occupied voxel
+    Open3D emits the voxels in the iteration order of an std::unordered_map, which is unspecified.  DEFINED here (and in
+    the library, include/dfu3d.h): first-seen order -- a voxel's place is that of its first point in the input list.
+    Returns the (m,3) centroids."""
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    if pts.shape[0] == 0:
+        return pts
+    if not voxel_size > 0.0:
+        raise ValueError("voxel_size <= 0")                       # Open3D: LogError
+    minb = pts.min(0) - voxel_size * 0.5
+    idx = np.floor((pts - minb) / voxel_size).astype(np.int64)
+    _, first, inv = np.unique(idx, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(first, kind="stable")                      # voxels by the position of their first point
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    slot = rank[inv]
+    acc = np.zeros((order.size, 3), np.float64)
+    np.add.at(acc, slot, pts)                                     # unbuffered: acc[slot[i]] += pts[i] for i = 0, 1, 2, ... in input order
+    cnt = np.bincount(slot, minlength=order.size).astype(np.float64)
+    return acc / cnt[:, None]
+
+
 def statistical_outlier(pts, nb_neighbors, std_ratio):
     """remove_statistical_outlier: returns kept indices (order preserved)."""
     pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
@@ -631,7 +661,8 @@ def instance_points(seem_name, lidar_pts, pseudo_pts, params: Params):
         P = pseudo_pts[radius_outlier(pseudo_pts, params.nb_points, params.radius_small)]
     else:                                       # H5: undefined in the reference
         L, P = lidar_pts, pseudo_pts
-    if params.stat_filter:
+    if params.stat_filter:                      # the reference's dormant pair, my_loader0.py:734-735
+        P = voxel_down_sample(P, params.stat_voxel)
         P = P[statistical_outlier(P, params.stat_nb_neighbors, params.stat_std_ratio)]
     if L.shape[0] > 0 and P.shape[0] > 0:       # my_loader.py:602-604
         P = P[ball_query(P, L, params.fuse_C)]

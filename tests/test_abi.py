@@ -100,11 +100,12 @@ def test_sizes_struct_layout_and_workspace_bytes(tmp_path):
     z = _lib.Sizes()
     z.V, z.H, z.W, z.max_inst, z.cap_n, z.cap_vox, z.cap_rows, z.max_points_per_voxel = 96, 900, 1600, 8, 34720, 1 << 18, 6144, 100
     z.pool_cap, z.table_entries, z.dense, z.stat_filter = 96 << 17, 824 * 1573, 1, 0
-    got = [L.dfu3d_workspace_bytes(s, ctypes.byref(z)) for s in range(11)]
+    got = [L.dfu3d_workspace_bytes(s, ctypes.byref(z)) for s in range(12)]
     assert got[0] == 0 and all(g > 0 for i, g in enumerate(got) if i != 0)
     assert all(g % 256 == 0 for g in got)
     assert got[5] >= 16 * z.pool_cap + z.pool_cap + 4 * z.pool_cap            # shadow (+ boxes) + flags + queue
-    assert L.dfu3d_workspace_bytes(11, ctypes.byref(z)) == -1 and L.dfu3d_workspace_bytes(5, None) == -1
+    assert got[11] == L.dfu3d_voxel_down_sample_scratch_bytes(z.pool_cap) == 80 * z.pool_cap      # DFU3D_STAGE_VOXEL_DOWN_SAMPLE
+    assert L.dfu3d_workspace_bytes(12, ctypes.byref(z)) == -1 and L.dfu3d_workspace_bytes(5, None) == -1
     # == dfu3d_chain_workspace_bytes of the same configuration
     c = _lib.ChainCfg()
     c.V, c.H, c.W, c.max_inst, c.cap_n, c.cap_vox, c.cap_rows = 96, 900, 1600, 8, 34720, 1 << 18, 6144

@@ -164,3 +164,90 @@ def test_keep_mask_of_a_bench_frame_equals_the_brute_force_count(st, nb):
         bad += int(((got != 0) != exp).sum()); tot += n; dropped += int((~exp).sum())
     assert tot > 100000 and dropped > 100
     assert bad == 0, "%d of %d flags differ from the brute-force count" % (bad, tot)
+
+
+# ------------------------------------------------------------------ a11: voxel down-sample + statistical filter
+def test_voxel_down_sample_matches_oracle(st):
+    """dfu3d_voxel_down_sample against oracle.voxel_down_sample (Open3D VoxelDownSample restated, my_loader0.py:734):
+    the centroids EQUAL bit for bit -- every sum is formed in list order on both sides -- and in the defined order
+    (first-seen voxel).  Sizes around the 1024-point chunk of the kernel, voxels that span several chunks, duplicates,
+    a disabled segment, an empty one."""
+    rng = np.random.default_rng(31)
+    segs = []
+    for n in (0, 1, 2, 37, 1023, 1024, 1025, 3000, 7000):
+        p_ = np.cumsum(rng.normal(0, 0.015, (n, 3)), 0) + rng.uniform(-30, 30, 3)     # a surface-like run: 1-6 points per voxel
+        if n > 100:
+            back = rng.integers(0, n, n // 10)                                        # revisits of earlier voxels, chunks later
+            p_[back] = p_[rng.integers(0, n, n // 10)] + rng.normal(0, 0.004, (n // 10, 3))
+        segs.append(p_)
+    segs.append(np.repeat(rng.normal(0, 1, (1, 3)), 2500, 0))                         # one voxel, 2 500 points, three chunks
+    segs.append(rng.uniform(-2, 2, (4000, 3)))                                        # nearly every point its own voxel
+    segs.append(rng.normal(0, 1, (300, 3)))                                           # disabled: must stay as it is
+    S = len(segs)
+    enable = np.ones(S, np.int32); enable[-1] = 0
+    base, cur, chunks = [], 5, [np.full((5, 3), 4242.0)]
+    for p_ in segs:
+        base.append(cur); chunks += [p_, np.full((3, 3), 777.0)]; cur += len(p_) + 3
+    P = np.concatenate(chunks)
+    cap = len(P) + 8
+    Pp = np.full((cap, 3), 555.0); Pp[:len(P)] = P
+    px, py, pz = _t(Pp[:, 0]), _t(Pp[:, 1]), _t(Pp[:, 2])
+    cnt = _t(np.array([len(p_) for p_ in segs], np.int32))
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(st.voxel_down_sample_scratch_bytes(cap), dtype=torch.uint8, device=DEV)
+    outs = []
+    for rep in range(2):                                                              # deterministic: two runs, the same bits
+        for t_, col in ((px, 0), (py, 1), (pz, 2)):
+            t_.copy_(_t(Pp[:, col]))
+        cnt.copy_(_t(np.array([len(p_) for p_ in segs], np.int32)))
+        scratch.fill_(0xAB if rep else 0)                                             # the scratch needs no initialisation
+        st.voxel_down_sample(px, py, pz, _t(np.array(base, np.int64)), cnt, _t(enable), 0.05, S, cap, scratch, status)
+        torch.cuda.synchronize()
+        outs.append((cnt.cpu().numpy().copy(), torch.stack([px, py, pz], 1).cpu().numpy().copy()))
+    assert int(status.item()) == 0
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    n_out, X = outs[0]
+    for s, p_ in enumerate(segs):
+        exp = O.voxel_down_sample(p_, 0.05) if enable[s] else p_
+        assert n_out[s] == len(exp), (s, n_out[s], len(exp))
+        assert np.array_equal(X[base[s]:base[s] + len(exp)], exp), s
+    assert np.all(X[:5] == 4242.0)                                                    # nothing outside the segments was touched
+
+
+def test_engine_with_the_statistical_pair_matches_oracle_at_bench_size():
+    """The path with the reference's dormant pair switched on (my_loader0.py:734-735: voxel_down_sample(0.05) ->
+    remove_statistical_outlier(30, 0.3) on the pseudo points of every instance) on one frame of bench.py's workload -- 34 720-point
+    sweep, 6 views of 1600x900, dense: pseudo lists of tens of thousands of points go through the voxel hash and the k-NN
+    kernel.  Every label row against the oracle; the chain (one C call) gives the same bits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dfu3d_amd import synth
+    from dfu3d_amd.engine import PseudoBoxEngine
+    from dfu3d_amd.params import Params
+    H, W, M, cams = 900, 1600, 8, 6
+    p = Params(stat_filter=True)
+    scenes = [synth.make_scene(21, H=H, W=W, M=M, cams=cams, dense=True, k_min=30, k_max=40)]
+    b = synth.to_view_batch(scenes, p, DEV, dense=True)
+    cap_n = scenes[0].points.shape[0]
+    eng = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=cams, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17)
+    rows, status = eng.run(b)
+    assert status == 0
+    op = O.Params(stat_filter=True)
+    exp = []
+    s = scenes[0]
+    for c, cal in enumerate(s.calibs):
+        oc = O.Calibration({"P2": cal.P2, "R0": cal.R0, "Tr_velo2cam": cal.V2C})
+        lid, _ = O.fov_filter(s.points.numpy(), oc, p.fov_hw)
+        n = int(s.n_inst[c])
+        res = O.depth2pointsrgbpm(s.depth[c].numpy().copy()[:, :, None], None, oc, lid, O.NUSC_CLASSES,
+                                  s.masks[c][:n].numpy().astype(np.float32), s.inst_class[c][:n].numpy(),
+                                  s.inst_box[c][:n].numpy(), op, plane_key=c, want_points=False)
+        exp += [(c, r.inst, r.cluster, r) for r in res.rows]
+    R = rows.cpu().numpy()
+    assert R.shape[0] == len(exp) and len(exp) >= 5, (R.shape[0], len(exp))
+    for got, (v, j, k, r) in zip(R, exp):
+        assert (int(got[0]), int(got[1]), int(got[2]), int(got[3])) == (v, j, k, r.cls)
+        np.testing.assert_allclose(got[4:16], r.as_vector(), rtol=1e-6, atol=1e-6)
+    rows2, st2 = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=cams, dense=True, cap_vox=1 << 18,
+                                 pool_per_view=1 << 17, chain=True).run(b)
+    assert st2 == 0 and torch.equal(rows, rows2)
