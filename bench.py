@@ -393,13 +393,14 @@ def main():
                                chain=not args.no_chain)
 
     eng = make_engine(args.lanes, views)
+    gather_cap = eng.cap_rows * (frames * CAMS // views)      # rows a rank can emit per step: ONE fixed-size all-gather per step
 
     def finish(handle):
         rows, status = eng.collect(handle)
         if status:
             from dfu3d_amd.stages import status_message
             raise SystemExit("device status: " + status_message(status))
-        return D.allgather_rows(eng.gather_layout(rows, batch))
+        return D.allgather_rows(eng.gather_layout(rows, batch), cap_rows=gather_cap)
 
     def barrier():
         if world > 1:
@@ -416,7 +417,7 @@ def main():
                 if st_:
                     from dfu3d_amd.stages import status_message
                     raise SystemExit("device status: " + status_message(st_))
-                rows = D.allgather_rows(eng.gather_layout(r_, batch))
+                rows = D.allgather_rows(eng.gather_layout(r_, batch), cap_rows=gather_cap)
             return rows
         for _ in range(k):
             h = eng.launch(batch)

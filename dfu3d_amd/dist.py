@@ -4,9 +4,9 @@ path: a variable-length all-gather of box rows.
 Frames are independent units (the reference's loop carries no state,
 tools/PENet/main.py:238-349); rank r of R takes frames r, r+R, r+2R, ... -- the
 interleave of the reference's own DistributedSampler
-(pcdet/datasets/__init__.py:48).  Box rows are gathered with the
-gather-sizes / pad / gather idiom of pcdet/utils/commu_utils.py:50-100, as one
-RCCL all_gather over xGMI (backend "nccl" on ROCm) or gloo on CPU.
+(pcdet/datasets/__init__.py:48).  Box rows are gathered as ONE RCCL all_gather per step over xGMI
+(backend "nccl" on ROCm; gloo on CPU) of fixed-capacity buffers that carry their own row count; a one-off gather
+of a whole run's rows uses the gather-sizes / pad / gather idiom of pcdet/utils/commu_utils.py:50-100.
 """
 import os
 from typing import List
@@ -82,23 +82,54 @@ def write_manifest(path, gathered: torch.Tensor, n_frames_total: int, world: int
     return man
 
 
-def allgather_rows(rows: torch.Tensor) -> torch.Tensor:
+# what allgather_rows has cost so far in this process (tests/test_dist.py asserts the per-step figures)
+STATS = {"collectives": 0, "host_syncs": 0}
+
+
+def allgather_rows(rows: torch.Tensor, cap_rows: int = None) -> torch.Tensor:
     """rows (n_r, C) on every rank -> (sum n_r, C) on every rank, rank-major.
 
-    Two collectives: one all_gather of the int64 row count, one all_gather of
-    the rows padded to the maximum count."""
+    cap_rows given (the per-step path: bench.py, a labelling loop): ONE collective and ONE host synchronisation per
+    call.  Every rank sends a fixed-capacity (cap_rows + 1, C) buffer whose first row carries its row count -- no
+    count exchange in front, no `.item()` per rank; the counts of all ranks are read back together after the gather.
+    cap_rows must be the same on every rank and an upper bound of every rank's n_r (the engine's row capacity: more
+    rows cannot exist); a rank with more raises on EVERY rank, after the collective, so that nobody hangs.
+    cap_rows None (a one-off gather of a whole run's rows): the gather-sizes / pad / gather idiom of
+    pcdet/utils/commu_utils.py:50-100 -- two collectives, world + 1 host synchronisations."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
-    cdev = torch.device("cpu") if dist.get_backend() == "gloo" else rows.device
+    gloo = dist.get_backend() == "gloo"
+    C = rows.shape[1]
+    if cap_rows is not None:
+        cap = int(cap_rows)
+        cdev = torch.device("cpu") if gloo else rows.device          # (gloo: CPU rehearsal of the multi-GPU path)
+        buf = torch.zeros((cap + 1, C), dtype=rows.dtype, device=rows.device)
+        n = min(rows.shape[0], cap)
+        buf[0, 0] = rows.shape[0]                                     # the TRUE count: an overflow is seen by everyone
+        buf[1:1 + n] = rows[:n]
+        send = buf.to(cdev)
+        out = torch.empty((world * (cap + 1), C), dtype=rows.dtype, device=cdev)
+        dist.all_gather_into_tensor(out, send)
+        STATS["collectives"] += 1
+        out = out.view(world, cap + 1, C)
+        counts = out[:, 0, 0].to("cpu").tolist()                      # the one host synchronisation
+        STATS["host_syncs"] += 1
+        counts = [int(c) for c in counts]
+        if max(counts) > cap:
+            raise RuntimeError("allgather_rows: rank %d holds %d rows, capacity %d" % (int(np.argmax(counts)), max(counts), cap))
+        return torch.cat([out[r, 1:1 + c] for r, c in enumerate(counts)], 0).to(rows.device)
+    cdev = torch.device("cpu") if gloo else rows.device
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=cdev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
+    STATS["collectives"] += 1
     counts = [int(c.item()) for c in counts]
+    STATS["host_syncs"] += world
     mx = max(max(counts), 1)
-    pad = torch.zeros((mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad = torch.zeros((mx, C), dtype=rows.dtype, device=rows.device)
     pad[:rows.shape[0]] = rows
-    if dist.get_backend() == "gloo" and pad.is_cuda:      # CPU rehearsal of the multi-GPU path
+    if gloo and pad.is_cuda:      # CPU rehearsal of the multi-GPU path
         cpu = pad.cpu()
         out = [torch.empty_like(cpu) for _ in range(world)]
         dist.all_gather(out, cpu)
@@ -106,4 +137,6 @@ def allgather_rows(rows: torch.Tensor) -> torch.Tensor:
     else:
         out = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(out, pad)
+    STATS["collectives"] += 1
+    STATS["host_syncs"] += 1
     return torch.cat([o[:c] for o, c in zip(out, counts)], 0)

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cap):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from dfu3d_amd import dist as D
@@ -34,21 +34,33 @@ def _worker(rank, world, port, q):
     D.init_from_env("gloo")
     n = 3 + 4 * rank if rank != 1 else 0            # ragged, one empty rank
     rows = torch.arange(n * 18, dtype=torch.float64).reshape(n, 18) + 1000 * rank
-    out = D.allgather_rows(rows)
-    q.put((rank, out.numpy()))
+    before = dict(D.STATS)
+    out = D.allgather_rows(rows, cap_rows=cap)
+    cost = {k: D.STATS[k] - before[k] for k in before}
+    err = None
+    if cap is not None:                             # a rank over the capacity: everybody raises, after the collective
+        try:
+            D.allgather_rows(torch.zeros((cap + 1 if rank == world - 1 else 1, 18), dtype=torch.float64), cap_rows=cap)
+        except RuntimeError as e:
+            err = str(e)
+    q.put((rank, out.numpy(), cost, err))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_allgather_rows_gloo(world):
+@pytest.mark.parametrize("world,cap", [(2, 16), (3, 16), (2, None), (3, None)])
+def test_allgather_rows_gloo(world, cap):
+    """cap given (the per-step path): ONE collective and ONE host synchronisation per call whatever the number of
+    ranks -- at N = 8 the count exchange + one `.item()` per rank of the two-collective form were ten host
+    synchronisations per 7.7 ms step; cap None: that form, still used for the one-off gather at the end of a run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cap)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(world)]
+    res = {r: o for r, o, _, _ in got}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -59,6 +71,12 @@ def test_allgather_rows_gloo(world):
     exp = np.concatenate(exp)
     for r in range(world):
         assert np.array_equal(res[r], exp)
+    for r, _, cost, err in got:
+        if cap is not None:
+            assert cost == {"collectives": 1, "host_syncs": 1}, (r, cost)
+            assert err is not None and "capacity" in err, (r, err)
+        else:
+            assert cost == {"collectives": 2, "host_syncs": world + 1}, (r, cost)
 
 
 # ------------------------------------------------------------------ rows carry their frame
