@@ -84,6 +84,10 @@ VARIANTS = {
     "no_mid": ["-DDFU3D_DBG_NO_MID"],
     # cycles between the DBG_T marks of a kernel, summed over its workgroups (tools/p1_timing.py)
     "timing": ["-DDFU3D_DBG_TIMING"],
+    # the HOST side of the C ABI (argument validation, geometry, workspace carve-up) under AddressSanitizer +
+    # UndefinedBehaviorSanitizer; device code as in the product.  CPU only (tools/sanitize_cpu.sh): GPU ASan is not available
+    "asan_host": ["-O1", "-g", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+                  "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-shared-libsan"],
 }
 
 

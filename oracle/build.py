@@ -15,17 +15,32 @@ SRC = os.path.join(HERE, "csrc", "dfu3d_oracle.c")
 SRCS = [SRC]
 DEPS = SRCS
 OUT = os.path.join(HERE, "libdfu3d_oracle.so")
+# `python -m oracle.build --sanitize`: the same source under AddressSanitizer + UndefinedBehaviorSanitizer (gcc), next to
+# the ordinary build.  oracle/penet_oracle.py loads it when DFU3D_ORACLE_SANITIZE=1 (tools/sanitize_cpu.sh; the process
+# needs gcc's libasan preloaded).  CPU only -- never on the GPU box.
+OUT_SAN = os.path.join(HERE, "libdfu3d_oracle_san.so")
 
 
-def build(force: bool = False) -> str:
-    if (not force and os.path.exists(OUT)
-            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)):
-        return OUT
-    cmd = ["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fno-fast-math",
-           "-shared", "-fPIC"] + SRCS + ["-o", OUT, "-lm"]
+def _fresh(out):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, sanitize: bool = False) -> str:
+    out = OUT_SAN if sanitize else OUT
+    if not force and _fresh(out):
+        return out
+    opt = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+           if sanitize else ["-O2"])
+    cmd = ["gcc"] + opt + ["-mfma", "-ffp-contract=off", "-fno-fast-math",
+                           "-shared", "-fPIC"] + SRCS + ["-o", out, "-lm"]
     subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+def selected() -> str:
+    """The library the oracle loads in this process."""
+    return build(sanitize=os.environ.get("DFU3D_ORACLE_SANITIZE") == "1")
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv))

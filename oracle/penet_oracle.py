@@ -35,10 +35,7 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
-        path = _build.OUT
-        if not os.path.exists(path):
-            path = _build.build()
-        _LIB = ctypes.CDLL(path)
+        _LIB = ctypes.CDLL(_build.selected())      # (built if missing or older than its source; DFU3D_ORACLE_SANITIZE=1: the ASan build)
     return _LIB
 
 
