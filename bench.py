@@ -43,7 +43,7 @@ STAGE_KERNELS = {
     "bp_vox": ["k_bp_vox"], "bp_repair": ["k_bp_rebin", "k_ovf_alloc", "k_ovf_gather", "k_ovf_select", "k_bp_fix",
                                           "k_bp_finalize"],
     "segments_build": ["k_seg_count", "k_seg_scan", "k_seg_alloc", "k_seg_write"],
-    "rf_flags": ["k_rf_stream"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"],
+    "rf_flags": ["k_rf_stream", "k_rf_pair"], "rf_resolve": ["k_rf_resolve", "k_rf_ranges"],
     "ballquery_fuse": ["k_tile_scan_class", "k_ball_flags", "k_seg_compact"],
     "range_cluster": ["k_range_cluster_grid", "k_range_cluster_small", "k_range_cluster_large"],
     "lshape_fit": ["k_fit_gather", "k_fit_tiny", "k_fit_medium", "k_fit_big_cost", "k_fit_big_box"],
@@ -90,6 +90,18 @@ def measure_copy_rate(dev, nbytes=1 << 30, reps=8):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
+def sources_sha16():
+    """sha256 over the library's sources (csrc/*.hip, *.hpp, include/dfu3d.h), first 16 hex digits: the committed counter
+    files carry the hash of the build they were collected on (tools/pmc_sq.sh, tools/pmc_to_json.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dfu3d_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dfu3d_amd", "csrc", "*.hpp"))
+                    + [os.path.join(ROOT, "include", "dfu3d.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernels):
     """HBM bytes per launch of the given kernels from the newest committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), summed; None if unknown.
@@ -108,7 +120,8 @@ def pmc_traffic(kernels):
                 if v["fetch_bytes"] is None or v["write_bytes"] is None:
                     return None, None
                 tot += (v["fetch_bytes"] + v["write_bytes"]) * v.get("launches_per_pass", 1)
-        return int(tot), {"file": os.path.basename(files[-1]), "views_per_launch": pm.get("views_per_launch")}
+        return int(tot), {"file": os.path.basename(files[-1]), "views_per_launch": pm.get("views_per_launch"),
+                          "collected_on_this_build": pm.get("sources_sha16") == sources_sha16()}
     except Exception:
         return None, None
 
@@ -127,9 +140,13 @@ def valu_limit(kernel, avg_ms):
         if not v:
             return None
         busy = v["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) / (avg_ms * 1e-3)
+        same = sq.get("_meta", {}).get("sources_sha16") == sources_sha16()
         return {"valu_busy_frac_est": round(busy, 3), "valu_insts_per_wave": round(v["valu_per_wave"], 1),
                 "wait_any_frac": round(v["wait_any_frac"], 3), "source": os.path.basename(files[-1]),
-                "reading": ("vector-instruction issue, not HBM" if busy > 0.5 else "latency / memory")}
+                # the counters are from a committed profiling run, the duration from this one: only the same build makes a figure
+                "collected_on_this_build": bool(same),
+                "reading": (("vector-instruction issue, not HBM" if busy > 0.5 else "latency / memory") if same else
+                            "counters of an OLDER build of the library: indicative only")}
     except Exception:
         return None
 
@@ -170,7 +187,6 @@ def parity_block(rows, exp, n_frames, frame_ids):
     R = rows.cpu().numpy()
     gid = {int(frame_ids[f]): f for f in range(n_frames)}
     sel = R[np.isin(R[:, 0].astype(np.int64), list(gid))]
-    key = lambda a: (a[0], a[1], a[2], a[3])
     got = sorted(((gid[int(r[0])], int(r[1]), int(r[3]), int(r[4])), int(r[2]), r[5:17]) for r in sel)
     want = sorted(((f, c, j, k), cls, np.asarray(v, np.float64)) for f, c, j, k, cls, v in exp)
     same_keys = [g[0] for g in got] == [w[0] for w in want] and [g[1] for g in got] == [w[1] for w in want]
@@ -318,8 +334,13 @@ def main():
     ap.add_argument("--graphs", action="store_true",
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=16,
-                    help="host processes of the 16-process CPU figure (0 = skip; forked before the GPU is initialised)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="host processes of the all-cores CPU figure (-1 = every core this process may run on, "
+                         "os.sched_getaffinity; 0 = skip; forked before the GPU is initialised)")
+    ap.add_argument("--rf-big-frames", type=int, default=192,
+                    help="radius filter once more on the pool of this many frames in ONE launch (0 = skip): the default "
+                         "step's shadow (92 / 184 MB) fits the 256 MiB memory-side cache it has just been written "
+                         "through, a 192-frame pool (550 MB) does not -- the HBM-resident figure next to the cache-resident one")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-steps", type=int, default=3,
                     help="extra passes AFTER the timed region in which every stage is bracketed with HIP events on the "
@@ -336,12 +357,14 @@ def main():
     cpu_pool = None
     under_profiler = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
                       or any(k.upper().startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ))
-    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.cpu_procs > 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_cpu = avail if args.cpu_procs < 0 else min(args.cpu_procs, avail)
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and n_cpu > 0
             and not torch.cuda.is_initialized() and not under_profiler):   # a profiler's preload already owns the GPU
         try:
-            cpu_pool = cpu_all_cores_start(min(args.cpu_procs, os.cpu_count() or 1))
+            cpu_pool = cpu_all_cores_start(n_cpu)
         except Exception as e:                       # the single-thread baseline below does not depend on it
-            log("16-process CPU baseline disabled: %s" % e)
+            log("all-cores CPU baseline disabled: %s" % e)
 
     if args.single_device:
         os.environ["LOCAL_RANK_OVERRIDE"] = "0"
@@ -372,9 +395,24 @@ def main():
                                k_min=args.boxes[0], k_max=args.boxes[1]) for fid in my_frames]
     batch = synth.to_view_batch(scenes, params, dev, dense=dense, frame_ids=my_frames)
     mask_word = 0
+    pack_ms = None
     if not args.byte_masks:
-        batch.pack_masks()                   # the resident input format: one word per pixel, bit j = instance j
+        # the resident input format: one word per pixel, bit j = instance j.  The reference hands uint8 planes
+        # (my_loader.py:522-525): what converting them costs is measured here and reported next to `value`
+        planes = batch.masks
+        batch.pack_masks()
         mask_word = batch.mask_format
+        if rank == 0:
+            from dfu3d_amd import stages as _st
+            V_, M_ = planes.shape[0], planes.shape[1]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                _st.pack_masks(planes.contiguous(), batch.n_inst.contiguous(), V_, M_, H, W, out=batch.masks, word_bytes=mask_word)
+            e1.record()
+            torch.cuda.synchronize()
+            pack_ms = e0.elapsed_time(e1) / 3
+        del planes
     cpu_scenes = None
     if rank == 0 and not args.no_cpu_baseline:
         keep = scenes[:10]
@@ -462,6 +500,40 @@ def main():
         eng.timing = False
         kern = eng.timing_summary()
         counts = eng.counters()
+    # ---- radius filter on a pool larger than the memory-side cache (one launch over --rf-big-frames frames) ----
+    rf_big = None
+    if (rank == 0 and world == 1 and not args.no_kernel_timing and args.timing_steps > 0 and args.rf_big_frames > frames
+            and dense):
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            nb = args.rf_big_frames
+            log("[bench] radius filter on %d frames in one launch ..." % nb)
+            scenes_b = [synth.make_scene(fid, H=H, W=W, M=MAX_INST, cams=CAMS, dense=True, device=dev,
+                                         k_min=args.boxes[0], k_max=args.boxes[1]) for fid in range(nb)]
+            big = synth.to_view_batch(scenes_b, params, dev, dense=True, frame_ids=list(range(nb)))
+            del scenes_b
+            if not args.byte_masks:
+                big.pack_masks()
+            engb = PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=nb * CAMS, dense=True, cap_vox=1 << 18,
+                                   pool_per_view=1 << 17, device=dev, lanes=1, chain=False)
+            engb.run(big)
+            engb.reset_timing()
+            engb.timing = True
+            for _ in range(2):
+                engb.run(big)
+            engb.timing = False
+            kb, cb = engb.timing_summary(), engb.counters()
+            pts = cb["pool_points"] / 2
+            ms = sum(kb[k][0] for k in RF_STAGE if k in kb) / 2
+            rf_big = {"frames": nb, "points_per_launch": int(pts), "shadow_MB": round(16 * pts / 1e6, 1),
+                      "avg_ms": round(ms, 4), "alg_bytes_per_launch": int(21 * pts),
+                      "achieved": round(21 * pts / (ms * 1e-3) / 1e9, 2), "frac": round(21 * pts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                      "stages_ms": {k: round(kb[k][0] / 2, 4) for k in RF_STAGE if k in kb}}
+            del engb, big
+            torch.cuda.empty_cache()
+        except Exception as e:                                       # never lose the timing line
+            rf_big = {"error": repr(e)}
     copy_rate = measure_copy_rate(dev) if rank == 0 else None
 
     if rank == 0:
@@ -481,6 +553,14 @@ def main():
                        "boxes_per_step_all_ranks": n_boxes, "parallelism": "frames sharded x%d" % world},
             "hbm_copy_GBs_measured": round(copy_rate, 1),
         }
+        if pack_ms is not None:
+            # `value` is quoted on masks that are resident as packed words (SURVEY.md 8d prices "M/8 mask-bits"); the
+            # reference's boundary hands uint8 planes: converting a step's planes, serialised in front of the step
+            step_s = dt / args.steps
+            out["mask_packing"] = {"pack_ms_per_step": round(pack_ms, 4), "bytes_read_per_step": int(frames * CAMS * MAX_INST * H * W),
+                                   "value_pack_inclusive": round(frames * world / (step_s + pack_ms * 1e-3), 3),
+                                   "how": "dfu3d_pack_masks on the step's (V, M, H, W) uint8 planes, HIP events, added to ms_per_step "
+                                          "(not overlapped); `--byte-masks` runs the path on the planes themselves"}
         if kern:
             V1 = frames * CAMS                         # views per launch of the bracketed passes
             c1 = {k: v / tsteps for k, v in counts.items()}      # per pass
@@ -498,6 +578,12 @@ def main():
                     row["frac_of_peak"] = round(alg[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 table.append(row)
             out["kernels"] = table
+            pass_ms = sum(ms for ms, _ in kern.values()) / tsteps
+            pass_alg = sum(v for k, v in alg.items() if k != "rf_stage" and k in kern) + alg["rf_stage"]
+            out["pass"] = {"alg_bytes": int(pass_alg), "ms": round(pass_ms, 3), "achieved": round(pass_alg / (pass_ms * 1e-3) / 1e9, 2),
+                           "frac": round(pass_alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                           "what": "algorithmic bytes of every stage of one single-stream pass over %d views / the sum of "
+                                   "the bracketed stage durations" % V1}
             out["kernel_timing"] = {"how": "HIP events on the launch stream around every stage, %d passes after the timed "
                                            "region, one stream, %d views per launch" % (tsteps, V1),
                                     "sum_ms_per_pass": round(sum(ms for ms, _ in kern.values()) / tsteps, 3),
@@ -530,7 +616,11 @@ def main():
                         "avg_ms": fl["avg_ms"], "achieved": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9, 2),
                         "frac": round(alg["rf_stage"] / (fl["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "points_per_launch": int(c1["pool_points"]),
-                    "undecided_after_phase_A": int(c1.get("rf_undecided", 0))}
+                    "undecided_after_phase_A": int(c1.get("rf_undecided", 0)),
+                    "cache_note": "the shadow of this launch (%.0f MB) was written by k_seg_write just before and is read back "
+                                  "through the 256 MiB memory-side cache; `big_pool` is the same stage on a pool that does not fit it"
+                                  % (16 * c1["pool_points"] / 1e6),
+                    "big_pool": rf_big}
         if cpu_scenes is not None and world == 1:
             fps, nf, secs, exp_rows = cpu_baseline(cpu_scenes, params, dense)
             try:
@@ -540,14 +630,14 @@ def main():
             if cpu_pool is not None:
                 try:
                     fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)
-                    out["cpu_baseline_16proc"] = {
+                    out["cpu_baseline_allcores"] = {
                         "value": round(fps_all, 3), "unit": "frames/s", "cores": cpu_pool["n"], "kind": "port",
-                        "sample": "%d processes (the box's CPU share, not all %d host cores), each the same synthetic frame "
-                                  "(6 cams) through the oracle at the same time; slowest %.1fs"
+                        "sample": "%d processes = every core this process may run on (os.sched_getaffinity; the host has %d), "
+                                  "each the same synthetic frame (6 cams) through the oracle at the same time; slowest %.1fs"
                                   % (cpu_pool["n"], os.cpu_count(), t_all)}
                     cpu_pool = None
                 except Exception as e:
-                    log("16-process CPU baseline failed: %s" % e)
+                    log("all-cores CPU baseline failed: %s" % e)
             out["cpu_baseline"] = {"value": round(fps, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d of the same synthetic frames (6 cams each) through oracle/penet_oracle.py "
                                              "(NumPy + C, 1 thread) in %.1fs; host has %d cores" % (nf, secs, os.cpu_count())}

@@ -218,3 +218,22 @@ def test_timed_layout_matches_oracle_packed_masks_chunks_lanes_chain():
     h1 = eng.launch(b)
     rows1, st1 = eng.collect(h1)
     assert st1 == 0 and torch.equal(rows, rows1)
+    # the layout of `bench.py --byte-masks` -- the reference's np.uint8(mask) planes (V, M, H, W) as they cross the
+    # boundary (my_loader.py:522-525), same chunks / lanes / chain -- gives the same rows bit for bit
+    bb = synth.to_view_batch(scenes, p, DEV, dense=True)
+    assert bb.mask_format == 0 and bb.masks.dim() == 4 and bb.masks.dtype == torch.uint8
+    rows_b, st_b = eng.run(bb)
+    assert st_b == 0 and torch.equal(rows, rows_b)
+
+
+def test_seeded_slice_of_the_randomised_parity_sweep():
+    """tools/stress_parity.py's sweep -- random image sizes, cameras, frames, chunkings, lanes, mask layouts, one C call
+    per chunk or stage by stage, and parameter variants (nb_points 2, voxel caps, the statistical pair on, sparse mode,
+    H4 off) -- for a fixed seed: every case's rows against the oracle, and a second run bit-identical.  The tool runs
+    more cases / other seeds after kernel changes; this slice is what every round's GPU suite sees."""
+    _need_gpu()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import stress_parity
+    done, bad, log = stress_parity.run_cases(n_cases=12, seed=2026, budget_s=75.0)
+    assert bad == 0, "\n".join(log)
+    assert done >= 6, "only %d cases inside the time budget" % done

@@ -30,6 +30,11 @@ for k, c in sorted(acc.items()):
     m["wait_any_frac"] = m.get("SQ_WAIT_ANY", 0) / wc
     m["active_valu_frac"] = m.get("SQ_ACTIVE_INST_VALU", 0) / wc
     out[k] = m
+import hashlib
+h = hashlib.sha256()
+for f in sorted(glob.glob("dfu3d_amd/csrc/*.hip") + glob.glob("dfu3d_amd/csrc/*.hpp") + ["include/dfu3d.h"]):
+    h.update(open(f, "rb").read())
+out["_meta"] = {"sources_sha16": h.hexdigest()[:16]}        # bench.py: are these counters of the build it is timing?
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print("wrote", sys.argv[2], len(out))
 PY
