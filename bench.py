@@ -241,6 +241,27 @@ def _cpu_worker(go, barrier, tasks, done):
         done.put("error: %s" % e)
 
 
+def usable_cores():
+    """Cores this process can actually use: its affinity mask, cut to the CPU quota of its control group (a GPU box
+    gives a job a share of the host -- 16 cores per GPU on this pool -- while the mask still shows all of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_all_cores_start(nproc):
     """Fork the idle workers (must happen before the first GPU call of this process)."""
     import multiprocessing as mp
@@ -335,8 +356,8 @@ def main():
                     help="replay one captured hipGraph per chunk (measured slower than stream launches on ROCm 7.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="host processes of the all-cores CPU figure (-1 = every core this process may run on, "
-                         "os.sched_getaffinity; 0 = skip; forked before the GPU is initialised)")
+                    help="host processes of the all-cores CPU figure (-1 = every core this job may use: affinity mask cut "
+                         "to the cgroup CPU quota; 0 = skip; forked before the GPU is initialised)")
     ap.add_argument("--rf-big-frames", type=int, default=192,
                     help="radius filter once more on the pool of this many frames in ONE launch (0 = skip): the default "
                          "step's shadow (92 / 184 MB) fits the 256 MiB memory-side cache it has just been written "
@@ -357,7 +378,7 @@ def main():
     cpu_pool = None
     under_profiler = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
                       or any(k.upper().startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ))
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = usable_cores()
     n_cpu = avail if args.cpu_procs < 0 else min(args.cpu_procs, avail)
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and n_cpu > 0
             and not torch.cuda.is_initialized() and not under_profiler):   # a profiler's preload already owns the GPU
@@ -632,8 +653,8 @@ def main():
                     fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)
                     out["cpu_baseline_allcores"] = {
                         "value": round(fps_all, 3), "unit": "frames/s", "cores": cpu_pool["n"], "kind": "port",
-                        "sample": "%d processes = every core this process may run on (os.sched_getaffinity; the host has %d), "
-                                  "each the same synthetic frame (6 cams) through the oracle at the same time; slowest %.1fs"
+                        "sample": "%d processes = every core this job may use (affinity mask cut to the control group's CPU quota; "
+                                  "the host has %d), each the same synthetic frame (6 cams) through the oracle at the same time; slowest %.1fs"
                                   % (cpu_pool["n"], os.cpu_count(), t_all)}
                     cpu_pool = None
                 except Exception as e:
