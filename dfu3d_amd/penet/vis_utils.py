@@ -39,10 +39,12 @@ def get_fov_flag_gpu(lidar, calib, img_shape, device="cuda:0"):
 
 
 def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=None, params=None,
-                         crop_hw=None, device="cuda:0", return_rows=False, save_points=True):
+                         crop_hw=None, device="cuda:0", return_rows=False, save_points=True, points_dir=None):
     """vis_utils.py:136-166.  `idx` is the frame id (int -> zero-padded to 6, or a
     file stem); `crop_hw` reproduces the shipped [:352,:1216] crop (hazard H11),
-    default: no crop (canonical nuScenes 900x1600)."""
+    default: no crop (canonical nuScenes 900x1600).  save_points=False: labels only -- the image is then used for
+    its size alone, and a data set without image_2/ is labelled on the depth map's size; points_dir: where the
+    float16 virtual-point file goes (default <root>/velodyne_depth, vis_utils.py:156)."""
     from PIL import Image
     p = params or Params()
     file_idx = str(idx).zfill(6)                                      # :137
@@ -51,14 +53,19 @@ def save_depth_as_points(depth, idx, root_path, seg_provider=None, label_root=No
     file_calib = os.path.join(root_path, 'calib', file_idx + '.txt')
     calib = Calibration(file_calib)                                   # :142
     lidar = np.fromfile(str(file_velo_path), dtype=np.float32).reshape(-1, 4)   # :144
-    image1 = np.array(Image.open(file_image_path).convert('RGB'), dtype=np.int32)   # :146
+    if save_points or os.path.exists(file_image_path):
+        image1 = np.array(Image.open(file_image_path).convert('RGB'), dtype=np.int32)   # :146
+    else:                                # labels only, no image on disk: its size is the depth map's, its colours are not needed
+        dshape = tuple(depth.shape)
+        image1 = np.zeros((int(dshape[-2]), int(dshape[-1]), 3), np.int32)
     image = image1 if crop_hw is None else image1[:crop_hw[0], :crop_hw[1]]
     seg = (seg_provider or (lambda path: load_seg_npz(root_path, file_idx)))(file_image_path)
     thing_classes, masks, classes, scores, boxes2D = seg              # :150
     H, W = image.shape[0], image.shape[1]
     lidar = lidar[get_fov_flag_gpu(lidar, calib, (H, W), device)]     # :152-154: FOV test on the (cropped) image size
-    paths = os.path.join(root_path, 'velodyne_depth')                 # :156-160
-    os.makedirs(paths, exist_ok=True)
+    paths = points_dir or os.path.join(root_path, 'velodyne_depth')   # :156-160
+    if save_points:
+        os.makedirs(paths, exist_ok=True)
     out_path = os.path.join(paths, file_idx + '.npy')
     if isinstance(depth, torch.Tensor):
         depth = depth.detach().cpu().numpy()

@@ -331,16 +331,18 @@ class BatchedLabeler:
         def __init__(self, stem, n_total=0):
             self.stem, self.image, self.points, self.n_total = stem, None, None, n_total
 
-    def _label_whole_frame(self, root, stem, label_out, depth_dir, view):
+    def _label_whole_frame(self, root, stem, label_out, depth_dir, view, npy_out=None):
         """A frame with more instances than one batch view holds (DFU3D_MAX_INST = 32): the reference loops over
         every mask (my_loader.py:547), so the frame goes through the one-frame path, which takes its instances in
         groups of 32 (penet/my_loader.py) -- same label file as `--batch-frames 0` writes.  -> engine rows with
-        column 0 = `view`."""
+        column 0 = `view`.  Like the batched path it needs image_2/ only when the virtual points are written, and it
+        writes them to the caller's npy_out."""
         from .penet.vis_utils import load_seg_npz, save_depth_as_points
         depth = np.load(os.path.join(depth_dir or os.path.join(root, 'depth_2'), stem + '.npy')).astype(np.float32)
         _, r = save_depth_as_points(depth, stem, root, label_root=label_out, params=self.p,
                                     seg_provider=(lambda path: load_seg_npz(root, stem, self.seg_dir)),
-                                    device=str(self.dev), return_rows=True, save_points=self.want_points)
+                                    device=str(self.dev), return_rows=True, save_points=self.want_points,
+                                    points_dir=npy_out)
         r = np.asarray(r, np.float64).reshape(-1, 24).copy()
         r[:, 0] = view
         return r
@@ -436,7 +438,7 @@ class BatchedLabeler:
                 print("[dfu3d] %s: %d instances, more than the %d of a batch view: labelled through the one-frame path"
                       % (frames[i].stem, frames[i].n_total, self.max_masks), file=sys.stderr)
                 rows_h = np.concatenate([rows_h[rows_h[:, 0] != i],
-                                         self._label_whole_frame(root, frames[i].stem, label_out, depth_dir, i)], 0)
+                                         self._label_whole_frame(root, frames[i].stem, label_out, depth_dir, i, npy_out)], 0)
                 self.stats["frames_over_32_instances"] = self.stats.get("frames_over_32_instances", 0) + 1
             pending.append(writers.submit(self._write, frames, rows_h, label_out, npy_out, vp, set(whole)))
             self.stats["frames"] += len(frames)

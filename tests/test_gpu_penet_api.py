@@ -406,8 +406,11 @@ def test_cli_batched_path_labels_every_instance_of_a_frame_with_40(tmp_path, cap
         exp[f] = O.depth2pointsrgbpm(s.depth[0].numpy().copy()[:, :, None], img, oc, lid, O.NUSC_CLASSES,
                                      masks.astype(np.float32), classes, boxes, op, plane_key=f, want_points=False)
     assert max(r.inst for r in exp[1].rows) >= 32                      # the case is real: boxes beyond the 32nd instance
-    for procs in ("0",):
-        assert cli.main(["--detpath", root, "--batch-frames", "4", "--reader-procs", procs, "--conf_files", "x.yaml"]) == 0
+    for procs in ("0", "1"):                  # reader threads | forked reader processes (the m_total path of reader_pool)
+        if procs == "1":                      # labels only: no image_2/ is needed, in the fallback for the 40-instance frame either
+            shutil.move(os.path.join(root, "image_2"), os.path.join(root, "image_2_away"))
+        assert cli.main(["--detpath", root, "--batch-frames", "4", "--reader-procs", procs, "--conf_files", "x.yaml"]
+                        + (["--no-virtual-points"] if procs == "1" else [])) == 0
         assert "000001: 40 instances" in capsys.readouterr().err
         for f in range(3):
             objs = read_label_file(os.path.join(root, "label_2", "%06d.txt" % f))
@@ -419,6 +422,7 @@ def test_cli_batched_path_labels_every_instance_of_a_frame_with_40(tmp_path, cap
                 np.testing.assert_allclose(got, r.as_vector(), rtol=1e-6, atol=1e-6)
         batched = {f: open(os.path.join(root, "label_2", "%06d.txt" % f)).read() for f in range(3)}
         shutil.rmtree(os.path.join(root, "label_2"))
+    shutil.move(os.path.join(root, "image_2_away"), os.path.join(root, "image_2"))
     assert cli.main(["--detpath", root, "--batch-frames", "0", "--conf_files", "x.yaml"]) == 0
     for f in range(3):
         assert open(os.path.join(root, "label_2", "%06d.txt" % f)).read() == batched[f]
