@@ -78,7 +78,7 @@ SIGNATURES = {
                                     c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P]),
     "dfu3d_bin_table_init": (c_i32, [_P, c_i64, _P]),
-    "dfu3d_backproject_scratch_words": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32,
+    "dfu3d_backproject_scratch_words": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64,
                                                 ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "dfu3d_backproject_bin": (c_i32, [_P, _P, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32,
                                       ctypes.POINTER(BinGeom), c_i32, _P, _P, _P, c_i32, _P,

@@ -54,7 +54,7 @@ int64_t carve(const dfu3d_chain_cfg *c, char *base, ChainWs *w) {
   t.table_entries = (int64_t)c->geom.t_n * c->geom.p_n;
   int64_t pw = 0, bw = 0;
   if (c->dense) {
-    dfu3d_backproject_scratch_words(c->V, c->H, c->W, c->cap_vox, c->geom.max_points_per_voxel, &pw, &bw);
+    dfu3d_backproject_scratch_words(c->V, c->H, c->W, c->cap_vox, c->geom.max_points_per_voxel, t.table_entries, &pw, &bw);
     t.table = take(V * t.table_entries * DFU3D_TABLE_ENTRY_BYTES);
     t.pix_bin = (uint32_t *)take(4 * pw);
     t.blk_cnt = (int32_t *)take(4 * bw);
@@ -133,7 +133,7 @@ extern "C" int64_t dfu3d_workspace_bytes(int32_t stage, const dfu3d_sizes *z) {
     case DFU3D_STAGE_BACKPROJECT_BIN: {                  /* table, pix_bin, blk_cnt */
       int64_t pw = 0, bw = 0;
       if (z->table_entries <= 0 ||
-          dfu3d_backproject_scratch_words(z->V, z->H, z->W, z->cap_vox, z->max_points_per_voxel, &pw, &bw))
+          dfu3d_backproject_scratch_words(z->V, z->H, z->W, z->cap_vox, z->max_points_per_voxel, z->table_entries, &pw, &bw))
         return DFU3D_EINVAL;
       return up(V * z->table_entries * DFU3D_TABLE_ENTRY_BYTES) + up(4 * pw) + up(4 * bw);
     }

@@ -154,6 +154,14 @@ __device__ __forceinline__ void toggle_first_bit(uint32_t *bitmap_v, int W, int 
   atomicXor(&bitmap_v[tile * 32 + (local >> 5)], 1u << (local & 31));
 }
 
+// Occupancy of a view's table: one BYTE per SEGMENT of 64 consecutive entries (a line of every plane).  Whoever commits
+// to a bin writes a 1 for its segment -- a plain store, every writer the same value; the voxel pass walks the occupied
+// segments and nothing else.  (One BIT per segment set with atomicOr was built first: every tile of an image region
+// hit the same few words, and the binning pass went from 2.8 to 8.4 ms on those same-address atomics.)
+constexpr int SEG_SHIFT = 6;
+// (segments of 64 entries of the FLAT bin index, whatever the row length: every load of the voxel pass is one aligned
+// line per plane; segments cut along the theta rows -- 25 per row, the last one partial -- measured 1.25 ms against 1.15)
+__device__ __forceinline__ void mark_segment(uint8_t *occ_v, uint32_t b) { occ_v[b >> SEG_SHIFT] = 1; }
 // table update of the exact (tier-2) classification
 __device__ __forceinline__ void commit_pixel(const Table &T, int64_t e, int pix, double key, int pix_bits,
                                              uint32_t *bitmap_v, int W, int tiles_x) {
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
     const FastCal *__restrict__ fastcal, const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, int W, int H,
     int tiles_x, int tiles_y, int key_axis,
     int64_t E_view, void *table, int64_t E_total, int *__restrict__ n_amb, uint32_t *__restrict__ amb_list,
-    int pix_bits, uint32_t *__restrict__ bitmap, int BW) {
+    int pix_bits, uint32_t *__restrict__ bitmap, int BW, uint8_t *__restrict__ occ, int OW) {
   __shared__ uint32_t s_bits[32 * RPT];           // this workgroup's piece of the first-pixel bit map (RPT bit-map tiles)
   // the workgroup's undecided pixels: a short list (0.7 % of the pixels are undecided: 14 of a tile's 2048; a list for
   // all 2048 took 8 KB of the workgroup's LDS); what does not fit goes to the global list one pixel at a time
@@ -556,6 +564,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
   if (threadIdx.x == 0) { s_namb = 0; s_t0 = 0x7FFFFFFF; s_p0 = 0x7FFFFFFF; }
   if (threadIdx.x < 32 * RPT) s_bits[threadIdx.x] = 0u;
   uint32_t *bitmap_v = bitmap + (size_t)v * BW;
+  uint8_t *occ_v = occ + (size_t)v * OW * 4;
   // The window keeps a bin's first pixel as its index INSIDE the workgroup's tile (row-major over the tile's
   // RPT * TILE_H rows of TILE_W pixels: the same order as the global index for pixels of one tile), which is also the
   // bit it has in s_bits; pixel `loc` of this tile became a bin's first pixel, oldf (global) is what it displaced
@@ -651,6 +660,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
         const uint32_t oldf = atomicMin(&T.first[e], base + k);
         atomicMin(&T.kmin[e], ok);
         atomicMin(&T.combo[e], cm);
+        mark_segment(occ_v, b);
         if (oldf > base + k) new_first(loc0 + k, oldf);
       }
     }
@@ -690,6 +700,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
         const uint32_t oldf = atomicMin(&T.first[e], pix);
         atomicMin(&T.kmin[e], ok);
         atomicMin(&T.combo[e], cm);
+        mark_segment(occ_v, b);
         if (oldf > pix) new_first(loc, oldf);
       }
     }
@@ -701,17 +712,18 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
   // (the bit-map update below needs it): all of a thread's atomics are issued before the first returned value is looked
   // at -- one memory round trip per workgroup instead of one per slot of the thread.
   constexpr int FL = (WIN_T * WIN_P + PB - 1) / PB;
-  uint32_t f_loc[FL], f_new[FL], f_old[FL];
+  uint32_t f_loc[FL], f_new[FL], f_old[FL], f_seg[FL];
 #pragma unroll
   for (int i = 0; i < FL; i++) {
     const int w = threadIdx.x + i * PB;
-    f_loc[i] = 0u; f_new[i] = NOBIN; f_old[i] = 0u;
+    f_loc[i] = 0u; f_new[i] = NOBIN; f_old[i] = 0u; f_seg[i] = NOBIN;
     const uint32_t cw = (w < WIN_T * WIN_P) ? s_cnt[w] : 0u;
     if (cw == 0u) continue;
     static_assert(WIN_T * WIN_P <= 768 && WIN_P == 48, "w / 48 as (w * 1366) >> 16 is exact below 768 * 48 / 18");
     const uint32_t wq = __umul24((uint32_t)w, 1366u) >> 16, wr = (uint32_t)w - __umul24(wq, (uint32_t)WIN_P);   // w / 48, w % 48
     const uint32_t b = __umul24((uint32_t)t0 + wq, (uint32_t)g.p_n) + ((uint32_t)p0 + wr);
     const int64_t e = tb0 + b;
+    f_seg[i] = b >> SEG_SHIFT;
     f_loc[i] = s_first[w];
     f_new[i] = global_pix(f_loc[i]);
     atomicAdd(&T.cnt[e], cw);
@@ -719,6 +731,9 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
     atomicMin(&T.kmin[e], s_kmin[w]);
     atomicMin(&T.combo[e], s_combo[w]);
   }
+#pragma unroll
+  for (int i = 0; i < FL; i++)
+    if (f_seg[i] != NOBIN) occ_v[f_seg[i]] = 1;                          // (consecutive lanes flush consecutive bins: 1-3 addresses per wave)
 #pragma unroll
   for (int i = 0; i < FL; i++)
     if (f_old[i] > f_new[i]) new_first(f_loc[i], f_old[i]);      // (f_new = NOBIN, the largest value, for an idle slot)
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g, int W,
     int HW, int key_axis, int64_t E_view, void *table, int64_t E_total, const int *__restrict__ n_amb,
     const uint32_t *__restrict__ amb_list, uint32_t *__restrict__ status, int pix_bits,
-    uint32_t *__restrict__ bitmap, int BW, int tiles_x) {
+    uint32_t *__restrict__ bitmap, int BW, int tiles_x, uint8_t *__restrict__ occ, int OW) {
   const int v = blockIdx.y;
   const int na = n_amb[v];
   const ViewCalib c = calib[v];
@@ -756,7 +771,10 @@ __global__ __launch_bounds__(256) void k_bp_bin_amb(
     const int pix = (int)amb_list[(size_t)v * HW + e];
     double key;
     const uint32_t b = pixel_bin(c, rc, g, W, pix, depth[(size_t)v * HW + pix], key_axis, key, rerr);
-    if (b != NOBIN) commit_pixel(T, tb0 + b, pix, key, pix_bits, bitmap + (size_t)v * BW, W, tiles_x);
+    if (b != NOBIN) {
+      commit_pixel(T, tb0 + b, pix, key, pix_bits, bitmap + (size_t)v * BW, W, tiles_x);
+      mark_segment(occ + (size_t)v * OW * 4, b);
+    }
   }
   if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
 }
@@ -769,9 +787,31 @@ __device__ __forceinline__ unsigned long long row_piece(const uint32_t *bitmap_v
 }
 __global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, const uint32_t *__restrict__ bitmap,
                                                  uint32_t *__restrict__ wpre, int *__restrict__ n_vox, int cap_vox,
-                                                 uint32_t *__restrict__ status) {
+                                                 uint32_t *__restrict__ status, const uint32_t *__restrict__ occ, int OW,
+                                                 int NSEG, int *__restrict__ seg_list, int *__restrict__ n_occ) {
   __shared__ int s_w[SCB / 64];
   const int v = blockIdx.x;
+  // The occupied segments of the view's table in ascending order -- theta row by theta row, along phi inside a row: the
+  // work list of the voxel pass (OW words of four occupancy bytes).  Consecutive entries are neighbours along phi, i.e.
+  // along an image row: their voxels have consecutive ranks, and the four waves of a workgroup of the voxel pass, which
+  // take four of them at the same time, write neighbouring pieces of the outputs and read the same bit-map lines.
+  // (The list ordered column by column -- vertical neighbours, which share depth-map and mask lines -- was measured:
+  // the voxel pass 1.33 ms instead of 1.15; a run of four vertical neighbours per wave: 1.40.)
+  {
+    const uint32_t *ov = occ + (size_t)v * OW;
+    int run = 0;
+    for (int w0 = 0; w0 < OW; w0 += SCB) {
+      const int w = w0 + threadIdx.x;
+      const uint32_t word = (w < OW) ? ov[w] : 0u;
+      int tot;
+      int at = run + block_excl_scan<SCB / 64>(__popc(word & 0x01010101u), s_w, tot);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if ((word >> (8 * q)) & 1u) seg_list[(size_t)v * NSEG + at++] = w * 4 + q;
+      run += tot;
+    }
+    if (threadIdx.x == 0) n_occ[v] = run;
+  }
   const uint32_t *bv = bitmap + (size_t)v * BW;
   int running = 0;
   for (int j0 = 0; j0 < NJ; j0 += SCB) {
@@ -792,11 +832,6 @@ __global__ __launch_bounds__(SCB) void k_bp_scan(int BW, int NJ, int tiles_x, co
   }
 }
 
-// the bit map and its prefix: the rank of a first pixel = the voxel's place in first-seen order
-struct RankMap {
-  const uint32_t *bitmap, *wpre;
-  int BW, NJ, tiles_x, W;
-};
 struct VoxOut {
   uint32_t *vox_pix, *it_bits;
   double *it_x, *it_y, *it_z;
@@ -815,181 +850,98 @@ __device__ __forceinline__ void emit_voxel(const VoxOut &o, size_t at, const Vie
   o.it_z[at] = z;
 }
 
-// what finishing a voxel needs of its view
-struct VoxCtx {
-  ViewCalib c;
-  Recip rc;
-  Table T;
-  const float *dv;
-  const void *masks;
-  int64_t tb0;
-  int mask_format, m, max_inst, HW, W, key_axis, pix_bits, cap_vox, cap_q, max_points, max_voxels;
-};
-__device__ __forceinline__ VoxCtx make_vox_ctx(const ViewCalib *calib, int v, void *table, int64_t E_total,
-                                               int64_t E_view, const void *masks, int mask_format, const int *n_inst,
-                                               int max_inst, const float *depth, int HW, int W, int key_axis,
-                                               int pix_bits, int cap_vox, int cap_q, int max_points, int max_voxels) {
-  VoxCtx X;
-  X.c = calib[v];
-  X.rc = make_recip(X.c);
-  X.T = table_view(table, E_total);
-  X.dv = depth + (size_t)v * HW;
-  X.masks = masks;
-  X.tb0 = (int64_t)v * E_view;
-  X.mask_format = mask_format;
-  X.m = masks ? min(max(n_inst[v], 0), max_inst) : 0;
-  X.max_inst = max_inst; X.HW = HW; X.W = W; X.key_axis = key_axis; X.pix_bits = pix_bits;
-  X.cap_vox = cap_vox; X.cap_q = cap_q; X.max_points = max_points; X.max_voxels = max_voxels;
-  return X;
-}
-
-// voxel k of view v lives in bin b: representative, outputs, table entry left clean (or queued for the repair)
-__device__ __forceinline__ void vox_finish(const VoxCtx &X, const VoxOut &out, int v, int k, uint32_t b,
-                                           uint32_t *q_bins, int *q_rank, int *n_q, uint32_t *status) {
-  const Table &T = X.T;
-  const int64_t e = X.tb0 + b;
-  // the three planes of the entry are requested together, and so are the two reads that hang on the representative
-  // pixel (its depth and its mask word): four dependent round trips per voxel instead of six
-  const uint32_t cw = T.cnt[e];
-  const unsigned long long e_combo = T.combo[e], e_kmin = T.kmin[e];
-  const uint32_t pix = (uint32_t)(e_combo & ((1ull << X.pix_bits) - 1ull));
-  const int row = (int)pix / X.W, col = (int)pix - row * X.W;
-  const float d_pix = X.dv[pix];
-  const uint32_t m_bits = X.masks ? mask_bits_at(X.masks, X.mask_format, v, X.max_inst, X.m, X.HW, (int)pix) : 0u;
-  double x, yy, z;
-  pixel_to_lidar(X.c, X.rc, col, row, d_pix, x, yy, z);
-  double key = (X.key_axis == 2) ? z : yy;
-  key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
-  // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
-  if (cw > (uint32_t)X.max_points || ordered_key(key) != e_kmin) {
-    const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
-    if (slot < X.cap_q) { q_bins[(size_t)v * X.cap_q + slot] = b; q_rank[(size_t)v * X.cap_q + slot] = k; }
-    else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
-    return;
-  }
-  if (k < X.max_voxels) {
-    const size_t at = (size_t)v * X.cap_vox + k;
-    out.vox_pix[at] = pix;
-    out.it_bits[at] = m_bits;
-    out.it_x[at] = x;
-    out.it_y[at] = yy;
-    out.it_z[at] = z;
-  }
-  // leave the table clean for the next pass (rep is only ever written by the repair)
-  T.kmin[e] = ~0ull;
-  T.combo[e] = ~0ull;
-  T.cnt[e] = 0u;
-  T.first[e] = NOBIN;
-}
-
-// ---- P4: raster walk over the first-pixel bit map: rank, bin, representative, outputs, table reset ----
-// The pass is a chain of four dependent memory round trips per voxel (first pixel's depth -> table entry ->
-// representative's depth and mask word -> stores): with fewer workgroups per compute unit it slows down in proportion
-// (measured: 3 / 2 / 1 workgroups per CU: 1.67 / 2.2 / 3.7 ms), so lanes in flight are what it runs on.  The first
-// pixels tier 1 cannot classify go through tier 1.5 (pixel_bin_mid) here; what even that leaves (in practice
-// nothing) is PARKED for k_bp_vox_amb: pixel_bin() inline cost 150 vector registers, i.e. three waves per SIMD.  A
-// voxel of the workgroup's list is one packed word (local row | local column | place in its row piece): 16 KB of LDS.
+// ---- P4: walk over the occupied table segments: rank, representative, outputs, table reset -------------------
+// A wave takes one segment of 64 consecutive table entries at a time: the four planes of the segment are four coalesced
+// loads, every entry with a count is a voxel, and its place in first-seen order is the rank of its FIRST pixel in the
+// bit map (prefix of the pixel's row piece + set bits before it).  What a voxel needs besides its entry -- the bit-map
+// word and prefix at its first pixel, depth and mask word at its representative pixel -- is requested together: TWO
+// dependent round trips per segment.  The representative is the pixel p* of the packed word: the smallest pixel among
+// those whose CUT key is minimal, a superset of the exact arg-mins, so it is the representative iff its exact key
+// equals kmin; bins where that fails (two keys differ only below the cut: practically never) and bins that saw more
+// than max_points pixels go to the exact repair.  The entries are reset with four coalesced stores.
+// (Until round 4 the pass walked the BIT MAP: a voxel was found as a set bit, its first pixel's depth was gathered and
+// the pixel classified a second time -- float32 tier, middle tier, a parked rest for a full-fp64 kernel -- only to learn
+// its bin; the table entry was three scattered reads behind that: four dependent round trips, 86 registers, 1.42 ms.)
 constexpr int VXB = 256;
-constexpr int VX_PIECES = 64;                 // rows of a workgroup's 64-pixel-wide tile = 4096 pixels
-struct VoxPark {
-  int *n;                                     // per view: parked voxels
-  uint32_t *f, *k;                            // per view, HW slots each: first pixel, rank
+constexpr int VOX_GX = 512;         // workgroups per view at most (2 048 waves; a wave walks its segments with the grid's stride).
+                                    // A camera of the bench touches ~1 800 of its table's 20 252 segments: a grid over the whole
+                                    // table would be workgroups that start only to find nothing.  Measured: 128 / 256 / 512 /
+                                    // 1 024 workgroups 1.13 / 1.17 / 1.07 / 1.07 ms; register budgets for 7 / 8 waves per SIMD
+                                    // (the code needs 76 registers: 6 waves) spill: 1.23 / 1.58 ms
+struct VoxWalk {
+  const int *seg_list, *n_occ;
+  const uint32_t *bitmap, *wpre;
+  int NSEG, BW, NJ, tiles_x;
 };
 __global__ __launch_bounds__(VXB) void k_bp_vox(
-    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const FastCal *__restrict__ fastcal,
-    const float2 *__restrict__ tab, dfu3d_bin_geom g, FastGeom fg, const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, RankMap R, VoxOut out, int key_axis,
-    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
-    uint32_t *__restrict__ status, VoxPark park) {
-  __shared__ uint32_t s_vox[VX_PIECES * 64];
-  __shared__ int s_wp[VX_PIECES];             // rank of the first voxel of each of the tile's row pieces
-  __shared__ int s_w[VXB / 64];
+    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, const void *__restrict__ masks, int mask_format,
+    const int *__restrict__ n_inst, int max_inst, int W, int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox,
+    VoxWalk Wk, VoxOut out, int key_axis, int pix_bits, int max_points, int max_voxels, int cap_q,
+    uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q, uint32_t *__restrict__ status) {
   const int v = blockIdx.y;
-  // A workgroup takes a 64-pixel-wide, VX_PIECES-row-high tile of the image, not a run of VX_PIECES row pieces of one
-  // row: the bins of a table line (8 consecutive phi bins) have their first pixels on two or three neighbouring
-  // rows, and with row strips those rows belonged to workgroups on different XCDs, each of which fetched (and
-  // partially rewrote) the line for itself -- 165 B fetched per voxel where the sectors touched add up to 60.
-  // The voxel's place in first-seen (raster) order does not depend on who handles it: prefix of its row piece +
-  // set bits before it in the piece.
-  const int tx = blockIdx.x % R.tiles_x, ty = blockIdx.x / R.tiles_x;
-  const int H = R.NJ / R.tiles_x;
-  // every thread takes a quarter (16 pixels) of a row piece
-  const int lrow = (int)(threadIdx.x >> 2), quarter = threadIdx.x & 3;
-  const int y = ty * VX_PIECES + lrow;
-  uint32_t m16 = 0u;
-  uint32_t ord = 0u;
-  if (y < H) {
-    const unsigned long long word = row_piece(R.bitmap + (size_t)v * R.BW, R.tiles_x, y, tx);
-    m16 = (uint32_t)(word >> (16 * quarter)) & 0xFFFFu;
-    ord = (uint32_t)__popcll(word & ((1ull << (16 * quarter)) - 1ull));
-    if (quarter == 0) s_wp[lrow] = word ? (int)R.wpre[(size_t)v * R.NJ + (size_t)y * R.tiles_x + tx] : 0;
-  }
-  int tot;
-  int off = block_excl_scan<VXB / 64>(__popc(m16), s_w, tot);
-  if (tot == 0) return;
-  while (m16) {
-    const int bpos = __ffs((int)m16) - 1;
-    m16 &= m16 - 1u;
-    s_vox[off++] = ((uint32_t)lrow << 12) | ((uint32_t)(quarter * 16 + bpos) << 6) | ord++;
-  }
-  __syncthreads();
-  const FastCal fc = fastcal[v];
-  VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
-                          key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
-  X.rc = recip_of(fc);
-  const KeyCol kcol = load_key_col(calib + v, key_axis);
-  for (int idx = threadIdx.x; idx < tot; idx += VXB) {
-    const uint32_t e = s_vox[idx];
-    const int k = s_wp[e >> 12] + (int)(e & 63u);
-    if (k >= cap_vox) continue;                    // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
-    const int fr = ty * VX_PIECES + (int)(e >> 12), fcol = tx * 64 + (int)((e >> 6) & 63u);
-    const uint32_t f = (uint32_t)(fr * W + fcol);
-    // the bin of the first pixel: tier 1 of the classification of P1, then tier 1.5
-    double key_f;
-    int it_, ip_;
-    const float d_f = X.dv[f];
-    uint32_t b = pixel_bin_fast(X.c, X.rc, fc, g, fg, tab, fr, fcol, d_f, kcol, false, key_f, it_, ip_);
-    if (b == AMBIG) {                              // (0.7 % of the voxels)
-      bool decided = false;
-      if (fg.mid_ok) b = pixel_bin_mid(X.c, X.rc, g, fg, tab, W, (int)f, d_f, decided);
-      if (!decided) {                              // -> k_bp_vox_amb
-        const int slot = atomicAdd(&park.n[v], 1);
-        park.f[(size_t)v * HW + slot] = f;
-        park.k[(size_t)v * HW + slot] = (uint32_t)k;
-        continue;
-      }
+  const int n_occ = Wk.n_occ[v];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (VXB / 64) + (threadIdx.x >> 6)));
+  if (wave >= n_occ) return;
+  const ViewCalib c = calib[v];
+  const Recip rc = make_recip(c);
+  const Table T = table_view(table, E_total);
+  const int64_t tb0 = (int64_t)v * E_view;
+  const float *dv = depth + (size_t)v * HW;
+  const uint32_t *bv = Wk.bitmap + (size_t)v * Wk.BW;
+  const int m_inst = masks ? min(max(n_inst[v], 0), max_inst) : 0;
+  const unsigned long long pix_mask = (1ull << pix_bits) - 1ull;
+  // consecutive list entries are neighbours along an image row (k_bp_scan): the four waves of a workgroup take four of
+  // them at the same time
+  for (int i = wave; i < n_occ; i += gridDim.x * (VXB / 64)) {                  // (uniform per wave)
+    const int sg = Wk.seg_list[(size_t)v * Wk.NSEG + i];
+    const int64_t b = ((int64_t)sg << SEG_SHIFT) + lane;                      // bin of the view
+    const bool in = b < E_view;
+    const int64_t e = tb0 + (in ? b : 0);
+    const uint32_t cw = in ? T.cnt[e] : 0u;
+    const uint32_t f = T.first[e];
+    const unsigned long long e_kmin = T.kmin[e], e_combo = T.combo[e];
+    const bool vox = cw != 0u && cw < OVF_FLAG;                                // (a flagged count belongs to a repair in flight: never here)
+    if (__ballot(vox) == 0ull) continue;
+    int k = 0;
+    uint32_t pix = 0u, m_bits = 0u;
+    float d_pix = 0.0f;
+    if (vox) {
+      const int fr = (int)f / W, fc = (int)f - fr * W;
+      const unsigned long long word = row_piece(bv, Wk.tiles_x, fr, fc >> 6);
+      const uint32_t pre = Wk.wpre[(size_t)v * Wk.NJ + (size_t)fr * Wk.tiles_x + (fc >> 6)];
+      pix = (uint32_t)(e_combo & pix_mask);
+      d_pix = dv[pix];
+      m_bits = masks ? mask_bits_at(masks, mask_format, v, max_inst, m_inst, HW, (int)pix) : 0u;
+      k = (int)pre + __popcll(word & ((1ull << (fc & 63)) - 1ull));
     }
-    if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
+    if (!vox || k >= cap_vox) continue;               // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
+    const int row = (int)pix / W, col = (int)pix - row * W;
+    double x, yy, z;
+    pixel_to_lidar(c, rc, col, row, d_pix, x, yy, z);
+    double key = (key_axis == 2) ? z : yy;
+    key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
+    // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
+    if (cw > (uint32_t)max_points || ordered_key(key) != e_kmin) {
+      const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
+      if (slot < cap_q) { q_bins[(size_t)v * cap_q + slot] = (uint32_t)b; q_rank[(size_t)v * cap_q + slot] = k; }
+      else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
+      continue;
+    }
+    if (k < max_voxels) {
+      const size_t at = (size_t)v * cap_vox + k;
+      out.vox_pix[at] = pix;
+      out.it_bits[at] = m_bits;
+      out.it_x[at] = x;
+      out.it_y[at] = yy;
+      out.it_z[at] = z;
+    }
+    // leave the table clean for the next pass (rep is only ever written by the repair)
+    T.kmin[e] = ~0ull;
+    T.combo[e] = ~0ull;
+    T.cnt[e] = 0u;
+    T.first[e] = NOBIN;
   }
-}
-
-// the voxels k_bp_vox parked: bin of the first pixel by the full fp64 classification
-__global__ __launch_bounds__(256) void k_bp_vox_amb(
-    const float *__restrict__ depth, const ViewCalib *__restrict__ calib, dfu3d_bin_geom g,
-    const void *__restrict__ masks, int mask_format, const int *__restrict__ n_inst, int max_inst, int W,
-    int HW, int64_t E_view, void *table, int64_t E_total, int cap_vox, VoxOut out, int key_axis,
-    int pix_bits, int cap_q, uint32_t *__restrict__ q_bins, int *__restrict__ q_rank, int *__restrict__ n_q,
-    uint32_t *__restrict__ status, VoxPark park) {
-  const int v = blockIdx.y;                       // ONE workgroup per view (gridDim.x == 1): it owns the view's counter
-  const int n = park.n[v];
-  if (n == 0) return;
-  const VoxCtx X = make_vox_ctx(calib, v, table, E_total, E_view, masks, mask_format, n_inst, max_inst, depth, HW, W,
-                                key_axis, pix_bits, cap_vox, cap_q, g.max_points_per_voxel, g.max_voxels);
-  bool rerr = false;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t f = park.f[(size_t)v * HW + i];
-    const int k = (int)park.k[(size_t)v * HW + i];
-    double key_f;
-    const uint32_t b = pixel_bin(X.c, X.rc, g, W, (int)f, X.dv[f], key_axis, key_f, rerr);
-    if (b == NOBIN) continue;                      // cannot happen: only binned pixels are ever marked
-    vox_finish(X, out, v, k, b, q_bins, q_rank, n_q, status);
-  }
-  if (rerr) atomicOr(status, DFU3D_ST_BIN_RANGE);
-  // the list is consumed: a VOX phase issued again without the BIN phase in front of it (which zeroes the counter too)
-  // must not finish these voxels a second time on entries that are reset already
-  __syncthreads();
-  if (threadIdx.x == 0) park.n[v] = 0;
 }
 
 // ---- O1: bin id per pixel, exact classification, only for views with a repair queue ----
@@ -1321,10 +1273,11 @@ extern "C" int dfu3d_bin_table_init(void *table, int64_t E, void *stream) {
 }
 
 // Scratch carve-up.
-// blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], n_park[V], bitmap[V*BW] -- everything up to here is
-//   zeroed at the start of a pass --, wpre[V*NJ], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
+// blk_cnt (int32 words): n_amb[V], n_q[V], q_cursor[V], n_occ[V], bitmap[V*BW], occ[V*OW] -- everything up to here is
+//   zeroed at the start of a pass --, wpre[V*NJ], seg_list[V*NSEG], q_cnt[V*cap_q], q_bins[V*cap_q], q_rank[V*cap_q], the float32
 //   calibration constants (80 B per view) and the edge tables of tier 1 (8 B x (TAB_T_MAX + TAB_P_MAX + 4) at most; the carve-up keeps round 2's 16 B)
-//   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, cap_q: queue_cap)
+//   (BW = 32 words per 64x16 tile, NJ = H * tiles_x, NSEG = 64-entry segments of a view's table, OW = NSEG / 4 words of
+//   occupancy bytes, cap_q: queue_cap)
 // pix_bin (uint32 words): [0, V*HW) bin id per pixel (written only for views under repair),
 //   [V*HW, 2*V*HW) undecided-pixel lists, later the pixel lists of the repair.
 static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
@@ -1333,16 +1286,20 @@ static inline int queue_cap(int64_t HW, int max_points, int cap_vox) {
   return (int)(q < cap_vox ? q : cap_vox);
 }
 
+// segments (64 entries) and occupancy words of a view's table; an upper bound when the geometry is not known yet
+static inline int64_t table_segments(int64_t E_view) { return (E_view + 63) >> SEG_SHIFT; }
+
 extern "C" int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
-                                                   int32_t cap_vox, int32_t max_points,
-                                                   int64_t *pix_words, int64_t *blk_words) {
-  if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1) return DFU3D_EINVAL;
+                                                    int32_t cap_vox, int32_t max_points, int64_t table_entries,
+                                                    int64_t *pix_words, int64_t *blk_words) {
+  if (V <= 0 || H <= 0 || W <= 0 || cap_vox <= 0 || max_points < 1 || table_entries <= 0) return DFU3D_EINVAL;
   const int64_t HW = (int64_t)H * W;
   const int64_t tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const int64_t BW = tiles_x * tiles_y * 32, NJ = (int64_t)H * tiles_x;
   const int64_t cap_q = queue_cap(HW, max_points, cap_vox);
   if (pix_words) *pix_words = 2 * V * HW;
-  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * NJ + 3 * V * cap_q + 20 * (int64_t)V + 16 +
+  const int64_t NSEG = table_segments(table_entries), OW = (NSEG + 3) / 4;
+  if (blk_words) *blk_words = 4 * (int64_t)V + V * BW + V * OW + V * NJ + V * NSEG + 3 * V * cap_q + 20 * (int64_t)V + 16 +
                               4 * (int64_t)(TAB_T_MAX + TAB_P_MAX) + 16;
   return 0;
 }
@@ -1374,12 +1331,16 @@ extern "C" int dfu3d_backproject_bin(
   const int64_t E_view = (int64_t)geom->t_n * geom->p_n;
   const int64_t E_total = E_view * V;
   hipStream_t st = (hipStream_t)stream;
+  const int NSEG = (int)table_segments(E_view), OW = (NSEG + 3) / 4;       // OW: words of the occupancy bytes
   int *n_amb = blk_cnt;
   int *n_q = n_amb + V;
   int *q_cursor = n_q + V;
-  uint32_t *bitmap = (uint32_t *)(q_cursor + 2 * (size_t)V);
-  uint32_t *wpre = bitmap + (size_t)V * BW;
-  int *q_cnt = (int *)(wpre + (size_t)V * NJ);
+  int *n_occ = q_cursor + V;
+  uint32_t *bitmap = (uint32_t *)(n_occ + V);
+  uint32_t *occ = bitmap + (size_t)V * BW;
+  uint32_t *wpre = occ + (size_t)V * OW;
+  int *seg_list = (int *)(wpre + (size_t)V * NJ);
+  int *q_cnt = seg_list + (size_t)V * NSEG;
   uint32_t *q_bins = (uint32_t *)(q_cnt + (size_t)V * cap_q);
   int *q_rank = (int *)(q_bins + (size_t)V * cap_q);
   FastCal *fastcal = (FastCal *)(((uintptr_t)(q_rank + (size_t)V * cap_q) + 15) & ~(uintptr_t)15);   // 80 B per view
@@ -1390,39 +1351,35 @@ extern "C" int dfu3d_backproject_bin(
   uint32_t *q_list = pix_bin + (size_t)V * HW;       // undecided pixels first, repair lists later
   const ViewCalib *cal = (const ViewCalib *)calib;
   const VoxOut out = {vox_pix, it_bits, it_x, it_y, it_z};
-  const RankMap R = {bitmap, wpre, BW, NJ, tiles_x, W};
-  // voxels parked by k_bp_vox: the counter is the fourth per-view word of the header, the lists sit where the bin ids
-  // and pixel lists of the repair go (written after P4, read before it only by k_bp_bin_amb: free in between)
-  const VoxPark park = {q_cursor + V, pix_bin, q_list};
+  const VoxWalk Wk = {seg_list, n_occ, bitmap, wpre, NSEG, BW, NJ, tiles_x};
 
   if (phases & DFU3D_BP_BIN) {
-    if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW), st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW + (size_t)V * OW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_tables, dim3((tables_threads(fg, *geom) + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_bin, dim3(tiles_x * ((tiles_y + RPT - 1) / RPT), V), dim3(PB), 0, st, depth, cal, fastcal, tab, *geom,
                        fg, W, H, tiles_x, tiles_y, key_axis, E_view, table, E_total, n_amb, q_list, pix_bits,
-                       bitmap, BW);
+                       bitmap, BW, (uint8_t *)occ, OW);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_AMB) {
     hipLaunchKernelGGL(k_bp_bin_amb, dim3(64, V), dim3(256), 0, st, depth, cal, *geom, W, HW,
-                       key_axis, E_view, table, E_total, n_amb, q_list, status, pix_bits, bitmap, BW, tiles_x);
+                       key_axis, E_view, table, E_total, n_amb, q_list, status, pix_bits, bitmap, BW, tiles_x, (uint8_t *)occ, OW);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_MARK) {
-    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, cap_vox, status);
+    hipLaunchKernelGGL(k_bp_scan, dim3(V), dim3(SCB), 0, st, BW, NJ, tiles_x, bitmap, wpre, n_vox, cap_vox, status, occ, OW,
+                       NSEG, seg_list, n_occ);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_VOX) {
-    hipLaunchKernelGGL(k_bp_vox, dim3(tiles_x * ((H + VX_PIECES - 1) / VX_PIECES), V), dim3(VXB), 0, st, depth, cal, fastcal, tab, *geom,
-                       fg, masks, mask_format, n_inst, max_inst, W, HW, E_view, table, E_total,
-                       cap_vox, R, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status, park);
-    DFU3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bp_vox_amb, dim3(1, V), dim3(256), 0, st, depth, cal, *geom, masks, mask_format, n_inst, max_inst,
-                       W, HW, E_view, table, E_total, cap_vox, out, key_axis, pix_bits, cap_q, q_bins, q_rank, n_q, status,
-                       park);
+    // a wave per occupied segment (more of them per wave only when a view occupies more than 2 048)
+    const int gx = std::min((NSEG + (VXB / 64) - 1) / (VXB / 64), VOX_GX);
+    hipLaunchKernelGGL(k_bp_vox, dim3(gx, V), dim3(VXB), 0, st, depth, cal, masks, mask_format, n_inst, max_inst, W, HW, E_view,
+                       table, E_total, cap_vox, Wk, out, key_axis, pix_bits, geom->max_points_per_voxel, geom->max_voxels,
+                       cap_q, q_bins, q_rank, n_q, status);
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_BP_REPAIR) {

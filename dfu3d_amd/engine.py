@@ -136,7 +136,7 @@ class PseudoBoxEngine:
                     self.p.vrange_min, self.p.vgrid, self.p.max_points_per_voxel, self.p.max_voxels)
                 L.table = torch.empty(V * L.E * st.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=d)
                 st.bin_table_init(L.table, V * L.E)
-                pw, bw = st.backproject_scratch_words(V, self.H, self.W, cv, self.p.max_points_per_voxel)
+                pw, bw = st.backproject_scratch_words(V, self.H, self.W, cv, self.p.max_points_per_voxel, L.geom)
                 L.pix_bin, L.blk_cnt = i32(pw), i32(bw)
             pc = self.pool_cap
             L.px, L.py, L.pz = f64(pc), f64(pc), f64(pc)

@@ -75,9 +75,10 @@ def make_geom(depth_min=0.001, z_max=1.0, theta_min=1.5,
     return g, int(n)
 
 
-def backproject_scratch_words(V, H, W, cap_vox, max_points):
+def backproject_scratch_words(V, H, W, cap_vox, max_points, geom):
+    """geom: the dfu3d_bin_geom of make_geom (its table decides the size of the segment lists)."""
     a, b = ctypes.c_int64(0), ctypes.c_int64(0)
-    rc = _lib.lib().dfu3d_backproject_scratch_words(V, H, W, cap_vox, max_points,
+    rc = _lib.lib().dfu3d_backproject_scratch_words(V, H, W, cap_vox, max_points, int(geom.t_n) * int(geom.p_n),
                                                     ctypes.byref(a), ctypes.byref(b))
     if rc != 0:
         raise Dfu3dError("dfu3d_backproject_scratch_words: invalid sizes")
@@ -199,7 +200,7 @@ def project_label(points, pt_off, view_frame, calib, plane, fov_idx, n_fov, mask
 def backproject_bin(depth, calib, masks, n_inst, V, max_inst, H, W, geom, table_entries,
                     key_axis, table, pix_bin, blk_cnt, cap_vox, n_vox, vox_pix, it_bits, it_x,
                     it_y, it_z, status, phases=BP_ALL, mask_format=MASK_BYTES):
-    pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel)
+    pw, bw = backproject_scratch_words(V, H, W, cap_vox, geom.max_points_per_voxel, geom)
     if table.data_ptr() % 8 or blk_cnt.data_ptr() % 8:
         raise Dfu3dError("table / blk_cnt: must be 8-byte aligned")
     if depth.data_ptr() % 16:

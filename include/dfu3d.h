@@ -176,7 +176,7 @@ int dfu3d_project_label(const float *points, const int32_t *pt_off,
  * per-pixel stream of the stage: nothing is written per pixel. */
 int dfu3d_bin_table_init(void *table, int64_t table_entries_total, void *stream);
 int64_t dfu3d_backproject_scratch_words(int32_t V, int32_t H, int32_t W,
-                                        int32_t cap_vox, int32_t max_points,
+                                        int32_t cap_vox, int32_t max_points, int64_t table_entries,
                                         int64_t *pix_words, int64_t *blk_words);
 int dfu3d_backproject_bin(const float *depth, const float *calib,
                           const void *masks, int32_t mask_format, const int32_t *n_inst,

@@ -616,7 +616,7 @@ def _bp_run(st, depth, cal, masks, max_points=100, max_voxels=1000000, key_axis=
     geom, E = st.make_geom(max_points_per_voxel=max_points, max_voxels=max_voxels)
     table = torch.empty(V * E * st.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=DEV)
     st.bin_table_init(table, V * E)
-    pw, bw = st.backproject_scratch_words(V, H, W, cap_vox, max_points)
+    pw, bw = st.backproject_scratch_words(V, H, W, cap_vox, max_points, geom)
     i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=DEV)
     f64 = lambda n: torch.zeros(n, dtype=torch.float64, device=DEV)
     n_vox, vox_pix, bits = i32(V), i32(V * cap_vox), i32(V * cap_vox)

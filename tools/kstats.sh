@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf /tmp/pk
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o ks -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $ROOT/gpurun_out/${R}_kstats_bench.json 2> $ROOT/gpurun_out/${R}_kstats_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o ks -- python3 $ROOT/bench.py --no-cpu-baseline --rf-big-frames 0 --steps 3 --warmup 1 "$@" > $ROOT/gpurun_out/${R}_kstats_bench.json 2> $ROOT/gpurun_out/${R}_kstats_bench.err
 STATS=$(ls /tmp/pk/*kernel_stats.csv /tmp/pk/*/*kernel_stats.csv 2>/dev/null | tail -1)
 python3 - "$STATS" "$ROOT/gpurun_out/${R}_kstats.csv" <<'PY'
 import csv, sys
