@@ -79,8 +79,8 @@ VARIANTS = {
     # packed min-(key|pixel) word with only 14 key bits: keys collide below the cut all the time, so the exact
     # repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never taken in the product build) does the work
     "keybits14": ["-DDFU3D_DBG_COMBO_KEYBITS=14"],
-    # no middle tier: what float32 leaves undecided goes to k_bp_bin_amb (pixels) and is parked for k_bp_vox_amb (first
-    # pixels of voxels) -- the paths the product build takes for a handful of pixels per launch
+    # no middle tier: what float32 leaves undecided goes to k_bp_bin_amb -- the path the product build takes for a handful
+    # of pixels per launch
     "no_mid": ["-DDFU3D_DBG_NO_MID"],
     # cycles between the DBG_T marks of a kernel, summed over its workgroups (tools/p1_timing.py)
     "timing": ["-DDFU3D_DBG_TIMING"],

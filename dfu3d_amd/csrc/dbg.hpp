@@ -5,7 +5,7 @@
 //                                collide all the time and the exact repair of k_bp_vox / k_ovf_* / k_bp_fix (practically never
 //                                taken in the product) does the work.  Same results as the product.
 //   DFU3D_DBG_NO_MID             test build: no middle tier of the bin classification -- everything float32 leaves undecided takes
-//                                the full fp64 kernels (k_bp_bin_amb, k_bp_vox_amb).  Same results as the product.
+//                                the full fp64 kernel (k_bp_bin_amb).  Same results as the product.
 //   DFU3D_DBG_TIMING             dev build: cycles of thread 0 between the DBG_T(k) marks of a kernel, summed over workgroups;
 //                                every source file that uses the marks has its own counters and exports a reader with
 //                                DBG_T_READER(name) (pixel_stage.hip: dfu3d_debug_timing_pixel; tools/p1_timing.py).

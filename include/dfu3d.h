@@ -193,13 +193,11 @@ int dfu3d_backproject_bin(const float *depth, const float *calib,
  * BIN starts a pass (it zeroes the per-view counters and the first-pixel bit map and
  * fills the table); AMB / MARK / VOX consume what BIN left and VOX resets every table
  * entry it finishes, so a phase repeated without BIN in front of it finds nothing to do
- * -- it must not be relied on to reproduce outputs.  Scratch aliasing: the lists of
- * voxels VOX parks for its fp64 kernel live in `pix_bin`, which AMB reads and REPAIR
- * rewrites; their per-view counter is zeroed by BIN and again by VOX once it has consumed them. */
+ * -- it must not be relied on to reproduce outputs. */
 #define DFU3D_BP_BIN 1     /* k_bp_bin: back-project, bin, table atomics, touched-bin list          */
 #define DFU3D_BP_AMB 2     /* k_bp_bin_amb: the pixels float32 could not classify, in fp64           */
-#define DFU3D_BP_MARK 4    /* k_bp_mark + k_bp_scan: first-pixel bit map and its popcount prefix     */
-#define DFU3D_BP_VOX 8     /* k_bp_vox: rank, representative, outputs, table reset                   */
+#define DFU3D_BP_MARK 4    /* k_bp_scan: popcount prefix of the first-pixel bit map, list of occupied table segments */
+#define DFU3D_BP_VOX 8     /* k_bp_vox: walk over the occupied table segments: rank, representative, outputs, reset */
 #define DFU3D_BP_REPAIR 16 /* exact repair of bins over the cap / key collisions (no-ops when none)  */
 #define DFU3D_BP_ALL 31
 

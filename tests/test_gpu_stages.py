@@ -678,9 +678,9 @@ def test_backproject_repair_path_with_colliding_keys(st, monkeypatch):
 
 def test_backproject_without_the_middle_tier_takes_the_full_fp64_paths(st, monkeypatch):
     """Test build of the library without the middle tier of the bin classification: every pixel the float32 tier
-    leaves undecided is classified by k_bp_bin_amb, and every voxel whose first pixel is undecided is parked by
-    k_bp_vox and finished by k_bp_vox_amb -- in the product build those two kernels see a few pixels per launch, here
-    they see 0.7 % of them.  Same answer as the oracle's, bit for bit, and the same as the product build's."""
+    leaves undecided is classified by k_bp_bin_amb (the reference's full fp64 expressions, scattered commits) -- in the
+    product build that kernel sees a few pixels per launch, here it sees 0.7 % of them.  Same answer as the oracle's,
+    bit for bit, and the same as the product build's."""
     from dfu3d_amd import _lib, synth
     s = synth.make_scene(35, H=180, W=320, M=4, cams=3, dense=True, k_min=10, k_max=14)
     depth = s.depth.numpy().copy()
