@@ -1386,7 +1386,9 @@ extern "C" int dfu3d_backproject_bin(
     // exact repair of the queued bins (more than max_points pixels, or a key collision below the cut of the
     // packed word); every kernel leaves at once for a view whose queue is empty
     const int nblk = (HW + PB - 1) / PB;
-    hipLaunchKernelGGL(k_bp_rebin, dim3(nblk < 64 ? nblk : 64, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
+    // (grids of a few workgroups per view: the queues are empty in all but pathological passes, and 75 000 workgroups that
+    // start only to find that out cost 25 us per pass; a view under repair walks its pixels with the grid's stride)
+    hipLaunchKernelGGL(k_bp_rebin, dim3(nblk < 16 ? nblk : 16, V), dim3(PB), 0, st, depth, cal, *geom, W, HW,
                        key_axis, n_q, pix_bin);
     DFU3D_LAUNCH_CHECK();
     const int ga = (cap_q + 255) / 256;
@@ -1394,7 +1396,7 @@ extern "C" int dfu3d_backproject_bin(
                        q_bins, n_q, q_cnt, q_cursor, HW, status);
     DFU3D_LAUNCH_CHECK();
     const int nblk4 = (HW + PBLK - 1) / PBLK;
-    hipLaunchKernelGGL(k_ovf_gather, dim3(nblk4 < 128 ? nblk4 : 128, V), dim3(PB), 0, st, pix_bin, table, E_total,
+    hipLaunchKernelGGL(k_ovf_gather, dim3(nblk4 < 16 ? nblk4 : 16, V), dim3(PB), 0, st, pix_bin, table, E_total,
                        E_view, HW, n_q, q_list);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ovf_select, dim3(cap_q < 32 ? cap_q : 32, V), dim3(256), 0, st, depth, cal, W, HW,

@@ -438,7 +438,7 @@ __device__ __forceinline__ void rf_queue_push(const RfScratch &W, long long key,
 
 
 template <bool NB1>
-__global__ __launch_bounds__(RFB, RF_OCC) void k_rf_stream(
+__global__ __launch_bounds__(RFB, NB1 ? RF_OCC : RF_OCC - 1) void k_rf_stream(
     const float4 *__restrict__ pq, const long long *__restrict__ n_used_ptr, long long n_max, int nb, int S, RfScratch W) {
   long long n_used = n_max;
   if (n_used_ptr) { const long long u = *n_used_ptr; n_used = u < n_max ? u : n_max; }
@@ -566,10 +566,14 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
     const int t_prev = min(n_prev, RF_WIN), t_next = min(n_next, RF_WIN);     // what of the neighbours is taken
     // all loads first: the range (two halves), its positions, the tail before, the head behind
     const bool v0 = lane < n_own, v1 = lane + 64 < n_own;
-    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 q0 = v0 ? W.uent[rg * RF_WLIST + lane] : none;
-    const uint32_t p0 = v0 ? W.upos[rg * RF_WLIST + lane] : 0u;
-    float4 q1 = none, eh = none;
+    // (every slot of the range's U list is readable memory: a lane beyond the count loads all the same and drops what it
+    // got -- a shared `none` value for the conditional loads went through scratch memory)
+    float4 q0 = W.uent[rg * RF_WLIST + lane];
+    uint32_t p0 = W.upos[rg * RF_WLIST + lane];
+    if (!v0) { q0.x = 0.f; q0.y = 0.f; q0.z = 0.f; q0.w = 0.f; p0 = 0u; }
+    float4 q1, eh;
+    q1.x = q1.y = q1.z = q1.w = 0.f;
+    eh.x = eh.y = eh.z = eh.w = 0.f;
     uint32_t p1 = 0u;
     if (n_own > 64) {                                // uniform
       if (v1) { q1 = W.uent[rg * RF_WLIST + 64 + lane]; p1 = W.upos[rg * RF_WLIST + 64 + lane]; }
@@ -598,14 +602,11 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
     }
     __builtin_amdgcn_wave_barrier();
     const int lo = RF_WIN - t_prev, hi = RF_WIN + n_own + t_next;      // the filled part of the LDS list
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      if (n_own <= h * 64) break;                    // uniform
-      const bool v = h ? v1 : v0;
-      const float4 q = h ? q1 : q0;
+    // one half (64 listed points) at a time; written as a function of the half's own registers (a loop over h that picks
+    // q0 / q1 with h put both into scratch memory: 32 bytes per lane)
+    auto half = [&](const bool v, const float4 q, const uint32_t p, const int ci) {
       const uint32_t wa = __float_as_uint(q.w);
       const float thr2 = rf_certain_hit2(q.x, q.y, q.z, __uint_as_float(wa << 16));
-      const int ci = RF_WIN + h * 64 + lane;         // the point's own place in the LDS list
       int cnt = 0;
 #pragma unroll 1
       for (int d0 = -RF_WIN; d0 <= RF_WIN; d0 += 4) {
@@ -621,11 +622,13 @@ __global__ __launch_bounds__(256) void k_rf_pair(const long long *__restrict__ n
         if (__ballot(v && cnt <= nb) == 0ull) break;
       }
       const bool pend = v && cnt <= nb;
-      const uint32_t gpos = (h ? p1 : p0) & ~RF_INCOH;
+      const uint32_t gpos = p & ~RF_INCOH;
       if (v) W.flags[gpos] = pend ? 0 : 1;
       const unsigned long long mp = __ballot(pend);
       if (mp) rf_queue_push(W, rg, mp, pend, gpos);
-    }
+    };
+    half(v0, q0, p0, RF_WIN + lane);                 // the point's own place in the LDS list
+    if (n_own > 64) half(v1, q1, p1, RF_WIN + 64 + lane);      // (uniform)
   }
 }
 
