@@ -915,32 +915,37 @@ __global__ __launch_bounds__(VXB) void k_bp_vox(
       m_bits = masks ? mask_bits_at(masks, mask_format, v, max_inst, m_inst, HW, (int)pix) : 0u;
       k = (int)pre + __popcll(word & ((1ull << (fc & 63)) - 1ull));
     }
-    if (!vox || k >= cap_vox) continue;               // DFU3D_ST_VOX_OVERFLOW (raised by the scan): the table stays dirty
-    const int row = (int)pix / W, col = (int)pix - row * W;
-    double x, yy, z;
-    pixel_to_lidar(c, rc, col, row, d_pix, x, yy, z);
-    double key = (key_axis == 2) ? z : yy;
-    key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
-    // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
-    if (cw > (uint32_t)max_points || ordered_key(key) != e_kmin) {
-      const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
-      if (slot < cap_q) { q_bins[(size_t)v * cap_q + slot] = (uint32_t)b; q_rank[(size_t)v * cap_q + slot] = k; }
-      else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
-      continue;
+    // an entry is left as it is when a repair in flight owns it, when its voxel is beyond cap_vox (DFU3D_ST_VOX_OVERFLOW,
+    // raised by the scan: the table stays dirty) and when it is queued for the repair below; every other entry of the
+    // segment -- the empty ones too: whole lines -- is written back clean
+    bool keep = !in || cw >= OVF_FLAG || (vox && k >= cap_vox);
+    if (vox && !keep) {
+      const int row = (int)pix / W, col = (int)pix - row * W;
+      double x, yy, z;
+      pixel_to_lidar(c, rc, col, row, d_pix, x, yy, z);
+      double key = (key_axis == 2) ? z : yy;
+      key += 0.0;                                   // -0.0 -> +0.0 (round to nearest), every other value unchanged
+      // over the cap ("the first max_points pixels" must be found), or two keys that agree in their top bits only
+      if (cw > (uint32_t)max_points || ordered_key(key) != e_kmin) {
+        const int slot = atomicAdd(&n_q[v], 1);        // exact repair (k_ovf_*, k_bp_fix); the entry stays as it is
+        if (slot < cap_q) { q_bins[(size_t)v * cap_q + slot] = (uint32_t)b; q_rank[(size_t)v * cap_q + slot] = k; }
+        else atomicOr(status, DFU3D_ST_VOX_PTS_OVERFLOW);
+        keep = true;
+      } else if (k < max_voxels) {
+        const size_t at = (size_t)v * cap_vox + k;
+        out.vox_pix[at] = pix;
+        out.it_bits[at] = m_bits;
+        out.it_x[at] = x;
+        out.it_y[at] = yy;
+        out.it_z[at] = z;
+      }
     }
-    if (k < max_voxels) {
-      const size_t at = (size_t)v * cap_vox + k;
-      out.vox_pix[at] = pix;
-      out.it_bits[at] = m_bits;
-      out.it_x[at] = x;
-      out.it_y[at] = yy;
-      out.it_z[at] = z;
+    if (!keep) {                                    // (rep is only ever written by the repair)
+      T.kmin[e] = ~0ull;
+      T.combo[e] = ~0ull;
+      T.cnt[e] = 0u;
+      T.first[e] = NOBIN;
     }
-    // leave the table clean for the next pass (rep is only ever written by the repair)
-    T.kmin[e] = ~0ull;
-    T.combo[e] = ~0ull;
-    T.cnt[e] = 0u;
-    T.first[e] = NOBIN;
   }
 }
 

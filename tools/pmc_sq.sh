@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf /tmp/psq
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/psq -o psq -- python3 $ROOT/bench.py --single-stream --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > /dev/null 2> $ROOT/gpurun_out/${R}_pmc_sq.err
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/psq -o psq -- python3 $ROOT/bench.py --single-stream --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --rf-big-frames 0 "$@" > /dev/null 2> $ROOT/gpurun_out/${R}_pmc_sq.err
 cd $ROOT
 python3 - /tmp/psq gpurun_out/${R}_pmc_sq.json <<'PY'
 import csv, glob, json, sys, collections
