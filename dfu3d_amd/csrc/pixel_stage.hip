@@ -243,7 +243,7 @@ inline FastGeom make_fast_geom(const dfu3d_bin_geom &g) {
   // most (1 + |q0|) / w + 1.  A geometry with bins so narrow that this eats the slop gets no tier 1 at all.
   const double slop_t = 1.8e-7 * ((1.0 + __builtin_fabs(f.tq0d)) / f.twd + 1.0), slop_p = 1.8e-7 * ((1.0 + __builtin_fabs(f.pq0d)) / f.pwd + 1.0);
   if (!(__builtin_fmax(slop_t, slop_p) <= TAB_SLOP_W)) f.dmax = 0.0f;
-  if (g.t_n >= (1 << 24) || g.p_n >= (1 << 24)) f.dmax = 0.0f;          // classify_fast forms the bin index with a 24-bit multiply
+  if (g.t_n >= (1 << 16) || g.p_n >= (1 << 16)) f.dmax = 0.0f;          // k_bp_bin packs the window coordinates into 16 + 16 bits (classify_fast forms the bin index with a 24-bit multiply)
   // tier 1.5: one fp64 edge per bin boundary of the window behind the float32 tables, if the scratch holds them
   f.mid_ok = (f.dmax > 0.0f) && ((int64_t)f.tJ + f.pJ + 4 + (int64_t)g.t_n + g.p_n + 2 <= 2 * (int64_t)(TAB_T_MAX + TAB_P_MAX));
   f.pad1 = 0;
@@ -532,7 +532,11 @@ __device__ __forceinline__ uint32_t pixel_bin_mid(const ViewCalib &c, const Reci
 constexpr int WIN_T = 16, WIN_P = 48;              // LDS bin window (theta x phi)
 
 constexpr int P1_AMB = 256;                        // undecided pixels a workgroup of k_bp_bin lists in LDS
-constexpr int P1_OCC = 5;                          // workgroups per compute unit the register budget is cut for (6 / 8 spilled: 3.98 / 6.11 ms against 3.23)
+constexpr int P1_OCC = 7;                          // workgroups per compute unit the register budget is cut for.  Round 3: 93 registers, five
+                                                   // (budgets for 6 / 8 spilled: 3.98 / 6.11 ms against 3.23).  Round 4: a kept pixel carries 16 bits
+                                                   // + 16 bits of window coordinates across the barrier and nothing else (its depth is read again, its
+                                                   // key formed behind the barrier): 67 registers, seven waves per SIMD -- 2.85 -> 2.61 ms (six: 2.75;
+                                                   // eight, with 12 B of scratch: 2.64)
 constexpr int RPT = 2;                             // rows per thread: a workgroup's tile is TILE_W x (RPT * TILE_H) pixels --
                                                    // the window set-up, its flush and the reductions are paid once per 2048 pixels
 __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
@@ -578,9 +582,11 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
   for (int i = threadIdx.x; i < WIN_T * WIN_P; i += PB) { s_kmin[i] = ~0ull; s_combo[i] = ~0ull; s_cnt[i] = 0u; s_first[i] = NOBIN; }
   __syncthreads();
   DBG_T(0);                                        // set-up: records, window reset, barrier
-  uint32_t bins[RPT][PPT];
-  double keys[RPT][PPT];
-  int its[RPT][PPT], ips[RPT][PPT];
+  // what a kept pixel carries across the origin's barrier: its window coordinates in ONE word (theta | phi << 16; NOBIN: not
+  // kept) and its depth -- the exact fp64 key is formed where it is used, behind the barrier.  (Until round 4: the bin
+  // index, the two coordinates and the key, 40 registers instead of 16, and the kernel sat at 93 of them, five waves
+  // per SIMD.)
+  uint32_t tp[RPT][PPT];
   bool inside[RPT];
   int tmin = 0x7FFFFFFF, pmin = 0x7FFFFFFF;
   uint32_t amb_mask = 0u;                         // bit r * PPT + k: pixel k of the thread's row r is undecided
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
     const int row = row0 + r * TILE_H;
     inside[r] = (row < H) && (col < W);
 #pragma unroll
-    for (int k = 0; k < PPT; k++) { bins[r][k] = NOBIN; keys[r][k] = 0.0; its[r][k] = 0; ips[r][k] = 0; }
+    for (int k = 0; k < PPT; k++) tp[r][k] = NOBIN;
     if (!inside[r]) continue;
     const float *dv = depth + (size_t)v * HW;
     float d[PPT];
@@ -598,17 +604,16 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
 #pragma unroll
     for (int k = 0; k < PPT; k++) cols[k] = col + k;
     uint32_t res[PPT];
-    classify_fast<PPT>(fc, g, fg, tab, row, cols, d, res, its[r], ips[r]);
+    int its[PPT], ips[PPT];
+    classify_fast<PPT>(fc, g, fg, tab, row, cols, d, res, its, ips);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       const uint32_t b = res[k];
       if (b == AMBIG) {
         amb_mask |= 1u << (r * PPT + k);
       } else if (b != NOBIN) {
-        bins[r][k] = b;
-        tmin = min(tmin, its[r][k]); pmin = min(pmin, ips[r][k]);
-        keys[r][k] = pixel_to_lidar_axis(c, rc, kcol, col + k, row, d[k]);
-        keys[r][k] += 0.0;                                    // -0.0 -> +0.0, every other value unchanged
+        tp[r][k] = (uint32_t)its[k] | ((uint32_t)ips[k] << 16);
+        tmin = min(tmin, its[k]); pmin = min(pmin, ips[k]);
       }
     }
   }
@@ -640,14 +645,18 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
   for (int r = 0; r < RPT; r++) {
     if (!inside[r]) continue;
     const uint32_t base = (uint32_t)((row0 + r * TILE_H) * W + col);
+    float dk[PPT];                                   // (the row's depths once more: a hit in the cache, eight registers less across the barrier)
+    load4(depth + (size_t)v * HW + (size_t)(row0 + r * TILE_H) * W, col, W, dk);
     const uint32_t loc0 = (uint32_t)(((threadIdx.x >> 4) + r * TILE_H) * TILE_W + (threadIdx.x & 15) * PPT);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
-      const uint32_t b = bins[r][k];
-      if (b == NOBIN) continue;
-      const unsigned long long ok = ordered_key(keys[r][k]);
+      if (tp[r][k] == NOBIN) continue;
+      const uint32_t it_k = tp[r][k] & 0xFFFFu, ip_k = tp[r][k] >> 16;
+      double key = pixel_to_lidar_axis(c, rc, kcol, col + k, row0 + r * TILE_H, dk[k]);
+      key += 0.0;                                                 // -0.0 -> +0.0, every other value unchanged
+      const unsigned long long ok = ordered_key(key);
       const unsigned long long cm = combo_word(ok, base + k, pix_bits);
-      const uint32_t lt = (uint32_t)(its[r][k] - t0), lp = (uint32_t)(ips[r][k] - p0);
+      const uint32_t lt = it_k - (uint32_t)t0, lp = ip_k - (uint32_t)p0;
       if ((lt < (uint32_t)WIN_T) & (lp < (uint32_t)WIN_P)) {      // aggregate in the LDS window
         const uint32_t w = __umul24(lt, (uint32_t)WIN_P) + lp;     // (24-bit multiplies issue at four times the rate of v_mul_lo_u32)
         atomicAdd(&s_cnt[w], 1u);
@@ -655,6 +664,7 @@ __global__ __launch_bounds__(PB, P1_OCC) void k_bp_bin(
         atomicMin(&s_kmin[w], ok);
         atomicMin(&s_combo[w], cm);
       } else {                                                    // outside the window: direct
+        const uint32_t b = __umul24(it_k, (uint32_t)g.p_n) + ip_k;
         const int64_t e = tb0 + b;
         atomicAdd(&T.cnt[e], 1u);
         const uint32_t oldf = atomicMin(&T.first[e], base + k);
