@@ -1,5 +1,7 @@
 """CPU-only tests of the host logic: calibration record, parameters, synthetic
 scene generator (no GPU compute)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,3 +110,17 @@ def test_reader_pool_fills_shared_staging(tmp_path):
         pool.close()
         shm.close()
         shm.unlink()
+
+
+def test_number_tables_of_the_prose_are_generated_from_the_committed_summaries():
+    """Every block between `BEGIN GENERATED` / `END GENERATED` markers in DESIGN.md and profiles/README_r04.md is what
+    tools/render_numbers.py writes from profiles/r04_* (kernel statistics, PMC counters, instruction mix, the bench line):
+    a number typed by hand into one of them, or a profile refreshed without re-rendering, fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "render_numbers.py"), "r04", "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    assert text.count("BEGIN GENERATED") == text.count("END GENERATED") >= 5

@@ -160,13 +160,13 @@ def apply(path, blocks, check):
     text = open(path).read()
     changed = False
     for name, body in blocks.items():
-        pat = re.compile(r"(<!-- BEGIN GENERATED %s \(tools/render_numbers\.py\) -->\n)(.*?)(\n<!-- END GENERATED %s -->)" % (name, name), re.S)
+        pat = re.compile(r"(<!-- BEGIN GENERATED %s \(tools/render_numbers\.py\) -->\n)(.*?)(<!-- END GENERATED %s -->)" % (name, name), re.S)
         m = pat.search(text)
         if not m:
             continue
-        if m.group(2) != body:
+        if m.group(2) != body + "\n":
             changed = True
-            text = text[:m.start(2)] + body + text[m.end(2):]
+            text = text[:m.start(2)] + body + "\n" + text[m.end(2):]
     if changed and not check:
         open(path, "w").write(text)
     return changed
