@@ -485,8 +485,12 @@ __device__ __forceinline__ void cell_unite(int *par, int a, int b) {
 }
 
 // -1: instance not eligible for this variant (NC_MIN < ncell <= NC handled here)
+// Launch bounds: the 48 KB variant is cut for 64 registers (eight waves per SIMD = TWO 1024-thread workgroups per compute
+// unit; 74 registers meant one): the kernel is a chain of short sweeps between barriers, a second workgroup fills the
+// waits -- 617 -> 501 us per 384 views (rocprofv3), with 44 B of scratch in the pairing loops.  (512-thread workgroups for the
+// instances up to 2048 / 4096 points, three per compute unit: no different, tools/ab_builds.py.)
 template <int NC, int NC_MIN, int TCT>
-__global__ __launch_bounds__(TCT) void k_range_cluster_grid(
+__global__ __launch_bounds__(TCT, (NC <= GRID_NC_SMALL ? 8 : 4)) void k_range_cluster_grid(
     const double *__restrict__ px, const double *__restrict__ py,
     const long long *__restrict__ seg_base, const int *__restrict__ seg_cnt, double R0,
     double Rd, int *__restrict__ label, double *__restrict__ sx, double *__restrict__ sy,
@@ -1395,7 +1399,8 @@ __global__ __launch_bounds__(256) void k_fit_tiny(
 }
 
 // ---- F2b: clusters of 65 .. LDS_MEMBERS points, one workgroup each ---------------
-__global__ __launch_bounds__(FT) void k_fit_medium(
+// (64 registers, no scratch: four workgroups per compute unit instead of three, 271 -> 256 us)
+__global__ __launch_bounds__(FT, 8) void k_fit_medium(
     const double *__restrict__ gsx, const double *__restrict__ gsy, int max_inst,
     const ViewCalib *__restrict__ calib, const int *__restrict__ inst_class,
     const int *__restrict__ inst_is_car, const float *__restrict__ inst_box,
