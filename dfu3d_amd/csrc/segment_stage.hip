@@ -188,13 +188,19 @@ __global__ __launch_bounds__(SEG_WPB * 64) void k_seg_write(
     const int *__restrict__ n_item, int cap_item, int max_inst, int NR,
     const long long *__restrict__ base, const int *__restrict__ cnt, const int *__restrict__ range_cnt,
     double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-    float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off) {
-  const int v = blockIdx.y;
+    float4 *__restrict__ pq, const double *__restrict__ rad, int seg_off, int V) {
+  // XCD-aware placement (as k_bp_vox): consecutive workgroups are dealt round the eight XCDs, and the ranges of ONE view
+  // continue each other's runs in the instance lists -- a run of ~32 points starts and ends inside a line of every
+  // plane.  With all workgroups of a view on one XCD the neighbouring runs meet in one L2 and leave as whole lines:
+  // 0.318 -> 0.280 ms for the stage (tools/ab_builds.py).
+  const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, turn = lin >> 3;
+  const int v = (int)((turn / gridDim.x) * 8u + (lin & 7u)), bx = (int)(turn % gridDim.x);
+  if (v >= V) return;                                  // (the grid's y is V rounded up to a multiple of 8)
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n = min(n_item[v], cap_item);
   const int nr = (n + SEG_WI - 1) / SEG_WI;
-  if (blockIdx.x * SEG_WPB + wave >= nr) return;
+  if (bx * SEG_WPB + wave >= nr) return;
   const bool lj = lane < max_inst;                     // lane j < max_inst: the facts of instance j
   const int cj = lj ? cnt[v * max_inst + lane] : 0;    // (0 also for the lists that did not fit the pool)
   const long long bj = lj ? base[v * max_inst + lane] : 0;
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(SEG_WPB * 64) void k_seg_write(
   const uint32_t live = (uint32_t)__ballot(cj > 0);   // instances of this view with a non-empty list
   if (live == 0u) return;
   const uint32_t sw = (lj && pq) ? shadow_word(seg_off + v * max_inst + lane, rj) : 0u;
-  for (int r = blockIdx.x * SEG_WPB + wave; r < nr; r += gridDim.x * SEG_WPB) {       // uniform per wave
+  for (int r = bx * SEG_WPB + wave; r < nr; r += gridDim.x * SEG_WPB) {       // uniform per wave
     const int w0 = r * SEG_WI;
     long long woff = bj + ((lane < DFU3D_MAX_INST) ? range_cnt[((size_t)v * NR + r) * DFU3D_MAX_INST + lane] : 0);
     uint32_t b[SEG_STEPS], wany[SEG_STEPS];
@@ -1566,11 +1572,11 @@ extern "C" int dfu3d_segments_build(
                      (long long *)base_a, (long long *)base_b, (long long)pool_cap,
                      (long long *)pool_cursor, status, J);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(gxa, V), dim3(SEG_WPB * 64), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
-                     max_inst, nra, (const long long *)base_a, cnt_a, rc_a, px, py, pz, (float4 *)shadow, rad_a, 0);
+  hipLaunchKernelGGL(k_seg_write, dim3(gxa, (V + 7) / 8 * 8), dim3(SEG_WPB * 64), 0, st, a_bits, a_x, a_y, a_z, a_n, a_cap,
+                     max_inst, nra, (const long long *)base_a, cnt_a, rc_a, px, py, pz, (float4 *)shadow, rad_a, 0, V);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_write, dim3(gxb, V), dim3(SEG_WPB * 64), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
-                     max_inst, nrb, (const long long *)base_b, cnt_b, rc_b, px, py, pz, (float4 *)shadow, rad_b, S);
+  hipLaunchKernelGGL(k_seg_write, dim3(gxb, (V + 7) / 8 * 8), dim3(SEG_WPB * 64), 0, st, b_bits, b_x, b_y, b_z, b_n, b_cap,
+                     max_inst, nrb, (const long long *)base_b, cnt_b, rc_b, px, py, pz, (float4 *)shadow, rad_b, S, V);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
 }
