@@ -9,7 +9,12 @@
 
 namespace {
 
-constexpr int NT = 1024;
+// Threads per workgroup of the one-workgroup-per-view kernels (k_fov_filter, k_plane_ransac, k_project_rows).  A step of 64
+// frames is 384 views on 256 compute units: with 1024 threads -- and k_plane_ransac's 128 registers -- a compute unit held ONE
+// workgroup and the kernels ran as two rounds; with 512 two fit and all views are in flight at once.  Measured in one
+// process (tools/ab_builds.py), 1024 / 512 / 256 threads: k_plane_ransac 0.199 / 0.148 / 0.185 ms, k_fov_filter 0.118 /
+// 0.103 / 0.141, k_project_rows + k_label_rows 0.048 / 0.041 / 0.046.
+constexpr int NT = 512;
 constexpr int NW = NT / 64;
 
 // ---------------------------------------------------------------- a4 FOV
