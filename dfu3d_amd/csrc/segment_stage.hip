@@ -1236,6 +1236,10 @@ __global__ __launch_bounds__(BT) void k_ball_flags(
 // (dst_after_base[s] + dst_after_cnt[s]); base_out[s] is updated then.
 constexpr int CPT = 1024;   // threads per compaction workgroup
 constexpr int CPE = 2;      // consecutive elements per thread (4 needed 76 VGPRs: one 1024-thread workgroup per CU)
+// (measured with tools/ab_builds.py, stage ballquery_fuse 0.78 ms: a second launch with 4 / 8 elements per thread for the lists
+// above 16 384 positions -- fewer steps for the longest list -- 0.85 / 0.95: a lane's consecutive elements are 32 / 64 bytes apart per
+// plane, the loads stop coalescing; coordinates requested together with the flag instead of behind it -- one round trip per
+// step instead of two -- 0.86: two thirds of a pseudo list are dropped by the fuse, their coordinates were read for nothing)
 // In-order compaction of segment s by flags.  dst = src (in place) or, when dst_after_base != nullptr, directly behind
 // another segment (dst_after_base[s] + dst_after_cnt[s]); seg_base[s] is updated then.
 // compact_front: that other segment carries flags as well (a joint filter pass without compaction).  The two lists are
