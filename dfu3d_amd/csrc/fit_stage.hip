@@ -484,6 +484,7 @@ __device__ __forceinline__ void cell_unite(int *par, int a, int b) {
   }
 }
 
+constexpr int CL_CLASSES = 3, CL_TOP = 8192;   // size classes of the launch order (see the kernel)
 // -1: instance not eligible for this variant (NC_MIN < ncell <= NC handled here)
 // Launch bounds: the 48 KB variant is cut for 64 registers (eight waves per SIMD = TWO 1024-thread workgroups per compute
 // unit; 74 registers meant one): the kernel is a chain of short sweeps between barriers, a second workgroup fills the
@@ -500,9 +501,24 @@ __global__ __launch_bounds__(TCT, (NC <= GRID_NC_SMALL ? 8 : 4)) void k_range_cl
   __shared__ int s_min[NC];          // smallest original index per root cell
   __shared__ double s_red[5 * (TCT / 64)];
   __shared__ int s_w[TCT / 64];
-  const int s = blockIdx.x;
+  // Longest first: the grid is CL_CLASSES times the segments, and workgroup b takes segment b % S only if its size falls into
+  // class b / S (above CL_TOP | above CL_TOP / 2 | the rest).  Workgroups start in the order of their index, so every long
+  // instance is under way before the first short one starts -- an instance of 50 000 points runs for half of what this kernel
+  // used to take, and in index order it could be among the last to start.  0.524 -> 0.448 ms (tools/ab_builds.py; classes above
+  // 12 288 / 4 096: 0.450, above 24 576 / 8 192: 0.475; four / five / six classes from 16 384 / 16 384 / 32 768 down: 0.457 /
+  // 0.461 / 0.478 -- every class costs a grid of workgroups that start only to leave).
+  constexpr int NCLS = CL_CLASSES;
+  const int S_ = (int)(gridDim.x / (unsigned)NCLS);
+  const int cls = (int)(blockIdx.x / (unsigned)S_);
+  const int s = (int)(blockIdx.x - (unsigned)cls * (unsigned)S_);
   const int n = seg_cnt[s];
   if (n <= n_lo || n > n_hi) return;                   // (n_lo >= 0) another launch of this kernel owns the instance
+  {                                                    // class 0: above TOP, class k: above TOP >> k, the last: the rest
+    int mine = NCLS - 1;
+#pragma unroll
+    for (int k = NCLS - 2; k >= 0; k--) if (n > (CL_TOP >> k)) mine = k;
+    if (mine != cls) return;
+  }
   const long long base = seg_base[s];
   const double *X = px + base, *Y = py + base;
   double *SX = sx + base, *SY = sy + base;
@@ -979,9 +995,14 @@ __global__ __launch_bounds__(FT) void k_fit_gather(
   __shared__ double s_red[FW];
   __shared__ int s_w[FW];
   __shared__ int s_q0, s_total;
-  const int s = blockIdx.x;
+  // (longest first, as k_range_cluster_grid: the grid is three times the segments, classes above 16 384 / above 8 192 / the rest;
+  // the stage 1.166 -> 1.117 ms, with 8 192 / 32 768 at the top 1.132 / 1.126)
+  const int S_ = (int)(gridDim.x / 3u);
+  const int cls = (int)(blockIdx.x / (unsigned)S_);
+  const int s = (int)(blockIdx.x - (unsigned)cls * (unsigned)S_);
   const int n = seg_cnt[s];
   if (n == 0) return;
+  if (cls != (n > 16384 ? 0 : (n > 8192 ? 1 : 2))) return;
   const long long base = seg_base[s];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const FitWs W = fit_ws_view(fit_ws, cap_rows, cap_big);
@@ -1672,11 +1693,11 @@ extern "C" int dfu3d_range_cluster(const double *px, const double *py, const int
   if (S <= 0 || pool_cap <= 0 || !(R0 > 0.0) || !(Rd >= 0.0)) return DFU3D_EINVAL;
   // fast path: union-find over spatial cells (two LDS footprints by bounding-box area)
   // (an instance is walked by ONE workgroup, and the longest instance is the tail of the stage: 1024 threads)
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(S), dim3(1024), 0,
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_SMALL, 0, 1024>), dim3(CL_CLASSES * S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL, 1024>), dim3(S), dim3(1024), 0,
+  hipLaunchKernelGGL((k_range_cluster_grid<GRID_NC_LARGE, GRID_NC_SMALL, 1024>), dim3(CL_CLASSES * S), dim3(1024), 0,
                      (hipStream_t)stream, px, py, (const long long *)seg_base, seg_cnt, R0, Rd,
                      label, sx, sy, si, (long long)pool_cap, 0, 0x7FFFFFFF);
   DFU3D_LAUNCH_CHECK();
@@ -1722,7 +1743,7 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
   const ViewCalib *vc = (const ViewCalib *)calib;
   if (hipMemsetAsync(fit_ws, 0, 16, st) != hipSuccess) return DFU3D_ELAUNCH;
   // F1: members of every cluster contiguous, one descriptor per cluster
-  hipLaunchKernelGGL(k_fit_gather, dim3(S), dim3(FT), 0, st, px, py, pz, label,
+  hipLaunchKernelGGL(k_fit_gather, dim3(3 * S), dim3(FT), 0, st, px, py, pz, label,
                      (const long long *)seg_base, seg_cnt, sx, sy, sroot, status, fit_ws,
                      cap_rows, cap_big);
   DFU3D_LAUNCH_CHECK();
