@@ -204,9 +204,9 @@ extern "C" int dfu3d_pseudo_boxes(
   carve(cfg, (char *)workspace, &w);
   hipStream_t st = (hipStream_t)stream;
   const int V = cfg->V, M = cfg->max_inst, S = V * M, cap_n = cfg->cap_n;
-  if (hipMemsetAsync(n_rows, 0, sizeof(int32_t), st) != hipSuccess) return DFU3D_ELAUNCH;
-  if (hipMemsetAsync(status, 0, sizeof(uint32_t), st) != hipSuccess) return DFU3D_ELAUNCH;
-  if (hipMemsetAsync(w.pool_cursor, 0, sizeof(int64_t), st) != hipSuccess) return DFU3D_ELAUNCH;
+  // (one small kernel, not three memsets: common.hpp, k_fill_words)
+  if (dfu3d_fill_small_async(n_rows, sizeof(int32_t), status, sizeof(uint32_t), w.pool_cursor, sizeof(int64_t), st) != hipSuccess)
+    return DFU3D_ELAUNCH;
   // a4
   if (cfg->apply_fov) {
     CHAIN_TRY(dfu3d_fov_filter(points, pt_off, view_frame, calib, V, cfg->fov_h, cfg->fov_w, cap_n,
@@ -235,7 +235,7 @@ extern "C" int dfu3d_pseudo_boxes(
                                     w.pix_bin, w.blk_cnt, cfg->cap_vox, w.n_vox, w.vox_pix, w.b_bits, w.b_x,
                                     w.b_y, w.b_z, status, DFU3D_BP_ALL, stream));
   } else {
-    if (hipMemsetAsync(w.n_vox, 0, sizeof(int32_t) * V, st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (dfu3d_fill_async(w.n_vox, 0, sizeof(int32_t) * V, st) != hipSuccess) return DFU3D_ELAUNCH;
   }
   const bool joint = !cfg->stat_filter;   // one radius-filter pass over the LiDAR and pseudo lists together
   CHAIN_TRY(dfu3d_segments_build(w.a_bits, w.a_x, w.a_y, w.a_z, w.K, cap_n, w.b_bits, w.b_x, w.b_y, w.b_z,

@@ -1741,7 +1741,7 @@ extern "C" int dfu3d_lshape_fit(const double *px, const double *py, const double
   hipStream_t st = (hipStream_t)stream;
   const int cap_big = (int)(pool_cap / LDS_MEMBERS + 1);
   const ViewCalib *vc = (const ViewCalib *)calib;
-  if (hipMemsetAsync(fit_ws, 0, 16, st) != hipSuccess) return DFU3D_ELAUNCH;
+  if (dfu3d_fill_small_async(fit_ws, 16, nullptr, 0, nullptr, 0, st) != hipSuccess) return DFU3D_ELAUNCH;
   // F1: members of every cluster contiguous, one descriptor per cluster
   hipLaunchKernelGGL(k_fit_gather, dim3(3 * S), dim3(FT), 0, st, px, py, pz, label,
                      (const long long *)seg_base, seg_cnt, sx, sy, sroot, status, fit_ws,

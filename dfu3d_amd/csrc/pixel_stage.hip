@@ -1382,7 +1382,7 @@ extern "C" int dfu3d_backproject_bin(
   const VoxWalk Wk = {seg_list, n_occ, bitmap, wpre, NSEG, BW, NJ, tiles_x};
 
   if (phases & DFU3D_BP_BIN) {
-    if (hipMemsetAsync(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW + (size_t)V * OW), st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (dfu3d_fill_async(blk_cnt, 0, sizeof(int) * (4 * (size_t)V + (size_t)V * BW + (size_t)V * OW), st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_bp_prep, dim3((V + 63) / 64), dim3(64), 0, st, cal, V, H, W, fastcal);
     DFU3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bp_tables, dim3((tables_threads(fg, *geom) + 255) / 256), dim3(256), 0, st, *geom, fg, (float2 *)tab);

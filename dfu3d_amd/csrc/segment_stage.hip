@@ -1624,7 +1624,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
   W.seg_base = (const long long *)seg_base;
   if (phases & DFU3D_RF_SHADOW) {
     // positions outside the given segments carry the "no segment" mark (all bits set)
-    if (hipMemsetAsync(pq, 0xFF, sizeof(float4) * (size_t)pool_cap, st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (dfu3d_fill_async(pq, 0xFF, sizeof(float4) * (size_t)pool_cap, st) != hipSuccess) return DFU3D_ELAUNCH;
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, S, seg_cnt, tile_off, QT);
     DFU3D_LAUNCH_CHECK();
     const int g = tile_grid(pool_cap, S);
@@ -1633,8 +1633,8 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_FLAGS) {
-    if (hipMemsetAsync(queue, 0, RF_QHDR * sizeof(int), st) != hipSuccess) return DFU3D_ELAUNCH;
-    if (hipMemsetAsync(W.work, 0, sizeof(int) * (size_t)(RF_WORK_HDR + S), st) != hipSuccess) return DFU3D_ELAUNCH;
+    if (dfu3d_fill_small_async(queue, RF_QHDR * sizeof(int), W.work, sizeof(int) * (size_t)(RF_WORK_HDR + S), nullptr, 0, st) != hipSuccess)
+      return DFU3D_ELAUNCH;
     const long long n_tiles = (pool_cap + RF_WG - 1) / RF_WG;
     const dim3 grid((unsigned)(n_tiles < RF_GRID ? n_tiles : RF_GRID));
     if (nb_points == 1)
