@@ -1253,12 +1253,11 @@ __global__ __launch_bounds__(CPT) void k_seg_compact(
     const uint8_t *__restrict__ flags, const long long *__restrict__ dst_after_base,
     int *__restrict__ dst_after_cnt, int compact_front) {
   __shared__ int s_w[CPT / 64];
-  // (longest first, as k_range_cluster_grid in fit_stage.hip: the grid is three times the segments, classes above 16 384 / above
-  // 8 192 positions / the rest -- the longest list is this kernel's duration and must not be among the last to start; the
-  // fuse stage 0.770 -> 0.751 ms)
-  const int S_ = (int)(gridDim.x / 3u);
-  const int cls = (int)(blockIdx.x / (unsigned)S_);
-  const int s = (int)(blockIdx.x - (unsigned)cls * (unsigned)S_);
+  // (NOT longest first as k_range_cluster_grid / k_fit_gather: a grid of size classes decides the class from seg_cnt, and this kernel
+  // REWRITES seg_cnt -- a list that shrank across a class boundary was compacted a second time by the workgroup of its new
+  // class whenever that one started late enough, i.e. in launches of thousands of segments only: 2 % more rows in bench.py's
+  // parity block, nothing in the tests of the time.  tests/test_gpu_engine.py now compares one large launch with many small ones.)
+  const int s = blockIdx.x;
   const int n = seg_cnt[s];
   const long long src = seg_base[s];
   const int front_all = dst_after_base ? dst_after_cnt[s] : 0;
@@ -1266,7 +1265,6 @@ __global__ __launch_bounds__(CPT) void k_seg_compact(
   const long long src_f = dst_after_base ? dst_after_base[s] : 0;
   const long long dst = dst_after_base ? src_f + (front_all - front) : src;
   const int n_all = front + n;
-  if (cls != (n_all > 16384 ? 0 : (n_all > 8192 ? 1 : 2))) return;
   if (n_all == 0) {
     if (dst_after_base && threadIdx.x == 0) seg_base[s] = dst;
     return;
@@ -1658,7 +1656,7 @@ extern "C" int dfu3d_radius_filter(double *px, double *py, double *pz, const int
     DFU3D_LAUNCH_CHECK();
   }
   if (phases & DFU3D_RF_COMPACT) {
-    hipLaunchKernelGGL(k_seg_compact, dim3(3 * S), dim3(CPT), 0, st, px, py, pz,
+    hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
                        (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
                        (int *)nullptr, 0);
     DFU3D_LAUNCH_CHECK();
@@ -1708,7 +1706,7 @@ extern "C" int dfu3d_stat_filter(double *px, double *py, double *pz, const int64
   hipLaunchKernelGGL(k_stat_flags, dim3(S), dim3(256), 0, st, (const long long *)seg_base,
                      seg_cnt, enable, std_ratio, mean_d, flags);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_compact, dim3(3 * S), dim3(CPT), 0, st, px, py, pz,
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz,
                      (long long *)seg_base, seg_cnt, flags, (const long long *)nullptr,
                      (int *)nullptr, 0);
   DFU3D_LAUNCH_CHECK();
@@ -1748,7 +1746,7 @@ static int ballquery_fuse_impl(double *px, double *py, double *pz, const int64_t
                      (const long long *)base_a, cnt_a, (const long long *)base_b, cnt_b, T, C, S,
                      tile_big, flags, masked);
   DFU3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_seg_compact, dim3(3 * S), dim3(CPT), 0, st, px, py, pz, (long long *)base_b,
+  hipLaunchKernelGGL(k_seg_compact, dim3(S), dim3(CPT), 0, st, px, py, pz, (long long *)base_b,
                      cnt_b, flags, (const long long *)base_a, cnt_a, masked == 2 ? 1 : 0);
   DFU3D_LAUNCH_CHECK();
   return DFU3D_OK;
