@@ -57,6 +57,7 @@ def main():
             fn.restype, fn.argtypes = res, a
         loaded[name] = L
     ref_rows = None
+    differ = set()
     acc = {n: {} for n, _ in libs}
     for rnd in range(args.rounds):
         for name, _ in libs:
@@ -69,6 +70,8 @@ def main():
             if ref_rows is None:
                 ref_rows = rows.clone()
             same = rows.shape == ref_rows.shape and bool(torch.equal(rows, ref_rows))
+            if not same:
+                differ.add(name)
             eng.reset_timing()
             eng.timing = True
             for _ in range(args.passes):
@@ -90,6 +93,10 @@ def main():
     for name, _ in libs:
         m = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in acc[name].items()}
         print("  %-12s pass %.3f  %s" % (name, m["pass"], " ".join("%s %.4f" % (k, m[k]) for k in keys if k != "pass")[:400]))
+    if differ:                                        # (say it LAST: a tuning build with other rows is a bug, whatever its speed)
+        print("ROWS DIFFER from the first build's in: " + ", ".join(sorted(differ)))
+        sys.exit(1)
+    print("rows of every build equal")
 
 
 if __name__ == "__main__":
