@@ -648,6 +648,10 @@ def main():
                 out["parity"] = parity_block(rows, exp_rows, nf, my_frames)
             except Exception as e:                                   # never lose the timing line
                 out["parity"] = {"error": repr(e)}
+            if not (out["parity"].get("rows_equal") and out["parity"].get("within_north_star_tolerance", False)):
+                # a fast step with other rows than the reference's is not a result: say so where nobody can miss it
+                log("[bench] PARITY FAILED: %s" % json.dumps(out["parity"]))
+                out["parity_failed"] = True
             if cpu_pool is not None:
                 try:
                     fps_all, t_all = cpu_all_cores_run(cpu_pool, cpu_scenes[0], params, dense)
