@@ -412,7 +412,9 @@ class PseudoBoxEngine:
                             status[c:c + 1])
         for L in self.lanes[1:]:
             main.wait_stream(L.stream)
-        self._last = (rows, n_rows, status)
+        done = torch.cuda.Event()
+        done.record(main)                           # the pass is complete here, whatever is enqueued behind it
+        self._last = (rows, n_rows, status, done)
         if not sync:
             return None, None
         return self.collect()
@@ -454,7 +456,7 @@ class PseudoBoxEngine:
                 g.replay()
         for L in self.lanes:
             main.wait_stream(L.stream)
-        self._last = (rows, n_rows, status)
+        self._last = (rows, n_rows, status, None)
         if not sync:
             return None, None
         return self.collect()
@@ -507,7 +509,18 @@ class PseudoBoxEngine:
         return self._last
 
     def collect(self, handle=None):
-        rows, n_rows, status = handle if handle is not None else self._last
+        """Rows of the pass behind `handle` (default: the last one).  May be called under another stream than the one the
+        pass was launched on (`with torch.cuda.stream(side): eng.collect(h)`): the reads then wait for THAT pass only, not
+        for whatever was enqueued behind it -- a caller that launches pass i+1 before it collects pass i gets the rows of
+        pass i while pass i+1 runs, and can enqueue pass i+2 long before the GPU runs dry (bench.py).  The returned
+        tensors belong to the calling stream."""
+        h = handle if handle is not None else self._last
+        rows, n_rows, status = h[:3]
+        if len(h) > 3 and h[3] is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(h[3])
+            for t in (rows, n_rows, status):
+                t.record_stream(cur)
         both = torch.stack((n_rows, status)).cpu().numpy()        # the one host sync
         counts = both[0]
         stw = int(np.bitwise_or.reduce(both[1].astype(np.int64)))
