@@ -938,7 +938,7 @@ __device__ void emit_box(double thb, double sin_s, double cos_s, double c1min, d
 
 // ---- workspace layout (doubles) ----------------------------------------------
 //   [0]            int q_count | int big_count
-//   [1]            int ticket counter of k_fit_big_cost (64 per item) | spare
+//   [1]            int ticket counter of k_fit_big_cost (64 per item) | int ticket counter of k_fit_medium (64 per descriptor)
 //   [2 ...)        cluster descriptors, 8 doubles each (cap_q of them):
 //                  0 segment s, 1 cluster ordinal kc, 2 root (smallest point index), 3 members m,
 //                  4 position of the members in gsx/gsy, 5 max z of the instance, 6 ordinal among
@@ -1439,7 +1439,19 @@ __global__ __launch_bounds__(FT, 8) void k_fit_medium(
     s_ct[threadIdx.x] = cos(theta);
     s_st[threadIdx.x] = sin(theta);
   }
-  for (int e = blockIdx.x; e < nq; e += gridDim.x) {
+  __shared__ int s_item;
+  while (true) {
+    // descriptors are handed out through a counter (the spare word of the workspace header, zeroed with it): a cluster of
+    // 2 000 members costs thirty times one of 65, and a fixed share of the queue per workgroup ended with a few workgroups
+    // busy (the fit stage 1.120 -> 1.090 ms)
+    __syncthreads();                             // the previous item is done with s_item and the members in LDS
+    if (wave == 0) {
+      const int ticket = atomicAdd(&W.counters[3], 1);        // every lane adds 1: the counter runs in units of 64 (see k_fit_big_cost)
+      if (lane == 0) s_item = ticket >> 6;
+    }
+    __syncthreads();
+    const int e = s_item;
+    if (e >= nq) break;
     const double *d = W.dsc + (size_t)8 * e;
     const int m = (int)d[3];
     if (m <= 64 || m > LDS_MEMBERS) continue;
