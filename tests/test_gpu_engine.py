@@ -247,7 +247,16 @@ def test_one_large_launch_equals_many_small_ones_and_itself():
     r1, s1 = big.run(b)
     r2, s2 = big.run(b)
     hs = [big.launch(b) for _ in range(3)]                # back to back, no host wait in between (the timed region's form)
-    piped = [big.collect(h) for h in hs]
+    side = torch.cuda.Stream()
+    piped = []
+    for k, h in enumerate(hs):                            # the middle one under a stream of its own (waits for ITS pass only)
+        if k == 1:
+            with torch.cuda.stream(side):
+                out = big.collect(h)
+            side.synchronize()
+            piped.append(out)
+        else:
+            piped.append(big.collect(h))
     del big
     torch.cuda.empty_cache()
     small = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=cams, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17,
