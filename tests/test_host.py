@@ -124,3 +124,35 @@ def test_number_tables_of_the_prose_are_generated_from_the_committed_summaries()
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(root, "DESIGN.md")).read()
     assert text.count("BEGIN GENERATED") == text.count("END GENERATED") >= 5
+
+
+def test_bench_parity_block_sees_extra_missing_and_moved_rows():
+    """bench.py's `parity` block is the last line of defence of the timed configuration (in round 4 it was the only check that
+    saw a race of large launches): equal rows -> rows_equal and within tolerance; one row more, one row less, another class
+    or a box that moved by a centimetre -> not."""
+    import numpy as np
+    import torch
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    import sys
+    sys.path.insert(0, sys_path)
+    import bench
+    rng = np.random.default_rng(3)
+    exp, rows = [], []
+    for f in range(2):
+        for c in range(3):
+            for j in range(2):
+                v = rng.normal(0, 5, 12)
+                exp.append((f, c, j, 0, 4, v))
+                rows.append([100 + f, c, 4, j, 0] + list(v) + [0.5])          # gathered layout: global frame id first
+    frame_ids = [100, 101]
+    R = torch.tensor(np.array(rows, np.float64))
+    ok = bench.parity_block(R, exp, 2, frame_ids)
+    assert ok["rows_equal"] and ok["within_north_star_tolerance"] and ok["rows_gpu"] == 12
+    extra = torch.cat((R, R[:1].clone() + torch.tensor([0, 0, 0, 0, 1] + [0.0] * 13, dtype=torch.float64)))   # one cluster more
+    assert not bench.parity_block(extra, exp, 2, frame_ids)["rows_equal"]
+    assert not bench.parity_block(R[1:], exp, 2, frame_ids)["rows_equal"]
+    other = R.clone(); other[3, 2] = 7                                           # another class
+    assert not bench.parity_block(other, exp, 2, frame_ids)["rows_equal"]
+    moved = R.clone(); moved[5, 5 + 8] += 0.01                                   # x of a box by a centimetre
+    b = bench.parity_block(moved, exp, 2, frame_ids)
+    assert b["rows_equal"] and not b["within_north_star_tolerance"]
