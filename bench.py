@@ -449,7 +449,7 @@ def main():
     def make_engine(lanes, vpc):
         return PseudoBoxEngine(params, H, W, MAX_INST, N_PTS, views_per_chunk=vpc, dense=dense, cap_vox=1 << 18,
                                pool_per_view=1 << 17, device=dev, lanes=lanes, graphs=args.graphs,
-                               chain=not args.no_chain)
+                               chain=not args.no_chain, free_lanes=True)
 
     eng = make_engine(args.lanes, views)
     gather_cap = eng.cap_rows * (frames * CAMS // views)      # rows a rank can emit per step: ONE fixed-size all-gather per step
@@ -458,6 +458,9 @@ def main():
     # stream those small kernels and the host read would queue up behind pass i+1, the host would get the rows of pass i when
     # pass i+1 is over, and the GPU would run dry while the host sorts them and enqueues pass i+2.  Measured on one box, three runs
     # each (profiles/r04_collect_stream_sweep.log): 8 640-8 970 -> 9 480-9 660 frames/s.
+    # The engine's lanes are FREE (no join between the lanes at the end of a pass: a lane's next chunk waits for that lane's previous
+    # chunk only): 9 670-9 810 -> 9 830-9 960 frames/s on one box (profiles/r04_free_lanes_sweep.log); starting the second lane
+    # half a chunk late on top of that: 9 890-10 020, inside the spread, not taken.
     side = torch.cuda.Stream(device=dev)
 
     def finish(handle):

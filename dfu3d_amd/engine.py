@@ -66,7 +66,7 @@ class PseudoBoxEngine:
                  views_per_chunk: int, dense: bool = True, cap_vox: int = 1 << 18,
                  pool_per_view: int = 1 << 16, rows_per_view: int = 64,
                  device="cuda:0", apply_fov: bool = True, lanes: int = 1, graphs: bool = False,
-                 chain: bool = False):
+                 chain: bool = False, free_lanes: bool = False):
         if not torch.cuda.is_available():
             raise Dfu3dError("PseudoBoxEngine needs a GPU (no CPU fallback)")
         # H, W: the canvas of the masks and the depth maps.  The in-bounds test of my_loader.py:526 is
@@ -96,8 +96,13 @@ class PseudoBoxEngine:
         # chain=True: every chunk is ONE C call (dfu3d_pseudo_boxes) that sequences the same stage entry
         # points over a single workspace -- what a non-Python host would bind.  Per-kernel timing needs the
         # stage-by-stage path, so `timing` overrides it.
+        # free_lanes=True (with lanes > 1, without graphs): every lane on a stream of its own and NO join between the lanes at the
+        # end of a pass -- a lane's next chunk waits for that lane's previous chunk only, the pass's handle carries one event per
+        # lane and collect() waits for those.  Lanes can then run out of step (one in the instruction-bound binning pass while the
+        # other is in the memory- and latency-bound stages) instead of being re-aligned at every pass.
         self.chain = bool(chain)
         self.graphs = bool(graphs)
+        self.free_lanes = bool(free_lanes) and int(lanes) > 1 and not self.graphs
         self._graph_key = None
         self._graph_state = None
         self.lanes = [self._make_lane(i, cap_n) for i in range(max(1, int(lanes)))]
@@ -113,7 +118,7 @@ class PseudoBoxEngine:
 
     def _make_lane(self, index, cap_n):
         L = PseudoBoxEngine._Lane()
-        L.stream = (torch.cuda.current_stream(self.dev) if index == 0 and not self.graphs
+        L.stream = (torch.cuda.current_stream(self.dev) if index == 0 and not self.graphs and not self.free_lanes
                     else torch.cuda.Stream(self.dev))
         with torch.cuda.stream(L.stream):
             V, S = self.Vc, self.Vc * self.M
@@ -400,7 +405,8 @@ class PseudoBoxEngine:
         n_rows = torch.zeros((nch,), dtype=torch.int32, device=d)
         status = torch.zeros((nch,), dtype=torch.int32, device=d)
         main = torch.cuda.current_stream(self.dev)
-        for L in self.lanes[1:]:
+        free = self.free_lanes and not self.timing
+        for L in (self.lanes if free else self.lanes[1:]):
             L.stream.wait_stream(main)              # inputs / row buffers are ready
             for t in (rows, n_rows, status):
                 t.record_stream(L.stream)
@@ -410,10 +416,20 @@ class PseudoBoxEngine:
             with torch.cuda.stream(L.stream if len(self.lanes) > 1 else main):
                 self._chunk(b, c * self.Vc, (c + 1) * self.Vc, rows[c], n_rows[c:c + 1],
                             status[c:c + 1])
-        for L in self.lanes[1:]:
-            main.wait_stream(L.stream)
-        done = torch.cuda.Event()
-        done.record(main)                           # the pass is complete here, whatever is enqueued behind it
+        if free:
+            done = []
+            for L in self.lanes[:min(nch, len(self.lanes))]:
+                e = torch.cuda.Event()
+                e.record(L.stream)                  # this lane's chunks of the pass are complete here
+                done.append(e)
+            if sync:
+                for e in done:
+                    main.wait_event(e)
+        else:
+            for L in self.lanes[1:]:
+                main.wait_stream(L.stream)
+            done = torch.cuda.Event()
+            done.record(main)                       # the pass is complete here, whatever is enqueued behind it
         self._last = (rows, n_rows, status, done)
         if not sync:
             return None, None
@@ -518,7 +534,8 @@ class PseudoBoxEngine:
         rows, n_rows, status = h[:3]
         if len(h) > 3 and h[3] is not None:
             cur = torch.cuda.current_stream(self.dev)
-            cur.wait_event(h[3])
+            for e in (h[3] if isinstance(h[3], (list, tuple)) else (h[3],)):
+                cur.wait_event(e)
             for t in (rows, n_rows, status):
                 t.record_stream(cur)
         both = torch.stack((n_rows, status)).cpu().numpy()        # the one host sync

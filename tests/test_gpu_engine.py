@@ -218,6 +218,20 @@ def test_timed_layout_matches_oracle_packed_masks_chunks_lanes_chain():
     h1 = eng.launch(b)
     rows1, st1 = eng.collect(h1)
     assert st1 == 0 and torch.equal(rows, rows1)
+    # free lanes (what bench.py times since round 4: no join between the lanes at the end of a pass, one event per lane in the
+    # handle), two passes in flight, collected under a stream of their own
+    free = PseudoBoxEngine(p, H, W, M, cap_n, views_per_chunk=12, dense=True, cap_vox=1 << 18, pool_per_view=1 << 17,
+                           lanes=2, chain=True, free_lanes=True)
+    hs = [free.launch(b), free.launch(b)]
+    side = torch.cuda.Stream()
+    for h in hs:
+        with torch.cuda.stream(side):
+            rows_f, st_f = free.collect(h)
+        side.synchronize()
+        assert st_f == 0 and torch.equal(rows, rows_f)
+    rows_fs, st_fs = free.run(b)                                       # and the synchronous form
+    assert st_fs == 0 and torch.equal(rows, rows_fs)
+    del free
     # the layout of `bench.py --byte-masks` -- the reference's np.uint8(mask) planes (V, M, H, W) as they cross the
     # boundary (my_loader.py:522-525), same chunks / lanes / chain -- gives the same rows bit for bit
     bb = synth.to_view_batch(scenes, p, DEV, dense=True)
