@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--compile-only", action="store_true")
+    ap.add_argument("--throughput", action="store_true",
+                    help="instead of the stage table: frames/s of the timed region's form (2 free lanes x 32-frame chunks, one C call per "
+                         "chunk, pass i+1 enqueued before pass i is collected under a side stream), wall clock over --passes passes")
     ap.add_argument("builds", nargs="+")
     args = ap.parse_args()
     from dfu3d_amd import _build
@@ -56,6 +59,50 @@ def main():
             fn = getattr(L, sym)
             fn.restype, fn.argtypes = res, a
         loaded[name] = L
+    if args.throughput:
+        import time
+        res = {n: [] for n, _ in libs}
+        ref = None
+        for rnd in range(args.rounds):
+            for name, _ in libs:
+                _lib._LIB = loaded[name]
+                eng = PseudoBoxEngine(p, 900, 1600, 8, 34720, views_per_chunk=args.frames * 6 // 2, dense=True, cap_vox=1 << 18,
+                                      pool_per_view=1 << 17, device=dev, lanes=2, chain=True, free_lanes=True)
+                side = torch.cuda.Stream()
+
+                def loop(k):
+                    pending, out = None, None
+                    for _ in range(k):
+                        h = eng.launch(b)
+                        if pending is not None:
+                            with torch.cuda.stream(side):
+                                out = eng.collect(pending)
+                            side.synchronize()
+                        pending = h
+                    with torch.cuda.stream(side):
+                        out = eng.collect(pending)
+                    side.synchronize()
+                    return out
+                rows, st_ = loop(3)
+                assert int(st_) == 0
+                if ref is None:
+                    ref = rows.clone()
+                same = rows.shape == ref.shape and bool(torch.equal(rows, ref))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(args.passes)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                fps = args.frames * args.passes / dt
+                res[name].append(fps)
+                print("round %d %-12s %s %.0f frames/s (%.3f ms per %d frames)" % (rnd, name, "rows_equal" if same else "ROWS DIFFER", fps,
+                                                                                   dt / args.passes * 1e3, args.frames), flush=True)
+                del eng
+                torch.cuda.empty_cache()
+        for name, _ in libs:
+            v = res[name]
+            print("  %-12s mean %.0f  min %.0f  max %.0f frames/s" % (name, sum(v) / len(v), min(v), max(v)))
+        return
     ref_rows = None
     differ = set()
     acc = {n: {} for n, _ in libs}
