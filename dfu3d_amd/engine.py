@@ -100,6 +100,8 @@ class PseudoBoxEngine:
         # end of a pass -- a lane's next chunk waits for that lane's previous chunk only, the pass's handle carries one event per
         # lane and collect() waits for those.  Lanes can then run out of step (one in the instruction-bound binning pass while the
         # other is in the memory- and latency-bound stages) instead of being re-aligned at every pass.
+        # (run(sync=True) still orders the calling stream behind the pass; after launch() the lanes' work is ordered behind nothing
+        # but collect(): call the other methods of the engine only when every pass in flight has been collected.)
         self.chain = bool(chain)
         self.graphs = bool(graphs)
         self.free_lanes = bool(free_lanes) and int(lanes) > 1 and not self.graphs
